@@ -1,0 +1,332 @@
+"""CPU oracle for the M2Trans training-step hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain-PyTorch (fp32/fp64, CPU) *restatement* of the arithmetic of the
+reference's hot path.  It is the checker for the HIP kernels, never the product:
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import it.  The product package ``m2trans_amd`` never imports anything from ``oracle/``.
+
+Pinning status: PINNED.  ``oracle/pin_against_reference.py`` imports the real reference
+(``/root/reference/models/M2Trans_network.py``, only available in the build container)
+and checks this restatement against it (forward, all parameter gradients, Adam step) and
+writes the golden fixtures under ``tests/golden/`` that ``tests/test_oracle_golden.py``
+re-checks without the reference.  The MedCLIP sub-path (``semantic_loss_value``) is
+"parity unpinned": the `medclip` package is not vendored in the reference (see
+``oracle/swin_oracle.py``).
+
+Every function cites the reference lines it restates (paths relative to the reference
+root).  The formulation is deliberately different from the reference's module code: it is
+functional, keyed by ``state_dict`` names, and builds the halo windows by explicit gather
+so that the zero-pad + relative-position semantics are spelled out.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+BLOCK = 8      # query window edge           (models/M2Trans_network.py:119-122, block_size=8)
+HALO = 1       # halo on each side           (models/M2Trans_network.py:119-122, halo_size=1)
+KWIN = BLOCK + 2 * HALO  # 10 -> 100 keys per window
+PAD_MULTIPLE = 32        # lcm(8,16,32)     (models/M2Trans_network.py:78-86)
+
+
+# --------------------------------------------------------------------------------------
+# parameter inventory  (models/M2Trans_network.py:17-56, 114-130, 267-288, 370-379)
+# --------------------------------------------------------------------------------------
+def branch_channels(n_feats: int) -> Tuple[int, int, int, int]:
+    """Channels of the four TBlocks of one CFTM (models/M2Trans_network.py:119-122)."""
+    return (n_feats // 4, n_feats, n_feats * 4, n_feats * 4)
+
+
+def param_shapes(n_feats: int = 64, scale: int = 4, n_blocks: int = 8, colors: int = 3
+                 ) -> "Dict[str, Tuple[int, ...]]":
+    """state_dict names -> shapes, in the reference's registration order (123 entries at
+    the shipped config: 4 frozen MeanShift tensors + 119 trainable)."""
+    s: Dict[str, Tuple[int, ...]] = {}
+    s["sub_mean.weight"] = (3, 3, 1, 1)
+    s["sub_mean.bias"] = (3,)
+    s["add_mean.weight"] = (3, 3, 1, 1)
+    s["add_mean.bias"] = (3,)
+    s["head.weight"] = (n_feats, colors, 3, 3)
+    s["head.bias"] = (n_feats,)
+    for b in range(n_blocks):
+        for i, c in enumerate(branch_channels(n_feats), start=1):
+            s[f"body.{b}.attn{i}.rel_h"] = (1, KWIN, 1, c // 2)
+            s[f"body.{b}.attn{i}.rel_w"] = (1, 1, KWIN, c // 2)
+            s[f"body.{b}.attn{i}.qkv_conv.weight"] = (3 * c, c, 1, 1)
+        s[f"body.{b}.feed_forward.0.weight"] = (n_feats, n_feats, 3, 3)
+        s[f"body.{b}.feed_forward.0.bias"] = (n_feats,)
+    if scale == 4:
+        s["tail.0.weight"] = (4 * n_feats, n_feats, 1, 1)
+        s["tail.0.bias"] = (4 * n_feats,)
+        s["tail.3.weight"] = (4 * n_feats, n_feats, 1, 1)
+        s["tail.3.bias"] = (4 * n_feats,)
+        s["tail.6.weight"] = (3, n_feats, 3, 3)
+    else:
+        s["tail.0.weight"] = (n_feats * scale * scale, n_feats, 1, 1)
+        s["tail.0.bias"] = (n_feats * scale * scale,)
+        s["tail.3.weight"] = (3, n_feats, 3, 3)
+    return s
+
+
+FROZEN = ("sub_mean.weight", "sub_mean.bias", "add_mean.weight", "add_mean.bias")
+
+
+def closed_form_params(n_feats=64, scale=4, n_blocks=8, colors=3, rgb_range=1.0,
+                       dtype=torch.float32, gain: float = 1.0) -> Params:
+    """Deterministic, RNG-free weights so every box regenerates the same tensors.
+
+    Magnitudes follow the reference's init distributions (conv: kaiming-uniform bound
+    1/sqrt(fan_in); qkv: kaiming-normal fan_out std sqrt(2/3C); rel-pos ~ N(0,1),
+    models/M2Trans_network.py:34,342-345) but values come from a sine sequence keyed by
+    the parameter's position in the inventory.
+    """
+    out: Params = {}
+    for k, (name, shp) in enumerate(param_shapes(n_feats, scale, n_blocks, colors).items()):
+        n = int(math.prod(shp))
+        idx = torch.arange(n, dtype=torch.float64)
+        base = torch.sin(idx * (0.61803398875 + 0.001 * k) + 0.37 * k) \
+            + 0.5 * torch.sin(idx * 1.7320508 + 1.1 * k)
+        if name in FROZEN:
+            if name.endswith("weight"):
+                v = torch.eye(3, dtype=torch.float64).reshape(3, 3, 1, 1)
+            else:
+                sign = -1.0 if name.startswith("sub") else 1.0
+                v = sign * rgb_range * torch.tensor([0.4488, 0.4371, 0.4040], dtype=torch.float64)
+            out[name] = v.to(dtype)
+            continue
+        if "rel_" in name:
+            amp = 0.8
+        elif "qkv_conv" in name:
+            amp = math.sqrt(2.0 / shp[0]) * 1.2
+        elif name.endswith("bias"):
+            amp = 0.05
+        else:
+            fan_in = shp[1] * shp[2] * shp[3]
+            amp = 1.0 / math.sqrt(fan_in) * 1.1
+        out[name] = (gain * amp * base).reshape(shp).to(dtype)
+    return out
+
+
+def closed_form_image(b: int, c: int, h: int, w: int, phase: float = 0.0,
+                      dtype=torch.float32) -> Tensor:
+    """Deterministic image in [0,1] (the reference feeds float32 NCHW in [0,1],
+    datas/us1k.py:169)."""
+    yy = torch.arange(h, dtype=torch.float64).view(1, 1, h, 1)
+    xx = torch.arange(w, dtype=torch.float64).view(1, 1, 1, w)
+    cc = torch.arange(c, dtype=torch.float64).view(1, c, 1, 1)
+    bb = torch.arange(b, dtype=torch.float64).view(b, 1, 1, 1)
+    v = 0.5 + 0.25 * torch.sin(0.37 * yy + 0.11 * xx * (1 + cc) + 0.9 * bb + phase) \
+        + 0.25 * torch.sin(0.23 * xx - 0.31 * yy + 1.3 * cc + 0.5 * bb * yy / h + 2 * phase)
+    return v.clamp(0, 1).to(dtype)
+
+
+# --------------------------------------------------------------------------------------
+# Haar DWT / IWT   (models/M2Trans_network.py:198-237)
+# --------------------------------------------------------------------------------------
+def dwt(x: Tensor) -> Tensor:
+    """[B,C,H,W] -> [B,4C,H/2,W/2], band-major (LL,HL,LH,HH) on channels
+    (models/M2Trans_network.py:203-209).  a,b,c,d = (even r, even c), (odd r, even c),
+    (even r, odd c), (odd r, odd c)."""
+    a = x[:, :, 0::2, 0::2]
+    b = x[:, :, 1::2, 0::2]
+    c = x[:, :, 0::2, 1::2]
+    d = x[:, :, 1::2, 1::2]
+    ll = 0.5 * (a + b + c + d)
+    hl = 0.5 * (-a - b + c + d)
+    lh = 0.5 * (-a + b - c + d)
+    hh = 0.5 * (a - b - c + d)
+    return torch.cat((ll, hl, lh, hh), dim=1)
+
+
+def iwt(x: Tensor) -> Tensor:
+    """[B,4C,h,w] -> [B,C,2h,2w]  (models/M2Trans_network.py:219-234)."""
+    B, C4, h, w = x.shape
+    C = C4 // 4
+    ll, hl, lh, hh = x[:, 0:C], x[:, C:2 * C], x[:, 2 * C:3 * C], x[:, 3 * C:4 * C]
+    out = x.new_zeros(B, C, 2 * h, 2 * w)
+    out[:, :, 0::2, 0::2] = 0.5 * (ll - hl - lh + hh)
+    out[:, :, 1::2, 0::2] = 0.5 * (ll - hl + lh - hh)
+    out[:, :, 0::2, 1::2] = 0.5 * (ll + hl - lh - hh)
+    out[:, :, 1::2, 1::2] = 0.5 * (ll + hl + lh + hh)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# halo window attention   (models/M2Trans_network.py:290-340 with sr=1, heads=1)
+# --------------------------------------------------------------------------------------
+def window_attention_core(q: Tensor, k: Tensor, v: Tensor, rel_h: Tensor, rel_w: Tensor
+                          ) -> Tensor:
+    """q,k,v: [B,C,h,w] (already projected).  Returns [B,C,h,w].
+
+    Restates models/M2Trans_network.py:310-332: 8x8 query windows, 10x10 key windows cut
+    from the ZERO-padded k/v planes (F.unfold padding=1), relative-position embedding
+    added to *every* one of the 100 keys -- including the zero-padded phantom ones, which
+    therefore take softmax mass with value 0 -- first C/2 channels get the
+    row embedding rel_h[r], last C/2 the column embedding rel_w[c] (:322-325).
+    """
+    B, C, h, w = q.shape
+    nh, nw = h // BLOCK, w // BLOCK
+    scale = float(C) ** -0.5                               # :311 (head_ch = C, heads = 1)
+    qw = q.view(B, C, nh, BLOCK, nw, BLOCK).permute(0, 2, 4, 3, 5, 1)   # B nh nw 8 8 C
+    qw = qw.reshape(B * nh * nw, BLOCK * BLOCK, C) * scale
+    kp = F.pad(k, (HALO, HALO, HALO, HALO))                # zero padding (:313 padding=halo)
+    vp = F.pad(v, (HALO, HALO, HALO, HALO))
+    # explicit gather of the 10x10 neighbourhoods: window (i,j) covers padded rows
+    # 8i..8i+9, cols 8j..8j+9
+    kw = kp.unfold(2, KWIN, BLOCK).unfold(3, KWIN, BLOCK)  # B C nh nw 10 10
+    vw = vp.unfold(2, KWIN, BLOCK).unfold(3, KWIN, BLOCK)
+    kw = kw.permute(0, 2, 3, 4, 5, 1).reshape(B * nh * nw, KWIN, KWIN, C)
+    vw = vw.permute(0, 2, 3, 4, 5, 1).reshape(B * nh * nw, KWIN * KWIN, C)
+    half = C // 2
+    bias = torch.cat((rel_h.reshape(1, KWIN, 1, half).expand(1, KWIN, KWIN, half),
+                      rel_w.reshape(1, 1, KWIN, half).expand(1, KWIN, KWIN, half)), dim=-1)
+    kw = (kw + bias).reshape(B * nh * nw, KWIN * KWIN, C)
+    sim = torch.bmm(qw, kw.transpose(1, 2))                # :328
+    attn = torch.softmax(sim, dim=-1)                      # :329
+    out = torch.bmm(attn, vw)                              # :331  [BL,64,C]
+    out = out.view(B, nh, nw, BLOCK, BLOCK, C).permute(0, 5, 1, 3, 2, 4)
+    return out.reshape(B, C, h, w)                         # :332
+
+
+def tblock(x: Tensor, p: Params, prefix: str) -> Tensor:
+    """TBlock.forward (models/M2Trans_network.py:290-340), sr=1, no pad branch."""
+    wq = p[prefix + "qkv_conv.weight"]
+    qkv = F.conv2d(x, wq)                                  # :307
+    q, k, v = torch.chunk(qkv, 3, dim=1)                   # :308
+    return window_attention_core(q, k, v, p[prefix + "rel_h"], p[prefix + "rel_w"])
+
+
+# --------------------------------------------------------------------------------------
+# CFTM and the full network   (models/M2Trans_network.py:58-86, 132-164)
+# --------------------------------------------------------------------------------------
+def instance_norm(x: Tensor, eps: float = 1e-5) -> Tensor:
+    """nn.InstanceNorm2d(nf): per-(b,c) biased variance, eps 1e-5, no affine
+    (models/M2Trans_network.py:127)."""
+    mu = x.mean(dim=(2, 3), keepdim=True)
+    var = x.var(dim=(2, 3), unbiased=False, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps)
+
+
+def cftm(x: Tensor, p: Params, prefix: str) -> Tensor:
+    """CFTM.forward, norm branch (models/M2Trans_network.py:132-164)."""
+    x1, x2, x3, x4 = torch.chunk(instance_norm(x), 4, dim=1)
+    x1 = tblock(x1, p, prefix + "attn1.") + x1
+    x2 = (x2 + x1) / 2.0
+    x2 = iwt(tblock(dwt(x2), p, prefix + "attn2.")) + x2
+    x3 = (x3 + x2) / 2.0
+    x3 = iwt(iwt(tblock(dwt(dwt(x3)), p, prefix + "attn3."))) + x3
+    x4 = (x4 + x3) / 2.0
+    x4 = iwt(iwt(tblock(dwt(dwt(x4)), p, prefix + "attn4."))) + x4
+    xc = torch.cat((x1, x2, x3, x4), dim=1)
+    return F.conv2d(xc, p[prefix + "feed_forward.0.weight"], p[prefix + "feed_forward.0.bias"],
+                    padding=1) + x                          # zero padding (:124-126,164)
+
+
+def pad_to_multiple(x: Tensor, m: int = PAD_MULTIPLE) -> Tensor:
+    """check_image_size (models/M2Trans_network.py:78-86): reflect pad right/bottom."""
+    h, w = x.shape[-2:]
+    ph, pw = (m - h % m) % m, (m - w % m) % m
+    if ph == 0 and pw == 0:
+        return x
+    return F.pad(x, (0, pw, 0, ph), mode="reflect")
+
+
+def conv3x3_reflect(x: Tensor, w: Tensor, b=None) -> Tensor:
+    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b)
+
+
+def tail(x: Tensor, p: Params, scale: int) -> Tensor:
+    """models/M2Trans_network.py:41-56."""
+    if scale == 4:
+        x = F.gelu(F.pixel_shuffle(F.conv2d(x, p["tail.0.weight"], p["tail.0.bias"]), 2))
+        x = F.gelu(F.pixel_shuffle(F.conv2d(x, p["tail.3.weight"], p["tail.3.bias"]), 2))
+        return conv3x3_reflect(x, p["tail.6.weight"])
+    x = F.gelu(F.pixel_shuffle(F.conv2d(x, p["tail.0.weight"], p["tail.0.bias"]), scale))
+    return conv3x3_reflect(x, p["tail.3.weight"])
+
+
+def forward(x: Tensor, p: Params, scale: int, n_blocks: int, rgb_range: float = 1.0,
+            return_preclamp: bool = False) -> Tensor:
+    """M2Trans.forward (models/M2Trans_network.py:58-76)."""
+    H, W = x.shape[-2:]
+    x = pad_to_multiple(x)
+    res = conv3x3_reflect(x, p["head.weight"], p["head.bias"])   # :63
+    y = res
+    for b in range(n_blocks):
+        y = cftm(y, p, f"body.{b}.")
+    y = res + y                                                  # :70
+    y = tail(y, p, scale)                                        # :72
+    if return_preclamp:
+        return y[:, :, : H * scale, : W * scale]
+    y = torch.clamp(y, 0.0, rgb_range)                           # :74
+    return y[:, :, : H * scale, : W * scale]                     # :76
+
+
+# --------------------------------------------------------------------------------------
+# train step   (train.py:76-82, 173-214, 358)
+# --------------------------------------------------------------------------------------
+def trainable_names(p: Params) -> List[str]:
+    return [k for k in p if k not in FROZEN]
+
+
+def l1_loss_and_grads(lr_img: Tensor, hr_img: Tensor, p: Params, scale: int, n_blocks: int,
+                      rgb_range: float = 1.0, lambda_l1: float = 1.0,
+                      loss_divisor: float | None = None):
+    """loss = lambda_l1 * mean|sr - hr|  (train.py:76,199); gradients by CPU autograd.
+    ``loss_divisor`` overrides the mean's denominator (data-parallel shards divide by the
+    GLOBAL element count so that the sum over ranks equals the full-batch gradient)."""
+    names = trainable_names(p)
+    leaves = {k: p[k].detach().clone().requires_grad_(True) for k in names}
+    q = dict(p)
+    q.update(leaves)
+    sr = forward(lr_img, q, scale, n_blocks, rgb_range)
+    if loss_divisor is None:
+        loss = (sr - hr_img).abs().mean() * lambda_l1
+    else:
+        loss = (sr - hr_img).abs().sum() / loss_divisor * lambda_l1
+    grads = torch.autograd.grad(loss, [leaves[k] for k in names])
+    return loss.detach(), sr.detach(), dict(zip(names, grads))
+
+
+def cosine_lr(epoch: int, lr0: float = 1e-4, eta_min: float = 1e-6, t_max: float = 200.0) -> float:
+    """CosineAnnealingLR closed form, stepped once per epoch (train.py:82,358)."""
+    return eta_min + 0.5 * (lr0 - eta_min) * (1.0 + math.cos(math.pi * epoch / t_max))
+
+
+def adam_update(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+                beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
+    """torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay=0) single-tensor
+    update (train.py:81,210).  ``step`` is the 1-based step count AFTER increment."""
+    m = beta1 * m + (1 - beta1) * grad
+    v = beta2 * v + (1 - beta2) * grad * grad
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    param = param - (lr / bc1) * (m / denom)
+    return param, m, v
+
+
+# --------------------------------------------------------------------------------------
+# metric   (utils.py:121-146,179-184; test.py:101-114 / train.py:299-312)
+# --------------------------------------------------------------------------------------
+def psnr_y(sr: Tensor, hr: Tensor, scale: int, rgb_range: float = 1.0) -> float:
+    """Y-channel PSNR exactly as the reference's eval loop computes it, including the
+    /255 inside rgb_to_ycbcr applied to inputs already in [0,1] (utils.py:136)."""
+    def y_of(img):
+        img = img / 255.0
+        return (65.481 * img[..., 0, :, :] + 128.553 * img[..., 1, :, :]
+                + 24.966 * img[..., 2, :, :] + 16.0).unsqueeze(-3)
+    s, h = y_of(sr), y_of(hr)
+    s = s[..., scale:-scale, scale:-scale]
+    h = h[..., scale:-scale, scale:-scale]
+    if rgb_range == 1:
+        s, h = s * 255.0, h * 255.0
+    diff = (s.double() - h.double()) / 255.0
+    mse = diff.pow(2).mean()
+    return float(-10.0 * math.log10(float(mse)))
