@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- M2Trans x4 train-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--dtype bf16|fp32]
+
+One "step" = one pass of the hot path (forward, L1 loss, backward, gradient all-reduce when
+N > 1, fused Adam) over one batch of synthetic 128x128 LR / 512x512 HR patches that are already
+resident in HBM.  For N > 1 launch under torch.distributed.run (one rank per GPU, RCCL); per-GPU
+batch is fixed (weak scaling); value = patches of ALL ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line (metric/value/... + "roofline" for the dominant kernel measured
+with HIP events inside the timed region + "cpu_baseline": the CPU oracle timed on the host).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (configs[1]: 16)")
+    ap.add_argument("--lr-size", type=int, default=128)
+    ap.add_argument("--scale", type=int, default=4)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+def synthetic_batch(B, h, scale, rank, step, device):
+    """U[0,1) LR and HR patches keyed by (seed 33, rank, step) -- train.py:40 uses seed 33."""
+    g = torch.Generator(device=device)
+    g.manual_seed(33 + 1000003 * rank + 7919 * step)
+    lr = torch.rand(B, 3, h, h, generator=g, device=device)
+    hr = torch.rand(B, 3, h * scale, h * scale, generator=g, device=device)
+    return lr, hr
+
+
+def cpu_baseline(args):
+    """The CPU oracle (plain PyTorch restatement pinned to the reference, oracle/) timed on the
+    host cores on a bounded sample: the same x4 128x128 train step at a small batch."""
+    from oracle import m2trans_oracle as O
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    B = args.cpu_baseline_batch
+    p = O.closed_form_params(64, args.scale, 8)
+    names = O.trainable_names(p)
+    m = {k: torch.zeros_like(p[k]) for k in names}
+    v = {k: torch.zeros_like(p[k]) for k in names}
+    g = torch.Generator().manual_seed(33)
+    x = torch.rand(B, 3, args.lr_size, args.lr_size, generator=g)
+    hr = torch.rand(B, 3, args.lr_size * args.scale, args.lr_size * args.scale, generator=g)
+
+    def one(step):
+        _, _, gr = O.l1_loss_and_grads(x, hr, p, args.scale, 8)
+        for k in names:
+            p[k], m[k], v[k] = O.adam_update(p[k], gr[k], m[k], v[k], step, 1e-4)
+
+    one(1)                          # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 8):
+        n += 1
+        one(n + 1)
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(B / dt, 4), "unit": "HR patches/s", "cores": ncores, "kind": "port",
+            "sample": f"x{args.scale} {args.lr_size}x{args.lr_size} LR train step (fwd+bwd+Adam, fp32), batch {B}, "
+                      f"{n} timed steps after 1 warm-up, torch CPU {torch.get_num_threads()} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from m2trans_amd import _lib
+    from m2trans_amd.M2Trans_network import create_model
+    from m2trans_amd.train_step import TrainStep
+    import types
+    _lib.load()
+    torch.manual_seed(33)
+    margs = types.SimpleNamespace(n_feats=64, scale=args.scale, rgb_range=1.0, n_blocks=8, colors=3,
+                                  compute_dtype=args.dtype)
+    model = create_model(margs).to(device)
+    ts = TrainStep(model, lr=1e-4, lambda_l1=1.0, process_group=pg, world_size=world)
+    B = args.batch
+    batches = [synthetic_batch(B, args.lr_size, args.scale, rank, s, device) for s in range(2)]
+
+    for s in range(args.warmup):
+        ts.step(*batches[s % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    prof = _lib.load()
+    have_prof = hasattr(prof, "m2t_profile_enable")
+    if have_prof:
+        prof.m2t_profile_enable(1)
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ts.step(*batches[s % 2])
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(ts.loss)
+    roofline = None
+    if have_prof:
+        from m2trans_amd.profile import roofline_report
+        roofline = roofline_report(args, B)
+        prof.m2t_profile_enable(0)
+
+    if rank == 0:
+        out = {
+            "metric": "train-step HR patches/sec at 128x128 LR x4",
+            "value": round(world * B * args.steps / dt, 3),
+            "unit": "HR patches/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic U[0,1) LR/HR patches resident in HBM, seed-33 reference init",
+            "config": {"workload": f"x{args.scale} SR train step (fwd + L1 + bwd + Adam), {args.lr_size}x{args.lr_size} LR "
+                                   f"patches, batch {B}/GPU, L1 loss only (BASELINE configs[1])",
+                       "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+/* m2t.h -- C ABI of libm2t.so: the MI355X (gfx950) implementation of the M2Trans
+ * data-parallel training-step hot path.
+ *
+ * The reference (eezkni/M2Trans) has no FFI: its hot path sits behind a Python plugin hook,
+ *     utils.import_module('models.M2Trans_network').create_model(args)      (train.py:70)
+ *     sr = model(lr)                                                         (train.py:183)
+ *     loss = L1Loss()(sr, hr) * lambda_l1 ; loss.backward() ; optimizer.step() (train.py:199-210)
+ * This library is what a drop-in `models/M2Trans_network.py` binds with ctypes
+ * (m2trans_amd/M2Trans_network.py; the binding a maintainer adds is shown in INTEGRATION.md).
+ * Every entry point takes plain device pointers, sizes and a hipStream_t; no torch types.
+ *
+ * Conventions
+ *   - return 0 on success, < 0 for argument errors (m2t_status), > 0 = hipError_t of a failed
+ *     launch; m2t_last_error_string() describes the last failure on the calling thread.
+ *     (The reference raises Python exceptions: `assert` M2Trans_network.py:305, ValueError
+ *     train.py:72, RuntimeError/KeyError M2Trans_network.py:100-112.)
+ *   - kernels never allocate, free or synchronise; the caller owns every buffer, including the
+ *     workspace whose size the plan reports.  All launches go to the given stream, so the whole
+ *     step can be captured in a HIP graph.
+ *   - tensors at the boundary use the reference's layout: NCHW float32, values in [0, rgb_range].
+ *     Internal activations are NHWC in `dtype` (0 = float32, exact-fp32 MFMA; 1 = bfloat16 MFMA
+ *     with fp32 accumulation / statistics / softmax / master weights).
+ *   - parameters live in ONE flat float32 buffer, the trainable tensors of the reference's
+ *     state_dict in registration order (head.weight, head.bias, body.0.attn1.rel_h, ...,
+ *     tail.*; the 4 frozen MeanShift tensors are not part of it -- they are never used by
+ *     forward, M2Trans_network.py:30-31,58-76).  Gradients use the same layout, which is what
+ *     makes the data-parallel exchange a single RCCL all-reduce.
+ */
+#ifndef M2T_H
+#define M2T_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct m2t_plan m2t_plan;
+
+enum m2t_status { M2T_OK = 0, M2T_ERR_ARG = -2, M2T_ERR_STATE = -3 };
+
+int m2t_version(void);
+const char* m2t_last_error_string(void);
+
+/* ---- plan: shapes, parameter offsets, workspace layout -------------------------------- */
+/* replaces M2Trans.__init__ (models/M2Trans_network.py:17-56) for fixed n_feats = 64, colors = 3.
+ * (B, H0, W0) = LR batch shape; the image is reflect-padded to multiples of 32 internally
+ * (check_image_size, :78-86). scale in {2,3,4}. */
+int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale, int n_blocks, int dtype);
+void m2t_plan_destroy(m2t_plan* p);
+/* named integer queries: "workspace_bytes", "num_params", "padded_h", "padded_w",
+ * "param:<state_dict name>" (offset in floats), "numel:<state_dict name>",
+ * "ws:<tensor>" (byte offset of a workspace tensor, e.g. "ws:b0.qkv3"), "wsn:<tensor>" (elements).
+ * Returns -1 for an unknown key. */
+long long m2t_plan_query(const m2t_plan* p, const char* key);
+/* one-time initialisation of the workspace (uploads the weight-packing table). */
+int m2t_plan_init_workspace(m2t_plan* p, void* workspace, void* stream);
+
+/* ---- model ----------------------------------------------------------------------------- */
+/* M2Trans.forward (models/M2Trans_network.py:58-76): x [B,3,H0,W0] -> sr [B,3,H0*s,W0*s].
+ * keep_activations != 0 saves what m2t_backward needs. */
+int m2t_forward(m2t_plan* p, const float* params, const float* x, float* sr, float rgb_range,
+                int keep_activations, void* workspace, void* stream);
+/* L1Loss()(sr, hr) * lambda_l1 (train.py:76,199) on the forward's output + the backward seed.
+ * loss_out: device float[1].  divisor = number of elements the mean runs over (pass the GLOBAL
+ * count B_global*3*Hs*Ws under data parallelism so that SUM-all-reduced gradients equal the
+ * full-batch gradient). */
+int m2t_l1_loss(m2t_plan* p, const float* hr, float lambda_l1, double divisor, float rgb_range,
+                float* loss_out, void* workspace, void* stream);
+/* alternative seed: an arbitrary upstream gradient g_sr [B,3,H0*s,W0*s] (torch autograd). */
+int m2t_set_output_grad(m2t_plan* p, const float* g_sr, float rgb_range, void* workspace, void* stream);
+/* loss.backward() (train.py:209) restricted to the model: fills grads (flat, same layout as
+ * params; every element is written). */
+int m2t_backward(m2t_plan* p, const float* params, const float* x, float* grads, void* workspace,
+                 void* stream);
+/* torch.optim.Adam(lr, betas, eps, weight_decay=0).step() (train.py:81,210), fused over the flat
+ * buffers; step = 1-based count; grad_scale multiplies g first (1/world_size after a SUM all-reduce). */
+int m2t_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                  float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
+/* ---- operators (NHWC tensors in `dtype` unless stated) ---------------------------------- */
+/* DWT.forward / IWT.forward (models/M2Trans_network.py:198-237), `levels` in {1,2} applied
+ * back-to-back; bit-exact in float32.  src [B,H,W,C] <-> dst [B,H/2^l,W/2^l,C*4^l]. */
+int m2t_dwt(int dtype, int levels, const void* src, void* dst, int B, int H, int W, int C, void* stream);
+int m2t_iwt(int dtype, int levels, const void* src, void* dst, int B, int H, int W, int C, void* stream);
+/* nn.PixelShuffle(r) / its inverse on NCHW float32 (models/M2Trans_network.py:43,46,53): bit-exact.
+ * in [B,C*r*r,H,W] -> out [B,C,H*r,W*r]. */
+int m2t_pixel_shuffle(const float* in, float* out, int B, int C, int H, int W, int r, void* stream);
+int m2t_pixel_unshuffle(const float* in, float* out, int B, int C, int H, int W, int r, void* stream);
+/* NCHW float32 -> NHWC dtype and back. */
+int m2t_to_nhwc(int dtype, const float* nchw, void* nhwc, int B, int C, int HW, void* stream);
+int m2t_to_nchw(int dtype, const void* nhwc, float* nchw, int B, int C, int HW, void* stream);
+/* TBlock.forward after the qkv projection (models/M2Trans_network.py:310-332):
+ * qkv [B,h,w,3C] (q|k|v), rel_h/rel_w float32 [10*C/2] -> out [B,h,w,C]; C in {16,64,256}. */
+int m2t_window_attention_fwd(int dtype, const void* qkv, const float* rel_h, const float* rel_w, void* out,
+                             int B, int h, int w, int C, void* stream);
+/* its autograd: gout [B,h,w,C] -> gqkv [B,h,w,3C], grel_h/grel_w float32 [10*C/2].
+ * scratch: m2t_window_attention_bwd_scratch_bytes(dtype,B,h,w,C) bytes. */
+size_t m2t_window_attention_bwd_scratch_bytes(int dtype, int B, int h, int w, int C);
+int m2t_window_attention_bwd(int dtype, const void* qkv, const float* rel_h, const float* rel_w, const void* gout,
+                             void* gqkv, float* grel_h, float* grel_w, void* scratch, int B, int h, int w, int C,
+                             void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,322 @@
+"""Drop-in replacement for the reference's ``models/M2Trans_network.py`` on MI355X.
+
+Same plugin surface as the reference (``create_model(args)`` resolved by module name,
+train.py:70; class ``M2Trans`` imported by test.py:16,66), same ``state_dict`` (123 entries,
+names/shapes/order of models/M2Trans_network.py:17-56), same ``forward`` contract
+(float32 NCHW in [0, rgb_range] -> float32 NCHW x scale, :58-76) -- but every device
+operation is a hand-written gfx950 kernel in ``libm2t.so`` reached through the C ABI of
+``include/m2t.h``.  PyTorch only owns the memory, the stream and (optionally) the autograd
+edge around the whole model.  There is no CPU / eager fallback: without the HIP library
+or a GPU tensor, ``forward`` raises.
+
+Differences that are deliberate (and invisible through the reference's own call sites):
+  * all trainable parameters are views into ONE flat float32 buffer (``model.flat_params``),
+    gradients likewise (``model.flat_grads``) -> fused Adam, single RCCL all-reduce;
+  * ``args.compute_dtype`` (optional, default "fp32"; or env M2T_COMPUTE_DTYPE) selects exact-fp32
+    MFMA or bf16 MFMA with fp32 accumulation/statistics/master weights.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import M2TError
+
+_BRANCH_C = (16, 64, 256, 256)
+
+
+def create_model(args):
+    """Reference hook: models/M2Trans_network.py:12-13."""
+    return M2Trans(args)
+
+
+class _Holder(nn.Module):
+    """A parameter container that only exists to reproduce the reference's state_dict names."""
+
+
+class Plan:
+    """m2t_plan + its workspace (one per (B, H0, W0, dtype))."""
+
+    def __init__(self, B: int, H0: int, W0: int, scale: int, n_blocks: int, dtype: int, device):
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.m2t_plan_create(C.byref(h), B, H0, W0, scale, n_blocks, dtype), "m2t_plan_create")
+        self.handle = h
+        self.B, self.H0, self.W0, self.scale, self.n_blocks, self.dtype = B, H0, W0, scale, n_blocks, dtype
+        self.device = device
+        self.gen = 0
+        nbytes = self.query("workspace_bytes")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            _lib.check(lib.m2t_plan_init_workspace(self.handle, _lib.ptr(self.workspace), _lib.stream_ptr()),
+                       "m2t_plan_init_workspace")
+
+    def query(self, key: str) -> int:
+        v = _lib.load().m2t_plan_query(self.handle, key.encode())
+        if v < 0:
+            raise KeyError(key)
+        return int(v)
+
+    def ws_tensor(self, name: str, shape=None, dtype=None) -> torch.Tensor:
+        """View of a named workspace tensor (tests / introspection)."""
+        off, n = self.query("ws:" + name), self.query("wsn:" + name)
+        if dtype is None:
+            dtype = torch.float32 if self.dtype == _lib.F32 else torch.bfloat16
+        es = torch.empty((), dtype=dtype).element_size()
+        t = self.workspace[off: off + n * es].view(dtype)
+        return t.view(shape) if shape is not None else t
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().m2t_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class _M2TransFunction(torch.autograd.Function):
+    """One autograd node around the whole network: forward = m2t_forward, backward =
+    m2t_set_output_grad + m2t_backward (hand-written kernels, no autograd graph inside)."""
+
+    @staticmethod
+    def forward(ctx, x, model, *params):
+        plan = model._plan_for(x)
+        sr = model._run_forward(plan, x, keep=True)
+        ctx.model, ctx.plan, ctx.gen = model, plan, plan.gen
+        ctx.save_for_backward(x)
+        return sr
+
+    @staticmethod
+    def backward(ctx, g_sr):
+        model, plan = ctx.model, ctx.plan
+        if ctx.gen != plan.gen:
+            raise M2TError("M2Trans.backward: the workspace of this shape was overwritten by a later forward; "
+                           "call backward before the next forward of the same shape")
+        (x,) = ctx.saved_tensors
+        lib = _lib.load()
+        g_sr = g_sr.contiguous().float()
+        with torch.cuda.device(x.device):
+            st = _lib.stream_ptr()
+            _lib.check(lib.m2t_set_output_grad(plan.handle, _lib.ptr(g_sr), float(model.rgb_range),
+                                               _lib.ptr(plan.workspace), st), "m2t_set_output_grad")
+            grads = torch.empty_like(model.flat_params)
+            _lib.check(lib.m2t_backward(plan.handle, _lib.ptr(model.flat_params), _lib.ptr(x), _lib.ptr(grads),
+                                        _lib.ptr(plan.workspace), st), "m2t_backward")
+        outs = [grads[o: o + n].view(s) for (o, n, s) in model._slots]
+        return (None, None, *outs)
+
+
+class M2Trans(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        n_feats = int(args.n_feats)
+        if n_feats != 64 or int(getattr(args, "colors", 3)) != 3:
+            raise M2TError("the gfx950 kernels are specialised for n_feats=64, colors=3 (every shipped config)")
+        self.scale = int(args.scale)
+        if self.scale not in (2, 3, 4):
+            raise M2TError("scale must be 2, 3 or 4")
+        self.window_sizes = [8, 16, 32]
+        self.rgb_range = float(args.rgb_range)
+        self.n_blocks = int(args.n_blocks)
+        cd = getattr(args, "compute_dtype", None) or os.environ.get("M2T_COMPUTE_DTYPE", "fp32")
+        self.compute_dtype = str(cd)
+        self._plans: Dict[Tuple, Plan] = {}
+        self._build_parameters(n_feats)
+        self._flatten()
+
+    # ------------------------------------------------------------------ parameters
+    def _build_parameters(self, nf: int):
+        """Create the parameters in the reference's construction order with the reference's
+        initialisers (models/M2Trans_network.py:30-56,119-126,277-288,342-345,370-379), so the
+        same torch seed yields the same initial weights."""
+        def conv(cin, cout, k, bias=True):
+            c = nn.Conv2d(cin, cout, kernel_size=k, bias=bias)      # default kaiming-uniform init
+            return c.weight.detach().clone(), (c.bias.detach().clone() if bias else None)
+
+        def mean_shift(sign):
+            conv(3, 3, 1)                                            # nn.Conv2d.__init__ consumes RNG first
+            h = _Holder()
+            std = torch.ones(3)
+            mean = torch.tensor([0.4488, 0.4371, 0.4040])
+            h.weight = nn.Parameter(torch.eye(3).view(3, 3, 1, 1) / std.view(3, 1, 1, 1), requires_grad=False)
+            h.bias = nn.Parameter(sign * self.rgb_range * mean / std, requires_grad=False)
+            return h
+
+        self.sub_mean = mean_shift(-1)
+        self.add_mean = mean_shift(1)
+        w, b = conv(3, nf, 3)
+        self.head = _Holder()
+        self.head.weight, self.head.bias = nn.Parameter(w), nn.Parameter(b)
+        self.body = nn.ModuleList()
+        for _ in range(self.n_blocks):
+            blk = _Holder()
+            for i, c in enumerate(_BRANCH_C, start=1):
+                a = _Holder()
+                a.rel_h = nn.Parameter(torch.randn(1, 10, 1, c // 2))
+                a.rel_w = nn.Parameter(torch.randn(1, 1, 10, c // 2))
+                wq, _ = conv(c, 3 * c, 1, bias=False)
+                a.qkv_conv = _Holder()
+                a.qkv_conv.weight = nn.Parameter(wq)
+                nn.init.kaiming_normal_(a.qkv_conv.weight, mode="fan_out", nonlinearity="relu")
+                nn.init.normal_(a.rel_h, 0, 1)
+                nn.init.normal_(a.rel_w, 0, 1)
+                setattr(blk, f"attn{i}", a)
+            w, b = conv(nf, nf, 3)
+            ff = _Holder()
+            ff.weight, ff.bias = nn.Parameter(w), nn.Parameter(b)
+            blk.feed_forward = nn.ModuleDict({"0": ff})
+            self.body.append(blk)
+        tail = OrderedDict()
+        if self.scale == 4:
+            for key in ("0", "3"):
+                w, b = conv(nf, nf * 4, 1)
+                h = _Holder()
+                h.weight, h.bias = nn.Parameter(w), nn.Parameter(b)
+                tail[key] = h
+            w, _ = conv(nf, 3, 3, bias=False)
+            h = _Holder()
+            h.weight = nn.Parameter(w)
+            tail["6"] = h
+        else:
+            w, b = conv(nf, nf * self.scale * self.scale, 1)
+            h = _Holder()
+            h.weight, h.bias = nn.Parameter(w), nn.Parameter(b)
+            tail["0"] = h
+            w, _ = conv(nf, 3, 3, bias=False)
+            h = _Holder()
+            h.weight = nn.Parameter(w)
+            tail["3"] = h
+        self.tail = nn.ModuleDict(tail)
+
+    def _trainable(self) -> List[Tuple[str, nn.Parameter]]:
+        return [(n, p) for n, p in self.named_parameters() if not n.startswith(("sub_mean", "add_mean"))]
+
+    def _flatten(self):
+        """(Re)build the flat fp32 parameter buffer and make every trainable parameter a view of it."""
+        named = self._trainable()
+        dev = named[0][1].device
+        for n, p in named:
+            if p.dtype != torch.float32:
+                raise M2TError("master parameters must stay float32 (use compute_dtype='bf16' for bf16 math)")
+        total = sum(p.numel() for _, p in named)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        slots, off = [], 0
+        for n, p in named:
+            k = p.numel()
+            flat[off: off + k].copy_(p.data.reshape(-1))
+            p.data = flat[off: off + k].view(p.shape)
+            slots.append((off, k, tuple(p.shape)))
+            off += k
+        self.flat_params = flat
+        self._slots = slots
+        self._names = [n for n, _ in named]
+        self.flat_grads = None
+        self._plans = {}
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flatten()
+        return out
+
+    def attach_flat_grads(self) -> torch.Tensor:
+        """Make every p.grad a view of one flat buffer (what the fused step driver uses)."""
+        if self.flat_grads is None or self.flat_grads.device != self.flat_params.device:
+            self.flat_grads = torch.zeros_like(self.flat_params)
+            for (n, p), (o, k, s) in zip(self._trainable(), self._slots):
+                p.grad = self.flat_grads[o: o + k].view(s)
+        return self.flat_grads
+
+    def param_offsets(self) -> Dict[str, Tuple[int, int]]:
+        return {n: (o, k) for n, (o, k, _) in zip(self._names, self._slots)}
+
+    # ------------------------------------------------------------------ state dict
+    def load_state_dict(self, state_dict, strict=False):
+        """Behaves like the reference's lenient loader (models/M2Trans_network.py:88-112):
+        copies matching names, tolerates a mismatching ``tail`` (different scale), raises on
+        any other shape mismatch; additionally strips DataParallel's ``module.`` prefix that
+        the reference's checkpoints carry (train.py:73,345)."""
+        own = self.state_dict()
+        seen = set()
+        for name, value in state_dict.items():
+            if name.startswith("module."):
+                name = name[len("module."):]
+            seen.add(name)
+            if name not in own:
+                if strict and "tail" not in name:
+                    raise KeyError('unexpected key "{}" in state_dict'.format(name))
+                continue
+            value = value.data if isinstance(value, nn.Parameter) else value
+            if tuple(own[name].shape) != tuple(value.shape):
+                if "tail" in name:
+                    print("Replace pre-trained upsampler to new one...")
+                    continue
+                raise RuntimeError("While copying the parameter named {}, whose dimensions in the model are {} "
+                                   "and whose dimensions in the checkpoint are {}.".format(
+                                       name, tuple(own[name].shape), tuple(value.shape)))
+            own[name].copy_(value)
+        if strict:
+            missing = set(own.keys()) - seen
+            if missing:
+                raise KeyError('missing keys in state_dict: "{}"'.format(missing))
+
+    # ------------------------------------------------------------------ forward
+    def _dtype_code(self) -> int:
+        if self.compute_dtype in ("fp32", "float32", "f32"):
+            return _lib.F32
+        if self.compute_dtype in ("bf16", "bfloat16"):
+            return _lib.BF16
+        raise M2TError(f"unknown compute_dtype {self.compute_dtype!r}")
+
+    def _plan_for(self, x: torch.Tensor) -> Plan:
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise M2TError("expected input of shape [B,3,H,W]")
+        if not x.is_cuda:
+            raise M2TError("M2Trans (MI355X build) runs only on a HIP device tensor; there is no CPU fallback")
+        if self.flat_params.device != x.device:
+            raise M2TError(f"model parameters are on {self.flat_params.device}, input on {x.device}")
+        B, _, H0, W0 = x.shape
+        key = (B, H0, W0, self._dtype_code(), x.device.index)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = Plan(B, H0, W0, self.scale, self.n_blocks, key[3], x.device)
+            if plan.query("num_params") != self.flat_params.numel():
+                raise M2TError("parameter inventory of the library and of the module differ")
+            for n, (o, k, _) in zip(self._names, self._slots):
+                if plan.query("param:" + n) != o or plan.query("numel:" + n) != k:
+                    raise M2TError(f"parameter layout mismatch for {n}")
+            self._plans[key] = plan
+        return plan
+
+    def _run_forward(self, plan: Plan, x: torch.Tensor, keep: bool, want_sr: bool = True):
+        lib = _lib.load()
+        x = x.contiguous().float()
+        B, _, H0, W0 = x.shape
+        sr = torch.empty(B, 3, H0 * self.scale, W0 * self.scale, dtype=torch.float32, device=x.device) if want_sr else None
+        plan.gen += 1
+        with torch.cuda.device(x.device):
+            _lib.check(lib.m2t_forward(plan.handle, _lib.ptr(self.flat_params), _lib.ptr(x), _lib.ptr(sr),
+                                       float(self.rgb_range), 1 if keep else 0, _lib.ptr(plan.workspace),
+                                       _lib.stream_ptr()), "m2t_forward")
+        return sr
+
+    def forward(self, x):
+        plan_needed_grad = torch.is_grad_enabled() and any(p.requires_grad for _, p in self._trainable())
+        if plan_needed_grad:
+            params = [p for _, p in self._trainable()]
+            return _M2TransFunction.apply(x, self, *params)
+        return self._run_forward(self._plan_for(x), x, keep=False)
+
+    def check_image_size(self, x):
+        """Kept for API parity (models/M2Trans_network.py:78-86); the kernels pad by index math."""
+        _, _, h, w = x.size()
+        wsize = 32
+        ph, pw = (wsize - h % wsize) % wsize, (wsize - w % wsize) % wsize
+        return torch.nn.functional.pad(x, (0, pw, 0, ph), "reflect")

@@ -1,0 +1,631 @@
+// k_attn.hip -- 8x8-query / 10x10-key halo window attention on the matrix cores (gfx950).
+//
+// Restates TBlock.forward after the qkv projection (models/M2Trans_network.py:310-332) and
+// its autograd:
+//   * one workgroup = one window; 4 waves x 16 queries; the 100 keys are padded to 7 tiles
+//     of 16 (the 12 pad keys are masked out of the softmax);
+//   * keys outside the image are NOT masked: they are the zero-padding of F.unfold, so their
+//     key vector is the relative-position embedding alone and their value is 0 (:313-325);
+//   * S^T = K^ Q^T is computed "swapped" (keys on the MFMA rows, queries on the lanes) so a
+//     query's softmax row sits in the 4 lanes {q, q+16, q+32, q+48} and the probabilities are
+//     directly the B operand of O^T = V^T P^T -- no LDS round trip for P;
+//   * V^T / K^T / Q^T / dO^T operands are staged transposed in LDS (key- or query-contiguous);
+//   * large C is processed in 64-channel chunks so the same code serves C = 16, 64, 256 in
+//     fp32 and bf16 inside 160 KB of LDS.
+#include "m2t_kernels.h"
+
+#define WA_NK 100
+#define WA_KT 7          // key tiles (112 keys)
+#define WA_KP 136        // transposed row length (128 keys + 8 pad)
+#define WA_QP 72         // 64 queries + 8 pad
+
+template <typename T> __device__ __forceinline__ Frag8<T> load4x2(const T* p0, const T* p1);
+template <> __device__ __forceinline__ Frag8<float> load4x2(const float* p0, const float* p1) {
+  Frag8<float> f;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p0);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p1);
+  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+  return f;
+}
+template <> __device__ __forceinline__ Frag8<bf16_t> load4x2(const bf16_t* p0, const bf16_t* p1) {
+  Frag8<bf16_t> f;
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(p0);
+  const bf16x4 b = *reinterpret_cast<const bf16x4*>(p1);
+  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+  return f;
+}
+
+struct WinGeom {
+  int h, w, nw, nh;
+  int b, wy, wx;
+  __device__ __forceinline__ bool key_pixel(int key, long long& pix) const {
+    const int kr = key / 10, kc = key - kr * 10;
+    const int y = 8 * wy + kr - 1, x = 8 * wx + kc - 1;
+    pix = ((long long)b * h + y) * w + x;
+    return (y >= 0 && y < h && x >= 0 && x < w);
+  }
+  __device__ __forceinline__ long long query_pixel(int q) const {
+    return ((long long)b * h + 8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
+  }
+};
+__device__ __forceinline__ WinGeom make_geom(int h, int w) {
+  WinGeom g;
+  g.h = h; g.w = w; g.nw = w / 8; g.nh = h / 8;
+  const int wi = blockIdx.x;
+  g.wx = wi % g.nw;
+  const int q = wi / g.nw;
+  g.wy = q % g.nh;
+  g.b = q / g.nh;
+  return g;
+}
+
+// stage K^ chunk (keys x CW channels, row-major, rel-pos added, pad keys / pad channels = 0)
+template <typename T, int C, int CC, int CW>
+__device__ __forceinline__ void stage_khat(T (*Ks)[CW + 8], const T* __restrict__ qkv, const float* __restrict__ rel_h,
+                                           const float* __restrict__ rel_w, const WinGeom& gm, int c0, int tid) {
+  constexpr int VEC = CW / 8;
+  for (int idx = tid; idx < WA_KT * 16 * VEC; idx += 256) {
+    const int cv = idx % VEC, key = idx / VEC;
+    const int c = cv * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (key < WA_NK && c < CC) {
+      long long pix;
+      if (gm.key_pixel(key, pix)) load8f(qkv + pix * (3 * C) + C + c0 + c, v);
+      const int kr = key / 10, kc = key - kr * 10;
+      const int cc = c0 + c;
+      const float* rp = (cc < C / 2) ? (rel_h + kr * (C / 2) + cc) : (rel_w + kc * (C / 2) + (cc - C / 2));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rp[e];
+    }
+    store8f(&Ks[key][c], v);
+  }
+}
+// stage a row-major chunk of keys x CW channels from channel offset `coff` of qkv (V rows), zero outside
+template <typename T, int C, int CC, int CW>
+__device__ __forceinline__ void stage_keys_rows(T (*Vs)[CW + 8], const T* __restrict__ qkv, int coff, const WinGeom& gm,
+                                                int c0, int tid) {
+  constexpr int VEC = CW / 8;
+  for (int idx = tid; idx < WA_KT * 16 * VEC; idx += 256) {
+    const int cv = idx % VEC, key = idx / VEC;
+    const int c = cv * 8;
+    Frag8<T> f = frag_zero<T>();
+    long long pix;
+    if (key < WA_NK && c < CC && gm.key_pixel(key, pix)) f = load8(qkv + pix * (3 * C) + coff + c0 + c);
+    store8(&Vs[key][c], f);
+  }
+}
+// stage TRANSPOSED key-side chunk: dst[c][key] for keys < 100 (pad keys must be pre-zeroed);
+// with_rel adds the relative-position embedding (K^)
+template <typename T, int C, int CC, bool WITH_REL>
+__device__ __forceinline__ void stage_keys_T(T (*dst)[WA_KP], const T* __restrict__ qkv, int coff,
+                                             const float* __restrict__ rel_h, const float* __restrict__ rel_w,
+                                             const WinGeom& gm, int c0, int tid) {
+  constexpr int VEC = CC / 8;
+  for (int idx = tid; idx < 128 * VEC; idx += 256) {
+    const int key = idx & 127, cv = idx >> 7;
+    if (key >= WA_NK) continue;
+    const int c = cv * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    long long pix;
+    if (gm.key_pixel(key, pix)) load8f(qkv + pix * (3 * C) + coff + c0 + c, v);
+    if (WITH_REL) {
+      const int kr = key / 10, kc = key - kr * 10;
+      const int cc = c0 + c;
+      const float* rp = (cc < C / 2) ? (rel_h + kr * (C / 2) + cc) : (rel_w + kc * (C / 2) + (cc - C / 2));
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rp[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[c + e][key] = from_f<T>(v[e]);
+  }
+}
+// stage TRANSPOSED query-side chunk: dst[c][q] = src[query pixel][coff + c0 + c]
+template <typename T, int CC>
+__device__ __forceinline__ void stage_queries_T(T (*dst)[WA_QP], const T* __restrict__ src, int ld, int coff,
+                                                const WinGeom& gm, int c0, int tid) {
+  constexpr int VEC = CC / 8;
+  for (int idx = tid; idx < 64 * VEC; idx += 256) {
+    const int q = idx & 63, cv = idx >> 6;
+    const Frag8<T> f = load8(src + gm.query_pixel(q) * ld + coff + c0 + cv * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[cv * 8 + e][q] = f.v_elem(e);
+  }
+}
+
+// row permutation of a 64-row operand so that a lane's accumulators over the 4 row tiles
+// are 16 consecutive rows (16 g + 4 mt + r); identity when there is a single tile
+template <int NT> __device__ __forceinline__ int perm_row(int mt, int i) {
+  return (NT == 4) ? (16 * (i >> 2) + 4 * mt + (i & 3)) : i;
+}
+
+// =======================================================================================
+// forward
+// =======================================================================================
+template <typename T, int C>
+__global__ void __launch_bounds__(256) window_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                              const float* __restrict__ rel_w, T* __restrict__ out, int ldo,
+                                                              int oc0, const T* __restrict__ res, int ldr, int h, int w) {
+  constexpr int CC = (C < 64) ? C : 64;       // channels per chunk
+  constexpr int CW = (CC < 32) ? 32 : CC;     // staged width (MFMA k-chunk is 32)
+  constexpr int NCH = C / CC;
+  constexpr int NT = CC / 16;
+  __shared__ __attribute__((aligned(16))) T Ks[WA_KT * 16][CW + 8];
+  __shared__ __attribute__((aligned(16))) T VT[CC][WA_KP];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const WinGeom gm = make_geom(h, w);
+  const int q = 16 * wv + lr;
+  const long long qpix = gm.query_pixel(q);
+
+  // zero the key padding of VT once (keys 100..135 are never written by the stagers)
+  for (int idx = tid; idx < CC * (WA_KP - WA_NK); idx += 256) {
+    const int r = idx / (WA_KP - WA_NK), k = WA_NK + idx % (WA_KP - WA_NK);
+    VT[r][k] = from_f<T>(0.f);
+  }
+
+  // ---- S^T = K^ Q^T ----
+  f32x4 s[WA_KT];
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = ch * CC;
+    __syncthreads();
+    stage_khat<T, C, CC, CW>(Ks, qkv, rel_h, rel_w, gm, c0, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < CW / 32; ++kc) {
+      Frag8<T> qf = frag_zero<T>();
+      if (kc * 32 + 8 * g < CC) qf = load8(qkv + qpix * (3 * C) + c0 + kc * 32 + 8 * g);
+#pragma unroll
+      for (int t = 0; t < WA_KT; ++t) {
+        const Frag8<T> kf = load8(&Ks[16 * t + lr][kc * 32 + 8 * g]);
+        mma16(s[t], kf, qf);
+      }
+    }
+  }
+  // ---- softmax over the 100 real keys; lane (q, g) holds keys 16 t + 4 g + r ----
+  const float scale = rsqrtf((float)C);   // head_ch ** -0.5 (:311); a power of two for C = 16, 64, 256
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * t + 4 * g + r;
+      s[t][r] = (key < WA_NK) ? s[t][r] * scale : -3.0e38f;
+      mx = fmaxf(mx, s[t][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * t + 4 * g + r;
+      const float e = (key < WA_NK) ? __expf(s[t][r] - mx) : 0.f;
+      s[t][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  // P as the B operand: k-chunk c4 covers key tiles 2c4, 2c4+1; slot (g, j) <-> key 16(2c4 + (j>>2)) + 4g + (j&3)
+  Frag8<T> pf[4];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = 2 * c4 + (j >> 2);
+      pf[c4].set(j, (t < WA_KT) ? s[t < WA_KT ? t : 0][j & 3] * inv : 0.f);
+    }
+
+  // ---- O^T = V^T P^T, 64 output channels at a time ----
+#pragma unroll 1
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = ch * CC;
+    __syncthreads();
+    stage_keys_T<T, C, CC, false>(VT, qkv, 2 * C, nullptr, nullptr, gm, c0, tid);
+    __syncthreads();
+    f32x4 o[NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) o[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) {
+        const int d = perm_row<NT>(mt, lr);
+        const Frag8<T> vf = load4x2(&VT[d][32 * c4 + 4 * g], &VT[d][32 * c4 + 16 + 4 * g]);
+        mma16(o[mt], vf, pf[c4]);
+      }
+    // lane (q, g): NT == 4 -> channels c0 + 16 g + 4 mt + r ; NT == 1 -> c0 + 4 g + r
+    if (NT == 4) {
+      float v[16];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * mt + r] = o[mt][r];
+      if (res) {
+        float p[16];
+        load16f(res + qpix * ldr + c0 + 16 * g, p);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += p[e];
+      }
+      store16f(out + qpix * ldo + oc0 + c0 + 16 * g, v);
+    } else {
+      float v[4] = {o[0][0], o[0][1], o[0][2], o[0][3]};
+      if (res) {
+        float p[4];
+        load4(res + qpix * ldr + c0 + 4 * g, p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p[e];
+      }
+      store4(out + qpix * ldo + oc0 + c0 + 4 * g, v);
+    }
+  }
+}
+
+int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0,
+                           const void* res, int ldr, int B, int h, int w, int C, hipStream_t st) {
+  if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn: h,w must be multiples of 8");
+  const int nwin = B * (h / 8) * (w / 8);
+#define GO(T_, C_) hipLaunchKernelGGL((window_attn_fwd_kernel<T_, C_>), dim3(nwin), dim3(256), 0, st, (const T_*)qkv, rel_h, rel_w, (T_*)out, ldo, oc0, (const T_*)res, ldr, h, w)
+  if (dt == M2T_F32) {
+    if (C == 16) GO(float, 16); else if (C == 64) GO(float, 64); else if (C == 256) GO(float, 256);
+    else return m2t_set_error(-2, "window_attn: C must be 16, 64 or 256");
+  } else {
+    if (C == 16) GO(bf16_t, 16); else if (C == 64) GO(bf16_t, 64); else if (C == 256) GO(bf16_t, 256);
+    else return m2t_set_error(-2, "window_attn: C must be 16, 64 or 256");
+  }
+#undef GO
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// backward: per window, recompute S and P, then
+//   dP = dO V^T ; delta = rowsum(P * dP) ; dS = P * (dP - delta) * scale
+//   dq = dS K^ ; dK^ = dS^T q ; dV = P^T dO
+// dq goes straight to gqkv[..., 0:C]; dK^ / dV go to the window-major scratch `win`
+// [B*L][100][2C] (dK^ | dV) that halo_gather sums over the <= 4 windows covering a pixel.
+// =======================================================================================
+template <typename T, int C>
+__global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                              const float* __restrict__ rel_w, const T* __restrict__ go,
+                                                              int ldg, int gc0, T* __restrict__ gqkv, T* __restrict__ win,
+                                                              int h, int w) {
+  constexpr int CC = (C < 64) ? C : 64;
+  constexpr int CW = (CC < 32) ? 32 : CC;
+  constexpr int NCH = C / CC;
+  constexpr int NT = CC / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // region A (phase 1): Ks, Vs row-major [112][CW+8];  (phase 2): KT[CC][136], DOT[CC][72], QT[CC][72]
+  // region B: PT[112][72], DST[112][72]
+  constexpr size_t szA1 = 2 * sizeof(T) * (WA_KT * 16) * (CW + 8);
+  constexpr size_t szA2 = sizeof(T) * CC * (WA_KP + 2 * WA_QP);
+  constexpr size_t szA = (szA1 > szA2 ? szA1 : szA2);
+  T(*Ks)[CW + 8] = reinterpret_cast<T(*)[CW + 8]>(smem);
+  T(*Vs)[CW + 8] = reinterpret_cast<T(*)[CW + 8]>(smem + sizeof(T) * (WA_KT * 16) * (CW + 8));
+  T(*KT)[WA_KP] = reinterpret_cast<T(*)[WA_KP]>(smem);
+  T(*DOT)[WA_QP] = reinterpret_cast<T(*)[WA_QP]>(smem + sizeof(T) * CC * WA_KP);
+  T(*QT)[WA_QP] = reinterpret_cast<T(*)[WA_QP]>(smem + sizeof(T) * CC * (WA_KP + WA_QP));
+  T(*PT)[WA_QP] = reinterpret_cast<T(*)[WA_QP]>(smem + szA);
+  T(*DST)[WA_QP] = reinterpret_cast<T(*)[WA_QP]>(smem + szA + sizeof(T) * (WA_KT * 16) * WA_QP);
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const WinGeom gm = make_geom(h, w);
+  const int q = 16 * wv + lr;
+  const long long qpix = gm.query_pixel(q);
+
+  // ---- phase 1: S^T = K^ Q^T and dP^T = V dO^T, accumulated over channel chunks ----
+  f32x4 s[WA_KT], dp[WA_KT];
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) { s[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll 1
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = ch * CC;
+    __syncthreads();
+    stage_khat<T, C, CC, CW>(Ks, qkv, rel_h, rel_w, gm, c0, tid);
+    stage_keys_rows<T, C, CC, CW>(Vs, qkv, 2 * C, gm, c0, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < CW / 32; ++kc) {
+      Frag8<T> qf = frag_zero<T>(), gf = frag_zero<T>();
+      if (kc * 32 + 8 * g < CC) {
+        qf = load8(qkv + qpix * (3 * C) + c0 + kc * 32 + 8 * g);
+        gf = load8(go + qpix * ldg + gc0 + c0 + kc * 32 + 8 * g);
+      }
+#pragma unroll
+      for (int t = 0; t < WA_KT; ++t) {
+        const Frag8<T> kf = load8(&Ks[16 * t + lr][kc * 32 + 8 * g]);
+        mma16(s[t], kf, qf);
+        const Frag8<T> vf = load8(&Vs[16 * t + lr][kc * 32 + 8 * g]);
+        mma16(dp[t], vf, gf);
+      }
+    }
+  }
+  // ---- softmax and dS ----
+  const float scale = rsqrtf((float)C);
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * t + 4 * g + r;
+      s[t][r] = (key < WA_NK) ? s[t][r] * scale : -3.0e38f;
+      mx = fmaxf(mx, s[t][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * t + 4 * g + r;
+      const float e = (key < WA_NK) ? __expf(s[t][r] - mx) : 0.f;
+      s[t][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  float delta = 0.f;
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[t][r] *= inv;                       // P
+      delta += s[t][r] * dp[t][r];
+    }
+  delta += __shfl_xor(delta, 16);
+  delta += __shfl_xor(delta, 32);
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dp[t][r] = s[t][r] * (dp[t][r] - delta) * scale;   // dS (scale folded)
+  // P^T and dS^T to LDS ([key][q]); dS also stays in registers as the B operand of dq
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      PT[16 * t + 4 * g + r][q] = from_f<T>(s[t][r]);
+      DST[16 * t + 4 * g + r][q] = from_f<T>(dp[t][r]);
+    }
+  Frag8<T> dsf[4];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = 2 * c4 + (j >> 2);
+      dsf[c4].set(j, (t < WA_KT) ? dp[t < WA_KT ? t : 0][j & 3] : 0.f);
+    }
+  __syncthreads();   // phase-1 reads of Ks/Vs done; PT/DST visible after the next barrier too
+  // zero the key padding of KT once
+  for (int idx = tid; idx < CC * (WA_KP - WA_NK); idx += 256) {
+    const int r = idx / (WA_KP - WA_NK), k = WA_NK + idx % (WA_KP - WA_NK);
+    KT[r][k] = from_f<T>(0.f);
+  }
+  const long long wbase = (long long)blockIdx.x * WA_NK * (2 * C);
+
+  // ---- phase 2: per 64-channel chunk: dq^T = K^^T dS^T ; dV^T = dO^T P ; dK^^T = q^T dS ----
+#pragma unroll 1
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = ch * CC;
+    if (ch > 0) __syncthreads();
+    stage_keys_T<T, C, CC, true>(KT, qkv, C, rel_h, rel_w, gm, c0, tid);
+    stage_queries_T<T, CC>(DOT, go, ldg, gc0, gm, c0, tid);
+    stage_queries_T<T, CC>(QT, qkv, 3 * C, 0, gm, c0, tid);
+    __syncthreads();
+    // dq for this wave's 16 queries
+    {
+      f32x4 o[NT];
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) o[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+          const int d = perm_row<NT>(mt, lr);
+          const Frag8<T> kf = load4x2(&KT[d][32 * c4 + 4 * g], &KT[d][32 * c4 + 16 + 4 * g]);
+          mma16(o[mt], kf, dsf[c4]);
+        }
+      if (NT == 4) {
+        float v[16];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * mt + r] = o[mt][r];
+        store16f(gqkv + qpix * (3 * C) + c0 + 16 * g, v);
+      } else {
+        float v[4] = {o[0][0], o[0][1], o[0][2], o[0][3]};
+        store4(gqkv + qpix * (3 * C) + c0 + 4 * g, v);
+      }
+    }
+    // dV^T and dK^^T: wave wv owns key tiles wv and wv + 4
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = wv + 4 * tt;
+      if (t >= WA_KT) break;
+      f32x4 av[NT], ak[NT];
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) { av[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ak[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        const Frag8<T> pfr = load8(&PT[16 * t + lr][32 * kc + 8 * g]);     // B: cols = keys, k = queries
+        const Frag8<T> dfr = load8(&DST[16 * t + lr][32 * kc + 8 * g]);
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) {
+          const int d = perm_row<NT>(mt, lr);
+          const Frag8<T> gof = load8(&DOT[d][32 * kc + 8 * g]);            // A: rows = channels
+          mma16(av[mt], gof, pfr);
+          const Frag8<T> qf = load8(&QT[d][32 * kc + 8 * g]);
+          mma16(ak[mt], qf, dfr);
+        }
+      }
+      const int key = 16 * t + lr;
+      if (key < WA_NK) {
+        T* wp = win + wbase + (long long)key * (2 * C);
+        if (NT == 4) {
+          float v[16], u[16];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[4 * mt + r] = ak[mt][r]; u[4 * mt + r] = av[mt][r]; }
+          store16f(wp + c0 + 16 * g, v);
+          store16f(wp + C + c0 + 16 * g, u);
+        } else {
+          float v[4] = {ak[0][0], ak[0][1], ak[0][2], ak[0][3]};
+          float u[4] = {av[0][0], av[0][1], av[0][2], av[0][3]};
+          store4(wp + c0 + 4 * g, v);
+          store4(wp + C + c0 + 4 * g, u);
+        }
+      }
+    }
+  }
+}
+
+// sum the per-window dK^ / dV rows over the (<= 4) windows whose 10x10 neighbourhood covers a pixel
+template <typename T>
+__global__ void __launch_bounds__(256) halo_gather_kernel(const T* __restrict__ win, T* __restrict__ gqkv, int B, int h,
+                                                          int w, int C) {
+  const int nv = 2 * C / 8;
+  const int nh = h / 8, nw = w / 8;
+  const long long total = (long long)B * h * w * nv;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(t % nv);
+    const long long pix = t / nv;
+    const int x = (int)(pix % w);
+    const long long q = pix / w;
+    const int y = (int)(q % h);
+    const int b = (int)(q / h);
+    int wys[2], krs[2], ny = 1, wxs[2], kcs[2], nx = 1;
+    wys[0] = y >> 3; krs[0] = (y & 7) + 1;
+    if ((y & 7) == 0 && wys[0] > 0) { wys[1] = wys[0] - 1; krs[1] = 9; ny = 2; }
+    else if ((y & 7) == 7 && wys[0] < nh - 1) { wys[1] = wys[0] + 1; krs[1] = 0; ny = 2; }
+    wxs[0] = x >> 3; kcs[0] = (x & 7) + 1;
+    if ((x & 7) == 0 && wxs[0] > 0) { wxs[1] = wxs[0] - 1; kcs[1] = 9; nx = 2; }
+    else if ((x & 7) == 7 && wxs[0] < nw - 1) { wxs[1] = wxs[0] + 1; kcs[1] = 0; nx = 2; }
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int a = 0; a < ny; ++a)
+      for (int c = 0; c < nx; ++c) {
+        const long long wi = ((long long)b * nh + wys[a]) * nw + wxs[c];
+        const int key = krs[a] * 10 + kcs[c];
+        float v[8];
+        load8f(win + (wi * WA_NK + key) * (2 * C) + cv * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += v[e];
+      }
+    store8f(gqkv + pix * (3 * C) + C + cv * 8, acc);
+  }
+}
+
+// relative-position gradients from the dK^ half of `win`:
+//   part[blk][i][c]:  c <  C/2 : sum over windows, cols of dK^[(i, col)][c]   (rel_h row i)
+//                     c >= C/2 : sum over windows, rows of dK^[(row, i)][c]   (rel_w col i)
+template <typename T>
+__global__ void __launch_bounds__(256) rel_reduce1_kernel(const T* __restrict__ win, float* __restrict__ part, int nwin, int C,
+                                                          int win_per_block) {
+  extern __shared__ float sh[];     // [nsub][10][C]
+  const int nsub = 256 / C > 0 ? 256 / C : 1;
+  const int c = threadIdx.x % C, sub = threadIdx.x / C;
+  const int w0 = blockIdx.x * win_per_block, w1 = min(nwin, w0 + win_per_block);
+  float acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+  if (sub < nsub)
+    for (int wi = w0 + sub; wi < w1; wi += nsub) {
+      const T* wp = win + (long long)wi * WA_NK * (2 * C) + c;
+      if (c < C / 2) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+#pragma unroll
+          for (int j = 0; j < 10; ++j) acc[i] += to_f(wp[(i * 10 + j) * (2 * C)]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 10; ++i)
+#pragma unroll
+          for (int j = 0; j < 10; ++j) acc[i] += to_f(wp[(j * 10 + i) * (2 * C)]);
+      }
+    }
+  if (sub < nsub) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) sh[(sub * 10 + i) * C + c] = acc[i];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 10 * C; idx += 256) {
+    float a = 0.f;
+    for (int s2 = 0; s2 < nsub; ++s2) a += sh[s2 * 10 * C + idx];
+    part[(long long)blockIdx.x * 10 * C + idx] = a;
+  }
+}
+__global__ void rel_reduce2_kernel(const float* __restrict__ part, float* __restrict__ grel_h, float* __restrict__ grel_w, int nblk,
+                                   int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 10 * C) return;
+  float a = 0.f;
+  for (int b = 0; b < nblk; ++b) a += part[(long long)b * 10 * C + idx];
+  const int i = idx / C, c = idx % C;
+  if (c < C / 2) grel_h[i * (C / 2) + c] = a;        // torch rel_h [1][10][1][C/2]
+  else grel_w[i * (C / 2) + (c - C / 2)] = a;        // torch rel_w [1][1][10][C/2]
+}
+
+template <typename T, int C> static size_t attn_bwd_smem() {
+  constexpr int CC = (C < 64) ? C : 64;
+  constexpr int CW = (CC < 32) ? 32 : CC;
+  const size_t szA1 = 2 * sizeof(T) * (WA_KT * 16) * (CW + 8);
+  const size_t szA2 = sizeof(T) * CC * (WA_KP + 2 * WA_QP);
+  return std::max(szA1, szA2) + 2 * sizeof(T) * (WA_KT * 16) * WA_QP;
+}
+
+template <typename T>
+static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const float* rel_w, const T* gout, int ldg, int gc0,
+                                    T* gqkv, T* win, float* rel_part, float* grel_h, float* grel_w, int B, int h, int w,
+                                    int C, hipStream_t st) {
+  const int nwin = B * (h / 8) * (w / 8);
+#define GO(C_)                                                                                                     \
+  {                                                                                                                \
+    const size_t sh = attn_bwd_smem<T, C_>();                                                                      \
+    (void)hipFuncSetAttribute((const void*)window_attn_bwd_kernel<T, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    hipLaunchKernelGGL((window_attn_bwd_kernel<T, C_>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, h, w); \
+  }
+  if (C == 16) GO(16) else if (C == 64) GO(64) else if (C == 256) GO(256)
+  else return m2t_set_error(-2, "window_attn_bwd: C must be 16, 64 or 256");
+#undef GO
+  M2T_LAUNCH_CHECK();
+  {
+    const long long total = (long long)B * h * w * (2 * C / 8);
+    const int g = (int)std::min<long long>(ceil_divll(total, 256), 4096);
+    hipLaunchKernelGGL(halo_gather_kernel<T>, dim3(g), dim3(256), 0, st, win, gqkv, B, h, w, C);
+    M2T_LAUNCH_CHECK();
+  }
+  {
+    int nblk = std::min(nwin, 128);
+    const int wpb = ceil_div(nwin, nblk);
+    nblk = ceil_div(nwin, wpb);
+    const int nsub = std::max(1, 256 / C);
+    hipLaunchKernelGGL(rel_reduce1_kernel<T>, dim3(nblk), dim3(256), sizeof(float) * nsub * 10 * C, st, win, rel_part, nwin, C, wpb);
+    M2T_LAUNCH_CHECK();
+    hipLaunchKernelGGL(rel_reduce2_kernel, dim3(ceil_div(10 * C, 256)), dim3(256), 0, st, rel_part, grel_h, grel_w, nblk, C);
+    M2T_LAUNCH_CHECK();
+  }
+  return 0;
+}
+int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
+                           int gc0, void* gqkv, void* win, float* rel_part, float* grel_h, float* grel_w, int B, int h,
+                           int w, int C, hipStream_t st) {
+  if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn_bwd: h,w must be multiples of 8");
+  if (dt == M2T_F32)
+    return launch_window_attn_bwd_t<float>((const float*)qkv, rel_h, rel_w, (const float*)gout, ldg, gc0, (float*)gqkv, (float*)win, rel_part, grel_h, grel_w, B, h, w, C, st);
+  return launch_window_attn_bwd_t<bf16_t>((const bf16_t*)qkv, rel_h, rel_w, (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, rel_part, grel_h, grel_w, B, h, w, C, st);
+}

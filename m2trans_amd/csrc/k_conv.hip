@@ -1,0 +1,566 @@
+// k_conv.hip -- the 3x3 convolutions of M2Trans on gfx950.
+//
+//   head   3->64  reflect pad, bias   (models/M2Trans_network.py:34,63)   VALU, K = 27
+//   ff     64->64 zero pad, bias, +x  (models/M2Trans_network.py:124-126,164) MFMA implicit GEMM
+//          (also its data gradient, with the flipped/transposed packed weights) + MFMA wgrad
+//   tail   64->3  reflect pad, no bias, input GELU fused on load (:44-48,54-55)  VALU, N = 3
+//
+// NHWC activations; a workgroup stages a pixel tile + halo once in LDS and re-uses it for
+// all 9 taps.
+#include "m2t_kernels.h"
+
+// =======================================================================================
+// head conv forward
+// x: NCHW fp32 [B][3][H0][W0]; logical image = x reflect-padded right/bottom to [H][W]
+// (check_image_size, :78-86) and then reflect-padded by 1 for the conv.
+// =======================================================================================
+__device__ __forceinline__ int head_src(int i, int n, int n0) {
+  i = reflect_idx(i, n);                 // the conv's own reflect padding on the padded image
+  return (i < n0) ? i : (2 * n0 - 2 - i);  // the right/bottom reflect pad to a multiple of 32
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) head_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, T* __restrict__ out, int B,
+                                                            int H0, int W0, int H, int W) {
+  __shared__ float ws[27][64];   // [ic*9 + tap][oc]
+  __shared__ float bs[64];
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+    const int oc = i / 27, q = i % 27;
+    ws[q][oc] = w[i];            // torch [oc][ic][ky][kx] flattened = oc*27 + (ic*9 + tap)
+  }
+  if (threadIdx.x < 64) bs[threadIdx.x] = bias[threadIdx.x];
+  __syncthreads();
+  const long long total = (long long)B * H * W * 4;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int og = (int)(t & 3);
+    const long long pix = t >> 2;
+    const int xx = (int)(pix % W);
+    const long long q = pix / W;
+    const int yy = (int)(q % H);
+    const int b = (int)(q / H);
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = bs[og * 16 + e];
+#pragma unroll
+    for (int ic = 0; ic < 3; ++ic)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int sy = head_src(yy + ky - 1, H, H0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int sx = head_src(xx + kx - 1, W, W0);
+          const float v = x[(((long long)b * 3 + ic) * H0 + sy) * W0 + sx];
+          const float* wr = &ws[ic * 9 + ky * 3 + kx][og * 16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[e] = fmaf(v, wr[e], acc[e]);
+        }
+      }
+    store16f(out + pix * 64 + og * 16, acc);
+  }
+}
+int launch_head_conv_fwd(int dt, const float* x, const float* w, const float* b, void* out, int B, int H0, int W0,
+                         int H, int W, hipStream_t st) {
+  const long long total = (long long)B * H * W * 4;
+  const int g = (int)std::min<long long>(ceil_divll(total, 256), 4096);
+  if (dt == M2T_F32) hipLaunchKernelGGL(head_conv_fwd_kernel<float>, dim3(g), dim3(256), 0, st, x, w, b, (float*)out, B, H0, W0, H, W);
+  else hipLaunchKernelGGL(head_conv_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x, w, b, (bf16_t*)out, B, H0, W0, H, W);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// head conv weight gradient: dW[oc][ic*9+tap] = sum_pixels g[p][oc] * xsrc(p, ic, tap)
+// thread (oc = tid&63, part = tid>>6); block = contiguous pixel range; slabs [nblk][64*27]
+template <typename T>
+__global__ void __launch_bounds__(256) head_conv_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ g,
+                                                              float* __restrict__ slabs, int B, int H0, int W0, int H,
+                                                              int W, long long pix_per_block) {
+  const int oc = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const long long P = (long long)B * H * W;
+  const long long p0 = blockIdx.x * pix_per_block, p1 = min(P, p0 + pix_per_block);
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.f;
+  for (long long pix = p0 + part; pix < p1; pix += 4) {
+    const int xx = (int)(pix % W);
+    const long long q = pix / W;
+    const int yy = (int)(q % H);
+    const int b = (int)(q / H);
+    const float gv = to_f(g[pix * 64 + oc]);
+#pragma unroll
+    for (int ic = 0; ic < 3; ++ic)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int sy = head_src(yy + ky - 1, H, H0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int sx = head_src(xx + kx - 1, W, W0);
+          acc[ic * 9 + ky * 3 + kx] = fmaf(gv, x[(((long long)b * 3 + ic) * H0 + sy) * W0 + sx], acc[ic * 9 + ky * 3 + kx]);
+        }
+      }
+  }
+  __shared__ float sh[4][27][64];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) sh[part][i][oc] = acc[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+    const int o = i / 27, q = i % 27;
+    slabs[(long long)blockIdx.x * (27 * 64) + i] = sh[0][q][o] + sh[1][q][o] + sh[2][q][o] + sh[3][q][o];
+  }
+}
+int launch_head_conv_wgrad(int dt, const float* x, const void* gout, float* slabs, int* nslab, int B, int H0, int W0,
+                           int H, int W, hipStream_t st) {
+  const long long P = (long long)B * H * W;
+  int nblk = (int)std::min<long long>(256, ceil_divll(P, 256));
+  const long long ppb = ceil_divll(P, nblk);
+  nblk = (int)ceil_divll(P, ppb);
+  if (dt == M2T_F32) hipLaunchKernelGGL(head_conv_wgrad_kernel<float>, dim3(nblk), dim3(256), 0, st, x, (const float*)gout, slabs, B, H0, W0, H, W, ppb);
+  else hipLaunchKernelGGL(head_conv_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, x, (const bf16_t*)gout, slabs, B, H0, W0, H, W, ppb);
+  M2T_LAUNCH_CHECK();
+  *nslab = nblk;
+  return 0;
+}
+
+// =======================================================================================
+// 64 -> 64 3x3 conv, zero padding: implicit GEMM on the matrix cores.
+// Workgroup = 8 x 16 output pixels x 64 output channels; 4 waves, wave w owns pixel rows
+// 2w, 2w+1 (two 16-pixel m-tiles) x 4 channel tiles.  LDS: input halo tile 10x18x64 and the
+// current tap's 64x64 weight slice.  Lane (pixel = lane&15, g = lane>>4) ends with 16
+// consecutive output channels at 16 g.
+// =======================================================================================
+#define C3_TH 8
+#define C3_TW 16
+#define C3_LD 72   // 64 channels + 8 pad
+
+template <typename T>
+__global__ void __launch_bounds__(256) conv3x3_c64_kernel(const T* __restrict__ x, const T* __restrict__ wp,
+                                                          const float* __restrict__ bias, const T* __restrict__ res1,
+                                                          const T* __restrict__ res2, T* __restrict__ y, int H, int W) {
+  __shared__ __attribute__((aligned(16))) T Xs[(C3_TH + 2) * (C3_TW + 2)][C3_LD];
+  __shared__ __attribute__((aligned(16))) T Ws[64][C3_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int x0 = blockIdx.x * C3_TW, y0 = blockIdx.y * C3_TH, b = blockIdx.z;
+  const T* xb = x + (long long)b * H * W * 64;
+
+  // stage the halo tile (zero outside the image)
+  for (int idx = tid; idx < (C3_TH + 2) * (C3_TW + 2) * 8; idx += 256) {
+    const int cv = idx & 7, p = idx >> 3;
+    const int py = p / (C3_TW + 2), px = p - py * (C3_TW + 2);
+    const int gy = y0 + py - 1, gx = x0 + px - 1;
+    Frag8<T> f = frag_zero<T>();
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) f = load8(xb + ((long long)gy * W + gx) * 64 + cv * 8);
+    store8(&Xs[p][cv * 8], f);
+  }
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    __syncthreads();   // previous tap's reads of Ws done (and, tap 0, Xs staged)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx >> 3, cv = idx & 7;
+      store8(&Ws[row][cv * 8], load8(wp + ((long long)tap * 64 + row) * 64 + cv * 8));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      Frag8<T> xf[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        xf[mt] = load8(&Xs[(2 * wv + mt + ky) * (C3_TW + 2) + lr + kx][kc * 32 + g * 8]);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int nl = 16 * (lr >> 2) + 4 * nt + (lr & 3);
+        const Frag8<T> wf = load8(&Ws[nl][kc * 32 + g * 8]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wf, xf[mt]);
+      }
+    }
+  }
+  // epilogue
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int gy = y0 + 2 * wv + mt, gx = x0 + lr;
+    const long long off = (((long long)b * H + gy) * W + gx) * 64 + 16 * g;
+    float v[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += bias[16 * g + e];
+    }
+    if (res1) {
+      float p[16];
+      load16f(res1 + off, p);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += p[e];
+    }
+    if (res2) {
+      float p[16];
+      load16f(res2 + off, p);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += p[e];
+    }
+    store16f(y + off, v);
+  }
+}
+int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias, const void* res1, const void* res2,
+                       void* y, int B, int H, int W, hipStream_t st) {
+  if (H % C3_TH || W % C3_TW) return m2t_set_error(-2, "conv3x3_c64: H%8 or W%16");
+  dim3 grid(W / C3_TW, H / C3_TH, B);
+  if (dt == M2T_F32) hipLaunchKernelGGL(conv3x3_c64_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)wp, bias, (const float*)res1, (const float*)res2, (float*)y, H, W);
+  else hipLaunchKernelGGL(conv3x3_c64_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, H, W);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// 64 -> 64 3x3 conv weight gradient:  dW[tap][oc][ic] = sum_p gy[p][oc] * x[p + tap][ic]
+// Workgroup sweeps tiles of TH x 16 pixels; per tile it stages, TRANSPOSED (pixel index
+// contiguous), gy as GT[oc][m] and three column-shifted copies of x as XT[dx][ic][m'] with
+// m' = (row+1)*16 + col over TH+2 rows, so that every tap's operand is an aligned run of 8
+// pixels.  Wave w owns oc rows 16w..16w+15 for all 4 ic tiles and all 9 taps (36 accumulators).
+// Output: fp32 slabs [nblk][9][64][64], summed (and permuted to torch layout) by reduce_slabs.
+// =======================================================================================
+template <typename T, int TH>
+__global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                                float* __restrict__ slabs, int B, int H, int W,
+                                                                int tiles_per_block) {
+  constexpr int MT = TH * 16;          // pixels per tile
+  constexpr int MX = (TH + 2) * 16;    // rows incl. halo
+  constexpr int LG = MT + 8, LX = MX + 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T(*GT)[LG] = reinterpret_cast<T(*)[LG]>(smem);
+  T(*XT)[64][LX] = reinterpret_cast<T(*)[64][LX]>(smem + sizeof(T) * 64 * LG);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int tw = W / 16, th = H / TH;
+  const long long ntiles = (long long)B * th * tw;
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int a = 0; a < 9; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const long long t0 = (long long)blockIdx.x * tiles_per_block;
+  const long long t1 = min(ntiles, t0 + tiles_per_block);
+  for (long long t = t0; t < t1; ++t) {
+    const int tx = (int)(t % tw);
+    const long long q = t / tw;
+    const int ty = (int)(q % th);
+    const int b = (int)(q / th);
+    const int x0 = tx * 16, y0 = ty * TH;
+    __syncthreads();
+    // gy tile -> GT[oc][m], m = row*16 + col
+    for (int idx = tid; idx < MT * 8; idx += 256) {
+      const int m = idx % MT, cv = idx / MT;
+      const int row = m >> 4, col = m & 15;
+      const Frag8<T> f = load8(gy + (((long long)b * H + y0 + row) * W + x0 + col) * 64 + cv * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) GT[cv * 8 + e][m] = f.v_elem(e);
+    }
+    // x halo -> three shifted transposed copies
+    for (int idx = tid; idx < (TH + 2) * 18 * 8; idx += 256) {
+      const int p = idx % ((TH + 2) * 18), cv = idx / ((TH + 2) * 18);
+      const int row = p / 18, xs = p - row * 18 - 1;        // xs in [-1, 16]
+      const int gyy = y0 + row - 1, gxx = x0 + xs;
+      Frag8<T> f = frag_zero<T>();
+      if (gyy >= 0 && gyy < H && gxx >= 0 && gxx < W) f = load8(x + (((long long)b * H + gyy) * W + gxx) * 64 + cv * 8);
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int col = xs - (dx - 1);                      // copy dx holds x[.., col + dx - 1]
+        if (col >= 0 && col < 16) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) XT[dx][cv * 8 + e][row * 16 + col] = f.v_elem(e);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ch = 0; ch < MT / 32; ++ch) {
+      // k-slot (g, j) <-> pixel m = 32 ch + 8 g + j : row = 2 ch + (g >> 1), col = 8 (g & 1) + j
+      const Frag8<T> gf = load8(&GT[16 * wv + lr][32 * ch + 8 * g]);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const Frag8<T> xf = load8(&XT[kx][16 * it + lr][(2 * ch + (g >> 1) + ky) * 16 + 8 * (g & 1)]);
+            mma16(acc[ky * 3 + kx][it], gf, xf);
+          }
+    }
+  }
+  float* out = slabs + (long long)blockIdx.x * (9 * 64 * 64);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[((long long)tap * 64 + 16 * wv + 4 * g + r) * 64 + 16 * it + lr] = acc[tap][it][r];
+}
+int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, int* nslab, int B, int H, int W,
+                             hipStream_t st) {
+  if (W % 16 || H % 8) return m2t_set_error(-2, "conv3x3_c64_wgrad: H%8 or W%16");
+  const int TH = (dt == M2T_F32) ? 4 : 8;
+  const long long ntiles = (long long)B * (H / TH) * (W / 16);
+  int nblk = (int)std::min<long long>(256, ntiles);
+  const int tpb = (int)ceil_divll(ntiles, nblk);
+  nblk = (int)ceil_divll(ntiles, tpb);
+  if (dt == M2T_F32) {
+    constexpr int MT = 4 * 16, MX = 6 * 16;
+    const size_t sh = sizeof(float) * (64 * (MT + 8) + 3 * 64 * (MX + 8));
+    (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<float, 4>), dim3(nblk), dim3(256), sh, st, (const float*)x, (const float*)gy, slabs, B, H, W, tpb);
+  } else {
+    constexpr int MT = 8 * 16, MX = 10 * 16;
+    const size_t sh = sizeof(bf16_t) * (64 * (MT + 8) + 3 * 64 * (MX + 8));
+    (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<bf16_t, 8>), dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)gy, slabs, B, H, W, tpb);
+  }
+  M2T_LAUNCH_CHECK();
+  *nslab = nblk;
+  return 0;
+}
+
+// =======================================================================================
+// tail conv 64 -> 3, reflect padding, no bias; input = GELU(tpre) applied while staging.
+// Workgroup = 16 x 16 output pixels, one pixel per thread, 3 accumulators; the weights are
+// wave-uniform (scalar loads).  Output NCHW fp32.
+// =======================================================================================
+#define FC_T 16
+#define FC_LD 72
+
+template <typename T>
+__device__ __forceinline__ void final_stage_act(T (*As)[FC_LD], const T* __restrict__ tb, int y0, int x0, int H, int W, int tid) {
+  for (int idx = tid; idx < (FC_T + 2) * (FC_T + 2) * 8; idx += 256) {
+    const int cv = idx & 7, p = idx >> 3;
+    const int py = p / (FC_T + 2), px = p - py * (FC_T + 2);
+    const int gy = reflect_idx(y0 + py - 1, H), gx = reflect_idx(x0 + px - 1, W);
+    Frag8<T> f = load8(tb + ((long long)gy * W + gx) * 64 + cv * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.set(e, gelu_erf(f.get(e)));
+    store8(&As[p][cv * 8], f);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) final_conv_fwd_kernel(const T* __restrict__ tpre, const float* __restrict__ w,
+                                                             float* __restrict__ out, int H, int W) {
+  __shared__ __attribute__((aligned(16))) T As[(FC_T + 2) * (FC_T + 2)][FC_LD];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * FC_T, y0 = blockIdx.y * FC_T, b = blockIdx.z;
+  final_stage_act<T>(As, tpre + (long long)b * H * W * 64, y0, x0, H, W, tid);
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const T* ap = &As[(ty + ky) * (FC_T + 2) + tx + kx][0];
+#pragma unroll
+    for (int cv = 0; cv < 8; ++cv) {
+      float v[8];
+      load8f(ap + cv * 8, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int ic = cv * 8 + e;
+        a0 = fmaf(v[e], w[(0 * 64 + ic) * 9 + tap], a0);
+        a1 = fmaf(v[e], w[(1 * 64 + ic) * 9 + tap], a1);
+        a2 = fmaf(v[e], w[(2 * 64 + ic) * 9 + tap], a2);
+      }
+    }
+  }
+  const long long hw = (long long)H * W;
+  const long long o = (long long)b * 3 * hw + (long long)(y0 + ty) * W + x0 + tx;
+  out[o] = a0;
+  out[o + hw] = a1;
+  out[o + 2 * hw] = a2;
+}
+int launch_final_conv_fwd(int dt, const void* tpre, const float* w, float* out, int B, int H, int W, hipStream_t st) {
+  if (H % FC_T || W % FC_T) return m2t_set_error(-2, "final_conv: H,W must be multiples of 16");
+  dim3 grid(W / FC_T, H / FC_T, B);
+  if (dt == M2T_F32) hipLaunchKernelGGL(final_conv_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)tpre, w, out, H, W);
+  else hipLaunchKernelGGL(final_conv_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)tpre, w, out, H, W);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// tail conv data gradient (+ GELU backward):
+//   g_act[p][ic] = sum_{oc,tap} w[oc][ic][tap] * Geff[oc][tap],   g_tpre = g_act * GELU'(tpre)
+// Geff[oc][tap] gathers gout at the output positions that read input pixel p through tap,
+// INCLUDING the reads that reached p through the reflect padding (rows/cols 1 and n-2 also
+// serve the padded ring positions -1 and n).   thread = (pixel, 16-channel group)
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) final_conv_dgrad_kernel(const float* __restrict__ gout, const float* __restrict__ w,
+                                                               const T* __restrict__ tpre, T* __restrict__ gt, int B, int H,
+                                                               int W) {
+  __shared__ float ws[27][64];   // [oc*9 + tap][ic]
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+    const int oc = i / 576, r = i % 576, ic = r / 9, tap = r % 9;   // torch [3][64][3][3]
+    ws[oc * 9 + tap][ic] = w[i];
+  }
+  __syncthreads();
+  const long long total = (long long)B * H * W * 4;
+  const long long hw = (long long)H * W;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    asm volatile("" ::: "memory");   // keep the 27x16 weight reads inside the loop (no 432-register hoist)
+    const int cgp = (int)(t & 3);
+    const long long pix = t >> 2;
+    const int xx = (int)(pix % W);
+    const long long q = pix / W;
+    const int yy = (int)(q % H);
+    const int b = (int)(q / H);
+    // padded-grid positions that map onto (yy, xx)
+    int pys[2], pxs[2], npy = 1, npx = 1;
+    pys[0] = yy; pxs[0] = xx;
+    if (yy == 1) pys[npy++] = -1;
+    if (yy == H - 2) { if (npy < 2) pys[npy++] = H; }
+    if (xx == 1) pxs[npx++] = -1;
+    if (xx == W - 2) { if (npx < 2) pxs[npx++] = W; }
+    // (for H or W == 3 a pixel could serve both ring sides; sizes here are >= 32)
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll 1
+    for (int oc = 0; oc < 3; ++oc) {       // one output channel at a time keeps the live set small
+      float ge[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) ge[i] = 0.f;
+      for (int a = 0; a < npy; ++a)
+        for (int c = 0; c < npx; ++c) {
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int oy = pys[a] - ky + 1;
+            if (oy < 0 || oy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const int ox = pxs[c] - kx + 1;
+              if (ox < 0 || ox >= W) continue;
+              ge[ky * 3 + kx] += gout[((long long)b * 3 + oc) * hw + (long long)oy * W + ox];
+            }
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const float gv = ge[i];
+        const float* wr = &ws[oc * 9 + i][cgp * 16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = fmaf(gv, wr[e], acc[e]);
+      }
+    }
+    float p[16];
+    load16f(tpre + pix * 64 + cgp * 16, p);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] *= gelu_erf_grad(p[e]);
+    store16f(gt + pix * 64 + cgp * 16, acc);
+  }
+}
+int launch_final_conv_dgrad(int dt, const float* gout, const float* w, const void* tpre, void* gtpre, int B, int H, int W,
+                            hipStream_t st) {
+  const long long total = (long long)B * H * W * 4;
+  const int g = (int)std::min<long long>(ceil_divll(total, 256), 8192);
+  if (dt == M2T_F32) hipLaunchKernelGGL(final_conv_dgrad_kernel<float>, dim3(g), dim3(256), 0, st, gout, w, (const float*)tpre, (float*)gtpre, B, H, W);
+  else hipLaunchKernelGGL(final_conv_dgrad_kernel<bf16_t>, dim3(g), dim3(256), 0, st, gout, w, (const bf16_t*)tpre, (bf16_t*)gtpre, B, H, W);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// tail conv weight gradient: dW[oc][ic][tap] = sum_p gout[oc][p] * act[refl(p + tap)][ic]
+// Workgroup sweeps 16x16 tiles; thread (ic = tid&63, wave = tid>>6 owns 4 tile rows) keeps
+// 27 accumulators and slides a 3x3 register window along each row (3 LDS reads per pixel).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) final_conv_wgrad_kernel(const float* __restrict__ gout, const T* __restrict__ tpre,
+                                                               float* __restrict__ slabs, int B, int H, int W,
+                                                               int tiles_per_block) {
+  __shared__ __attribute__((aligned(16))) T As[(FC_T + 2) * (FC_T + 2)][FC_LD];
+  __shared__ float Gs[3][FC_T * FC_T];
+  const int tid = threadIdx.x, ic = tid & 63, wv = tid >> 6;
+  const int tw = W / FC_T, th = H / FC_T;
+  const long long ntiles = (long long)B * th * tw;
+  const long long hw = (long long)H * W;
+  float acc[27];
+#pragma unroll
+  for (int i = 0; i < 27; ++i) acc[i] = 0.f;
+  const long long t0 = (long long)blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
+  for (long long t = t0; t < t1; ++t) {
+    const int tx = (int)(t % tw);
+    const long long q = t / tw;
+    const int ty = (int)(q % th);
+    const int b = (int)(q / th);
+    const int x0 = tx * FC_T, y0 = ty * FC_T;
+    __syncthreads();
+    final_stage_act<T>(As, tpre + (long long)b * hw * 64, y0, x0, H, W, tid);
+    for (int i = tid; i < 3 * FC_T * FC_T; i += 256) {
+      const int oc = i >> 8, p = i & 255;
+      Gs[oc][p] = gout[((long long)b * 3 + oc) * hw + (long long)(y0 + (p >> 4)) * W + x0 + (p & 15)];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int rr = 0; rr < 4; ++rr) {
+      const int py = 4 * wv + rr;
+      float win[3][3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        win[ky][1] = to_f(As[(py + ky) * (FC_T + 2) + 0][ic]);
+        win[ky][2] = to_f(As[(py + ky) * (FC_T + 2) + 1][ic]);
+      }
+#pragma unroll 4
+      for (int px = 0; px < FC_T; ++px) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          win[ky][0] = win[ky][1];
+          win[ky][1] = win[ky][2];
+          win[ky][2] = to_f(As[(py + ky) * (FC_T + 2) + px + 2][ic]);
+        }
+        const float g0 = Gs[0][py * FC_T + px], g1 = Gs[1][py * FC_T + px], g2 = Gs[2][py * FC_T + px];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            acc[0 * 9 + ky * 3 + kx] = fmaf(g0, win[ky][kx], acc[0 * 9 + ky * 3 + kx]);
+            acc[1 * 9 + ky * 3 + kx] = fmaf(g1, win[ky][kx], acc[1 * 9 + ky * 3 + kx]);
+            acc[2 * 9 + ky * 3 + kx] = fmaf(g2, win[ky][kx], acc[2 * 9 + ky * 3 + kx]);
+          }
+      }
+    }
+  }
+  __syncthreads();
+  float(*red)[27][64] = reinterpret_cast<float(*)[27][64]>(&As[0][0]);   // 4*27*64*4 = 27.6 KB <= sizeof(As)
+#pragma unroll
+  for (int i = 0; i < 27; ++i) red[wv][i][ic] = acc[i];
+  __syncthreads();
+  for (int i = tid; i < 27 * 64; i += 256) {
+    // torch layout [oc][ic][tap]: i = (oc*64 + ic)*9 + tap
+    const int oc = i / 576, r = i % 576, c = r / 9, tap = r % 9;
+    const int a = oc * 9 + tap;
+    slabs[(long long)blockIdx.x * (27 * 64) + i] = red[0][a][c] + red[1][a][c] + red[2][a][c] + red[3][a][c];
+  }
+}
+int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* slabs, int* nslab, int B, int H, int W,
+                            hipStream_t st) {
+  const long long ntiles = (long long)B * (H / FC_T) * (W / FC_T);
+  int nblk = (int)std::min<long long>(512, ntiles);
+  const int tpb = (int)ceil_divll(ntiles, nblk);
+  nblk = (int)ceil_divll(ntiles, tpb);
+  if (dt == M2T_F32) hipLaunchKernelGGL(final_conv_wgrad_kernel<float>, dim3(nblk), dim3(256), 0, st, gout, (const float*)tpre, slabs, B, H, W, tpb);
+  else hipLaunchKernelGGL(final_conv_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, gout, (const bf16_t*)tpre, slabs, B, H, W, tpb);
+  M2T_LAUNCH_CHECK();
+  *nslab = nblk;
+  return 0;
+}

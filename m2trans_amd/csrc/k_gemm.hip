@@ -1,0 +1,250 @@
+// k_gemm.hip -- matrix-core GEMMs over pixel-major activations (gfx950).
+//
+//  gemm_nt :  Y[M][N] = A[M][K] * W[N][K]^T          1x1 convs (qkv projection, tail
+//             expansions) and their data gradients (with the transposed packed weight).
+//             A-side variants: plain rows | GELU(rows) | pixel-UNshuffle gather;
+//             epilogues: plain | +bias | +bias & pixel-shuffle scatter | * GELU'(aux).
+//             (models/M2Trans_network.py:42-47,52-54,281,307 and their autograd)
+//  wgrad_tn:  dW[N][K] = sum_m G[m][N] * X[m][K]      weight gradients; split over M into
+//             fp32 slabs that a deterministic reduction sums (no atomics).
+//
+// Tile product orientation: the weight rows are the MFMA "A" operand and the activation
+// rows the "B" operand, so each lane ends up with 16 CONSECUTIVE output channels of one
+// pixel -> 32/64-byte vector stores along the contiguous NHWC axis.
+#include "m2t_kernels.h"
+#include "m2t_gemm_load.h"
+
+#define GEMM_BM 128
+#define GEMM_BN 64
+#define GEMM_BK 32
+#define GEMM_PAD 8
+
+template <typename T, int AMODE, int EMODE>
+__global__ void __launch_bounds__(256)
+gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __restrict__ Y, int ldy,
+               const float* __restrict__ bias, const T* __restrict__ aux, int ldaux, long long M, int N, int K,
+               ShufGeom sg) {
+  __shared__ __attribute__((aligned(16))) T As[GEMM_BM][GEMM_BK + GEMM_PAD];
+  __shared__ __attribute__((aligned(16))) T Ws[GEMM_BN][GEMM_BK + GEMM_PAD];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * GEMM_BM;
+  const int n0 = blockIdx.y * GEMM_BN;
+
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
+    // ---- stage A (128 x 32) and W (64 x 32) ----
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx >> 2, kv = idx & 3;
+      const long long m = m0 + row;
+      const int k = k0 + kv * 8;
+      Frag8<T> f = frag_zero<T>();
+      if (m < M && k < K) f = gemm_load_a<T, AMODE>(A, lda, m, k, sg);
+      store8(&As[row][kv * 8], f);
+    }
+    {
+      const int row = tid >> 2, kv = tid & 3;
+      const int n = n0 + row, k = k0 + kv * 8;
+      Frag8<T> f = frag_zero<T>();
+      if (n < N && k < K) f = load8(W + (long long)n * K + k);
+      store8(&Ws[row][kv * 8], f);
+    }
+    __syncthreads();
+    // ---- 2 x 4 tile products per wave ----
+    Frag8<T> xf[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) xf[mt] = load8(&As[32 * wv + 16 * mt + lr][g * 8]);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int nl = 16 * (lr >> 2) + 4 * nt + (lr & 3);
+      const Frag8<T> wf = load8(&Ws[nl][g * 8]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wf, xf[mt]);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (m = lr, g) holds n_local = 16 g + 4 nt + r ----
+  const int nn = n0 + 16 * g;
+  if (nn >= N) return;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const long long m = m0 + 32 * wv + 16 * mt + lr;
+    if (m >= M) continue;
+    float v[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
+    if (EMODE == M2T_E_PLAIN) {
+      store16f(Y + m * ldy + nn, v);
+    } else if (EMODE == M2T_E_BIAS) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += bias[nn + e];
+      store16f(Y + m * ldy + nn, v);
+    } else if (EMODE == M2T_E_BIAS_SHUF) {
+      // column n' = sub*C + c  <->  torch channel c*r*r + sub ; destination pixel (h*r+i, w*r+j)
+      const int sub = nn / sg.C, c0 = nn - sub * sg.C;
+      const int i = sub / sg.r, j = sub - i * sg.r;
+      const int rr = sg.r * sg.r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += bias[(c0 + e) * rr + sub];
+      const int w = (int)(m % sg.W);
+      const long long q = m / sg.W;
+      const int h = (int)(q % sg.H);
+      const long long b = q / sg.H;
+      const long long pix = (b * sg.H * sg.r + (h * sg.r + i)) * ((long long)sg.W * sg.r) + (w * sg.r + j);
+      store16f(Y + pix * sg.C + c0, v);
+    } else {   // M2T_E_GELU_GRAD
+      float p[16];
+      load16f(aux + m * ldaux + nn, p);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] *= gelu_erf_grad(p[e]);
+      store16f(Y + m * ldy + nn, v);
+    }
+  }
+}
+
+template <typename T>
+static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStream_t st) {
+  if (a.K % 8 || a.N % 16) return m2t_set_error(-2, "gemm_nt: K must be a multiple of 8 and N of 16");
+  dim3 grid((unsigned)ceil_divll(a.M, GEMM_BM), (unsigned)ceil_div(a.N, GEMM_BN));
+  ShufGeom sg{a.H, a.Wd, a.r, a.C};
+#define GO(AM, EM)                                                                                              \
+  hipLaunchKernelGGL((gemm_nt_kernel<T, AM, EM>), grid, dim3(256), 0, st, (const T*)a.A, a.lda, (const T*)a.W, \
+                     (T*)a.Y, a.ldy, a.bias, (const T*)a.aux, a.ldaux, a.M, a.N, a.K, sg)
+  if (amode == M2T_A_PLAIN && emode == M2T_E_PLAIN) GO(M2T_A_PLAIN, M2T_E_PLAIN);
+  else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS) GO(M2T_A_PLAIN, M2T_E_BIAS);
+  else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_SHUF) GO(M2T_A_PLAIN, M2T_E_BIAS_SHUF);
+  else if (amode == M2T_A_GELU && emode == M2T_E_BIAS_SHUF) GO(M2T_A_GELU, M2T_E_BIAS_SHUF);
+  else if (amode == M2T_A_UNSHUF && emode == M2T_E_PLAIN) GO(M2T_A_UNSHUF, M2T_E_PLAIN);
+  else if (amode == M2T_A_UNSHUF && emode == M2T_E_GELU_GRAD) GO(M2T_A_UNSHUF, M2T_E_GELU_GRAD);
+  else return m2t_set_error(-2, "gemm_nt: unsupported (A mode, epilogue) combination");
+#undef GO
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+int launch_gemm_nt(int dt, int amode, int emode, const m2t_gemm_args& a, hipStream_t st) {
+  if (dt == M2T_F32) return launch_gemm_nt_t<float>(amode, emode, a, st);
+  return launch_gemm_nt_t<bf16_t>(amode, emode, a, st);
+}
+
+// =======================================================================================
+// wgrad_tn: dW[n][k] = sum_m G[m][n] X[m][k]
+// grid (N/64, K/64, nslab); each block sweeps its M range 64 rows at a time, staging both
+// operands TRANSPOSED in LDS ([n][m] and [k][m]) so the contraction index m is lane-contiguous.
+// =======================================================================================
+#define WG_BM 64
+#define WG_LDT (WG_BM + 8)
+
+// transposed staging of a [64 rows][64 cols] operand tile: dst[col][row]
+template <typename T, int MODE>
+__device__ __forceinline__ void wg_stage(T (*dst)[WG_LDT], const T* __restrict__ src, int ld, long long mbase, long long mend,
+                                         int c0, int cmax, const ShufGeom& sg, int tid) {
+  if (sizeof(T) == 4) {
+    // one row per item: 64 rows x 8 vecs = 512 items, row fastest across lanes
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx & 63, cv = idx >> 6;
+      const long long m = mbase + row;
+      const int c = c0 + cv * 8;
+      Frag8<T> f = frag_zero<T>();
+      if (m < mend && c < cmax) f = gemm_load_a<T, MODE>(src, ld, m, c, sg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[cv * 8 + e][row] = f.v_elem(e);
+    }
+  } else {
+    // two rows per item packed into one dword: 32 row-pairs x 8 vecs = 256 items
+    const int rp = tid & 31, cv = tid >> 5;
+    const long long m = mbase + 2 * rp;
+    const int c = c0 + cv * 8;
+    Frag8<T> f0 = frag_zero<T>(), f1 = frag_zero<T>();
+    if (c < cmax) {
+      if (m < mend) f0 = gemm_load_a<T, MODE>(src, ld, m, c, sg);
+      if (m + 1 < mend) f1 = gemm_load_a<T, MODE>(src, ld, m + 1, c, sg);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      T* p = &dst[cv * 8 + e][2 * rp];
+      p[0] = f0.v_elem(e);
+      p[1] = f1.v_elem(e);
+    }
+  }
+}
+
+template <typename T, int GMODE, int XMODE>
+__global__ void __launch_bounds__(256)
+wgrad_tn_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ X, int ldx, float* __restrict__ slabs,
+                long long M, int N, int K, long long rows_per_slab, ShufGeom sg) {
+  __shared__ __attribute__((aligned(16))) T GT[64][WG_LDT];
+  __shared__ __attribute__((aligned(16))) T XT[64][WG_LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const long long mb = (long long)blockIdx.z * rows_per_slab;
+  const long long me = min(M, mb + rows_per_slab);
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (long long ms = mb; ms < me; ms += WG_BM) {
+    wg_stage<T, GMODE>(GT, G, ldg, ms, me, n0, N, sg, tid);
+    wg_stage<T, XMODE>(XT, X, ldx, ms, me, k0, K, sg, tid);
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const Frag8<T> gf = load8(&GT[16 * wv + lr][ch * 32 + g * 8]);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        const Frag8<T> xf = load8(&XT[16 * kt + lr][ch * 32 + g * 8]);
+        mma16(acc[kt], gf, xf);
+      }
+    }
+    __syncthreads();
+  }
+  float* out = slabs + (long long)blockIdx.z * N * K;
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int k = k0 + 16 * kt + lr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 16 * wv + 4 * g + r;
+      if (n < N && k < K) out[(long long)n * K + k] = acc[kt][r];
+    }
+  }
+}
+
+template <typename T>
+static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_t st) {
+  if (a.K % 8 || a.N % 8) return m2t_set_error(-2, "wgrad_tn: N,K must be multiples of 8");
+  const int tn = ceil_div(a.N, 64), tk = ceil_div(a.K, 64);
+  // enough slabs to fill the chip, rows per slab a multiple of the 64-row step
+  long long want = std::max<long long>(1, 512 / (tn * tk));
+  int nslab = (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want, ceil_divll(a.M, WG_BM)));
+  long long rps = ceil_divll(ceil_divll(a.M, nslab), WG_BM) * WG_BM;
+  nslab = (int)ceil_divll(a.M, rps);
+  ShufGeom sg{a.H, a.Wd, a.r, a.C};
+  dim3 grid(tn, tk, nslab);
+#define GO(GM, XM)                                                                                               \
+  hipLaunchKernelGGL((wgrad_tn_kernel<T, GM, XM>), grid, dim3(256), 0, st, (const T*)a.G, a.ldg, (const T*)a.X, \
+                     a.ldx, a.slabs, a.M, a.N, a.K, rps, sg)
+  if (a.gmode == M2T_A_PLAIN && a.xmode == M2T_A_PLAIN) GO(M2T_A_PLAIN, M2T_A_PLAIN);
+  else if (a.gmode == M2T_A_UNSHUF && a.xmode == M2T_A_PLAIN) GO(M2T_A_UNSHUF, M2T_A_PLAIN);
+  else if (a.gmode == M2T_A_UNSHUF && a.xmode == M2T_A_GELU) GO(M2T_A_UNSHUF, M2T_A_GELU);
+  else return m2t_set_error(-2, "wgrad_tn: unsupported operand modes");
+#undef GO
+  M2T_LAUNCH_CHECK();
+  *nslab_out = nslab;
+  return 0;
+}
+int launch_wgrad_tn(int dt, const m2t_wgrad_args& a, int* nslab_out, hipStream_t st) {
+  if (dt == M2T_F32) return launch_wgrad_tn_t<float>(a, nslab_out, st);
+  return launch_wgrad_tn_t<bf16_t>(a, nslab_out, st);
+}

@@ -1,0 +1,887 @@
+// k_pointwise.hip -- the HBM-bound kernels of the M2Trans step (gfx950).
+//
+// Everything here moves bytes with little arithmetic: Haar DWT/IWT fused with the
+// InstanceNorm apply / branch mixing / residuals, InstanceNorm statistics, pixel shuffle,
+// column sums, clamp + L1 (+ its backward seed), the weight packer and fused Adam.  Loads
+// and stores are 8/16-byte vectors along the contiguous channel axis of the NHWC tensors.
+//
+// Reference arithmetic restated (paths in /root/reference):
+//   DWT / IWT ............... models/M2Trans_network.py:198-237
+//   InstanceNorm2d .......... models/M2Trans_network.py:127,135
+//   branch mixing/residuals . models/M2Trans_network.py:137-163
+//   PixelShuffle ............ models/M2Trans_network.py:43,46,53
+//   clamp, crop, L1 ......... models/M2Trans_network.py:74-76, train.py:76,199
+//   Adam .................... train.py:81,210
+#include "m2t_kernels.h"
+#include "m2t_gemm_load.h"
+
+// =======================================================================================
+// Haar butterflies on registers (association order = the reference's, so fp32 is bit-exact)
+// =======================================================================================
+__device__ __forceinline__ void haar2_fwd(float a, float b, float c, float d, float (&o)[4]) {
+  // a=(even r,even c) b=(odd r,even c) c=(even r,odd c) d=(odd r,odd c)  (:203-207)
+  o[0] = 0.5f * (((a + b) + c) + d);
+  o[1] = 0.5f * (((-a - b) + c) + d);
+  o[2] = 0.5f * (((-a + b) - c) + d);
+  o[3] = 0.5f * (((a - b) - c) + d);
+}
+__device__ __forceinline__ void haar2_inv(float ll, float hl, float lh, float hh, float& a, float& b,
+                                          float& c, float& d) {
+  a = 0.5f * (((ll - hl) - lh) + hh);   // even r, even c   (:225)
+  b = 0.5f * (((ll - hl) + lh) - hh);   // odd r,  even c   (:227)
+  c = 0.5f * (((ll + hl) - lh) - hh);   // even r, odd c    (:229)
+  d = 0.5f * (((ll + hl) + lh) + hh);   // odd r,  odd c    (:231)
+}
+
+// L-level transform of one channel of a (2^L x 2^L) pixel block.
+// in: v[y][x];  out: o[band index], band index = band_L * 4^(L-1) + ... + band_1 (band-major
+// nesting exactly as repeated torch.cat((LL,HL,LH,HH),1) produces).
+template <int L> struct Haar;
+template <> struct Haar<0> {
+  static constexpr int S = 1, N = 1;
+  __device__ static __forceinline__ void fwd(const float (&v)[1][1], float (&o)[1]) { o[0] = v[0][0]; }
+  __device__ static __forceinline__ void inv(const float (&o)[1], float (&v)[1][1]) { v[0][0] = o[0]; }
+};
+template <> struct Haar<1> {
+  static constexpr int S = 2, N = 4;
+  __device__ static __forceinline__ void fwd(const float (&v)[2][2], float (&o)[4]) {
+    haar2_fwd(v[0][0], v[1][0], v[0][1], v[1][1], o);
+  }
+  __device__ static __forceinline__ void inv(const float (&o)[4], float (&v)[2][2]) {
+    haar2_inv(o[0], o[1], o[2], o[3], v[0][0], v[1][0], v[0][1], v[1][1]);
+  }
+};
+template <> struct Haar<2> {
+  static constexpr int S = 4, N = 16;
+  __device__ static __forceinline__ void fwd(const float (&v)[4][4], float (&o)[16]) {
+    float t[2][2][4];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+        haar2_fwd(v[2 * I][2 * J], v[2 * I + 1][2 * J], v[2 * I][2 * J + 1], v[2 * I + 1][2 * J + 1], t[I][J]);
+#pragma unroll
+    for (int b1 = 0; b1 < 4; ++b1) {
+      float r[4];
+      haar2_fwd(t[0][0][b1], t[1][0][b1], t[0][1][b1], t[1][1][b1], r);
+#pragma unroll
+      for (int b2 = 0; b2 < 4; ++b2) o[b2 * 4 + b1] = r[b2];
+    }
+  }
+  __device__ static __forceinline__ void inv(const float (&o)[16], float (&v)[4][4]) {
+    float t[2][2][4];
+#pragma unroll
+    for (int b1 = 0; b1 < 4; ++b1)
+      haar2_inv(o[0 * 4 + b1], o[1 * 4 + b1], o[2 * 4 + b1], o[3 * 4 + b1], t[0][0][b1], t[1][0][b1],
+                t[0][1][b1], t[1][1][b1]);
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+        haar2_inv(t[I][J][0], t[I][J][1], t[I][J][2], t[I][J][3], v[2 * I][2 * J], v[2 * I + 1][2 * J],
+                  v[2 * I][2 * J + 1], v[2 * I + 1][2 * J + 1]);
+  }
+};
+
+// =======================================================================================
+// generic L-level DWT / IWT on an NHWC tensor slice (operator API + bit-exact tests)
+//   src [B][H][W][lds] (channels c0..c0+C)  ->  dst [B][H/S][W/S][ldd] (channels d0 + band*C + c)
+// one thread = one pixel block x 4 channels
+// =======================================================================================
+template <typename T, int L>
+__global__ void __launch_bounds__(256) dwt_kernel(const T* __restrict__ src, int lds_, int c0, T* __restrict__ dst,
+                                                  int ldd, int d0, int B, int H, int W, int C) {
+  constexpr int S = Haar<L>::S, N = Haar<L>::N;
+  const int cg = C / 4;
+  const int hb = H / S, wb = W / S;
+  const long long total = (long long)B * hb * wb * cg;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(t % cg);
+    long long r = t / cg;
+    const int j = (int)(r % wb); r /= wb;
+    const int i = (int)(r % hb);
+    const int b = (int)(r / hb);
+    float v[4][S][S];
+#pragma unroll
+    for (int y = 0; y < S; ++y)
+#pragma unroll
+      for (int x = 0; x < S; ++x) {
+        float q[4];
+        load4(src + (((long long)b * H + (i * S + y)) * W + (j * S + x)) * lds_ + c0 + g * 4, q);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c][y][x] = q[c];
+      }
+    float o[4][N];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Haar<L>::fwd(v[c], o[c]);
+    T* dp = dst + (((long long)b * hb + i) * wb + j) * ldd + d0 + g * 4;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float q[4] = {o[0][n], o[1][n], o[2][n], o[3][n]};
+      store4(dp + n * C, q);
+    }
+  }
+}
+
+template <typename T, int L>
+__global__ void __launch_bounds__(256) iwt_kernel(const T* __restrict__ src, int lds_, int c0, T* __restrict__ dst,
+                                                  int ldd, int d0, int B, int H, int W, int C) {
+  // src [B][H/S][W/S][lds] holds N*C channels at c0; dst [B][H][W][ldd] gets C channels at d0
+  constexpr int S = Haar<L>::S, N = Haar<L>::N;
+  const int cg = C / 4;
+  const int hb = H / S, wb = W / S;
+  const long long total = (long long)B * hb * wb * cg;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(t % cg);
+    long long r = t / cg;
+    const int j = (int)(r % wb); r /= wb;
+    const int i = (int)(r % hb);
+    const int b = (int)(r / hb);
+    float o[4][N];
+    const T* sp = src + (((long long)b * hb + i) * wb + j) * lds_ + c0 + g * 4;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float q[4];
+      load4(sp + n * C, q);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c][n] = q[c];
+    }
+    float v[4][S][S];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Haar<L>::inv(o[c], v[c]);
+#pragma unroll
+    for (int y = 0; y < S; ++y)
+#pragma unroll
+      for (int x = 0; x < S; ++x) {
+        float q[4] = {v[0][y][x], v[1][y][x], v[2][y][x], v[3][y][x]};
+        store4(dst + (((long long)b * H + (i * S + y)) * W + (j * S + x)) * ldd + d0 + g * 4, q);
+      }
+  }
+}
+
+static inline int grid_for(long long total, int block = 256, int cap = 256 * 16) {
+  long long g = ceil_divll(total, block);
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <typename T>
+int launch_dwt_t(int L, const T* src, int lds_, int c0, T* dst, int ldd, int d0, int B, int H, int W, int C,
+                 bool inverse, hipStream_t st) {
+  const int S = 1 << L;
+  const long long total = (long long)B * (H / S) * (W / S) * (C / 4);
+  const int g = grid_for(total);
+  if (!inverse) {
+    if (L == 1) hipLaunchKernelGGL((dwt_kernel<T, 1>), dim3(g), dim3(256), 0, st, src, lds_, c0, dst, ldd, d0, B, H, W, C);
+    else if (L == 2) hipLaunchKernelGGL((dwt_kernel<T, 2>), dim3(g), dim3(256), 0, st, src, lds_, c0, dst, ldd, d0, B, H, W, C);
+    else return m2t_set_error(-2, "dwt: levels must be 1 or 2");
+  } else {
+    if (L == 1) hipLaunchKernelGGL((iwt_kernel<T, 1>), dim3(g), dim3(256), 0, st, src, lds_, c0, dst, ldd, d0, B, H, W, C);
+    else if (L == 2) hipLaunchKernelGGL((iwt_kernel<T, 2>), dim3(g), dim3(256), 0, st, src, lds_, c0, dst, ldd, d0, B, H, W, C);
+    else return m2t_set_error(-2, "iwt: levels must be 1 or 2");
+  }
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+int launch_dwt(int dt, int L, const void* src, int lds_, int c0, void* dst, int ldd, int d0, int B, int H, int W,
+               int C, bool inverse, hipStream_t st) {
+  if (C % 4 || H % (1 << L) || W % (1 << L)) return m2t_set_error(-2, "dwt: C%4 or H,W not divisible");
+  if (dt == M2T_F32) return launch_dwt_t<float>(L, (const float*)src, lds_, c0, (float*)dst, ldd, d0, B, H, W, C, inverse, st);
+  return launch_dwt_t<bf16_t>(L, (const bf16_t*)src, lds_, c0, (bf16_t*)dst, ldd, d0, B, H, W, C, inverse, st);
+}
+
+// =======================================================================================
+// pixel shuffle / unshuffle on NCHW fp32 (the reference layout): pure index permutation,
+// bit-exact.  out[b,c,h*r+i,w*r+j] = in[b,c*r*r+i*r+j,h,w]   (nn.PixelShuffle)
+// =======================================================================================
+__global__ void __launch_bounds__(256) pixel_shuffle_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                  int B, int C, int H, int W, int r, int inverse) {
+  const long long total = (long long)B * C * r * r * H * W;   // C = channels AFTER shuffle
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    // t indexes the shuffled tensor [B][C][H*r][W*r]
+    const int ow = (int)(t % (W * r));
+    long long q = t / (W * r);
+    const int oh = (int)(q % (H * r)); q /= (H * r);
+    const int c = (int)(q % C);
+    const int b = (int)(q / C);
+    const int h = oh / r, i = oh % r, w = ow / r, j = ow % r;
+    const long long s = (((long long)b * C * r * r + (c * r * r + i * r + j)) * H + h) * W + w;
+    if (!inverse) out[t] = in[s]; else out[s] = in[t];
+  }
+}
+int launch_pixel_shuffle_nchw(const float* in, float* out, int B, int C, int H, int W, int r, int inverse,
+                              hipStream_t st) {
+  const long long total = (long long)B * C * r * r * H * W;
+  hipLaunchKernelGGL(pixel_shuffle_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, out, B, C, H, W, r, inverse);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// InstanceNorm statistics: per (b,c) mean and 1/sqrt(var+eps) over the P pixels of an
+// NHWC [B][P][64] tensor.  Two deterministic stages, Welford/Chan merges in fp32.
+// Stage 1: grid (nsplit, B); a block of 256 threads = 8 channel-groups(8 ch) x 32 pixel lanes.
+// Also used for the backward reductions (sum g, sum g*xhat) through kernel below.
+// =======================================================================================
+struct Wf { float n, mean, m2; };
+__device__ __forceinline__ Wf wf_merge(const Wf& a, const Wf& b) {
+  Wf r;
+  r.n = a.n + b.n;
+  if (r.n == 0.f) { r.mean = 0.f; r.m2 = 0.f; return r; }
+  const float d = b.mean - a.mean;
+  const float f = b.n / r.n;
+  r.mean = a.mean + d * f;
+  r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+  return r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) instnorm_stats1_kernel(const T* __restrict__ x, float* __restrict__ part, int P,
+                                                              int nsplit) {
+  // part [B][nsplit][64][3]
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int cgp = threadIdx.x & 7, pl = threadIdx.x >> 3;   // 8 groups x 32 lanes
+  const int per = ceil_div(P, nsplit);
+  const int p0 = sp * per, p1 = min(P, p0 + per);
+  Wf w[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { w[c].n = 0.f; w[c].mean = 0.f; w[c].m2 = 0.f; }
+  for (int p = p0 + pl; p < p1; p += 32) {
+    float v[8];
+    load8f(x + ((long long)b * P + p) * 64 + cgp * 8, v);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      w[c].n += 1.f;
+      const float d = v[c] - w[c].mean;
+      w[c].mean += d / w[c].n;
+      w[c].m2 += d * (v[c] - w[c].mean);
+    }
+  }
+  __shared__ float sh[256][8][3];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { sh[threadIdx.x][c][0] = w[c].n; sh[threadIdx.x][c][1] = w[c].mean; sh[threadIdx.x][c][2] = w[c].m2; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int ch = threadIdx.x, g = ch >> 3, c = ch & 7;
+    Wf a; a.n = 0.f; a.mean = 0.f; a.m2 = 0.f;
+    for (int l = 0; l < 32; ++l) {
+      Wf q; q.n = sh[l * 8 + g][c][0]; q.mean = sh[l * 8 + g][c][1]; q.m2 = sh[l * 8 + g][c][2];
+      a = wf_merge(a, q);
+    }
+    float* o = part + (((long long)b * nsplit + sp) * 64 + ch) * 3;
+    o[0] = a.n; o[1] = a.mean; o[2] = a.m2;
+  }
+}
+__global__ void instnorm_stats2_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
+                                       int nsplit, float eps) {
+  const int b = blockIdx.x, ch = threadIdx.x;   // 64 threads
+  Wf a; a.n = 0.f; a.mean = 0.f; a.m2 = 0.f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* o = part + (((long long)b * nsplit + s) * 64 + ch) * 3;
+    Wf q; q.n = o[0]; q.mean = o[1]; q.m2 = o[2];
+    a = wf_merge(a, q);
+  }
+  mean[b * 64 + ch] = a.mean;
+  rstd[b * 64 + ch] = 1.0f / sqrtf(a.m2 / a.n + eps);   // biased variance
+}
+int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float* part, int B, int P, hipStream_t st) {
+  const int nsplit = M2T_NORM_SPLIT;
+  if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_stats1_kernel<float>, dim3(nsplit, B), dim3(256), 0, st, (const float*)x, part, P, nsplit);
+  else hipLaunchKernelGGL(instnorm_stats1_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, st, (const bf16_t*)x, part, P, nsplit);
+  M2T_LAUNCH_CHECK();
+  hipLaunchKernelGGL(instnorm_stats2_kernel, dim3(B), dim3(64), 0, st, part, mean, rstd, nsplit, 1e-5f);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// branch_prep<L>: the input side of CFTM branch k (k = chunk index 0..3, L = DWT levels)
+//   xin = norm(x)[chunk k]                      (k = 0)         (:135-139)
+//   xin = (norm(x)[chunk k] + xc[chunk k-1]) / 2 (k >= 1)        (:141,147,155)
+//   d   = DWT^L(xin)                                              (:143,149-150,157-158)
+// x, xc: [B][H][W][64];  xin: [B][H][W][16];  d: [B][H/S][W/S][16*4^L]
+// one thread = one (2^L)^2 pixel block x 4 channels
+// =======================================================================================
+template <typename T, int L>
+__global__ void __launch_bounds__(256) branch_prep_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const T* __restrict__ xc,
+                                                          int k, T* __restrict__ xin, T* __restrict__ d, int B, int H, int W) {
+  constexpr int S = Haar<L>::S, N = Haar<L>::N;
+  const int hb = H / S, wb = W / S;
+  const long long total = (long long)B * hb * wb * 4;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(t & 3);
+    long long r = t >> 2;
+    const int j = (int)(r % wb); r /= wb;
+    const int i = (int)(r % hb);
+    const int b = (int)(r / hb);
+    float mu[4], rs[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { mu[c] = mean[b * 64 + k * 16 + g * 4 + c]; rs[c] = rstd[b * 64 + k * 16 + g * 4 + c]; }
+    float v[4][S][S];
+#pragma unroll
+    for (int y = 0; y < S; ++y)
+#pragma unroll
+      for (int xx = 0; xx < S; ++xx) {
+        const long long pix = ((long long)b * H + (i * S + y)) * W + (j * S + xx);
+        float q[4];
+        load4(x + pix * 64 + k * 16 + g * 4, q);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = (q[c] - mu[c]) * rs[c];
+        if (k > 0) {
+          float p[4];
+          load4(xc + pix * 64 + (k - 1) * 16 + g * 4, p);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) q[c] = (q[c] + p[c]) * 0.5f;
+        }
+        if (L > 0) {
+          // keep the stored (rounded) value and the transformed value identical
+          store4(xin + pix * 16 + g * 4, q);
+          if (sizeof(T) == 2) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[c] = to_f(from_f<T>(q[c]));
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c][y][xx] = q[c];
+      }
+    float o[4][N];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Haar<L>::fwd(v[c], o[c]);
+    T* dp = d + (((long long)b * hb + i) * wb + j) * (16 * N) + g * 4;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float q[4] = {o[0][n], o[1][n], o[2][n], o[3][n]};
+      store4(dp + n * 16, q);
+    }
+  }
+}
+template <typename T>
+int launch_branch_prep_t(int L, const T* x, const float* mean, const float* rstd, const T* xc, int k, T* xin, T* d,
+                         int B, int H, int W, hipStream_t st) {
+  const int S = 1 << L;
+  const int g = grid_for((long long)B * (H / S) * (W / S) * 4);
+  if (L == 0) hipLaunchKernelGGL((branch_prep_kernel<T, 0>), dim3(g), dim3(256), 0, st, x, mean, rstd, xc, k, xin, d, B, H, W);
+  else if (L == 1) hipLaunchKernelGGL((branch_prep_kernel<T, 1>), dim3(g), dim3(256), 0, st, x, mean, rstd, xc, k, xin, d, B, H, W);
+  else hipLaunchKernelGGL((branch_prep_kernel<T, 2>), dim3(g), dim3(256), 0, st, x, mean, rstd, xc, k, xin, d, B, H, W);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+int launch_branch_prep(int dt, int L, const void* x, const float* mean, const float* rstd, const void* xc, int k,
+                       void* xin, void* d, int B, int H, int W, hipStream_t st) {
+  if (dt == M2T_F32) return launch_branch_prep_t<float>(L, (const float*)x, mean, rstd, (const float*)xc, k, (float*)xin, (float*)d, B, H, W, st);
+  return launch_branch_prep_t<bf16_t>(L, (const bf16_t*)x, mean, rstd, (const bf16_t*)xc, k, (bf16_t*)xin, (bf16_t*)d, B, H, W, st);
+}
+
+// =======================================================================================
+// branch_post<L>: xc[chunk k] = IWT^L(a) + xin       (:145,153,161)
+// =======================================================================================
+template <typename T, int L>
+__global__ void __launch_bounds__(256) branch_post_kernel(const T* __restrict__ a, const T* __restrict__ xin,
+                                                          T* __restrict__ xc, int k, int B, int H, int W) {
+  constexpr int S = Haar<L>::S, N = Haar<L>::N;
+  const int hb = H / S, wb = W / S;
+  const long long total = (long long)B * hb * wb * 4;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(t & 3);
+    long long r = t >> 2;
+    const int j = (int)(r % wb); r /= wb;
+    const int i = (int)(r % hb);
+    const int b = (int)(r / hb);
+    float o[4][N];
+    const T* sp = a + (((long long)b * hb + i) * wb + j) * (16 * N) + g * 4;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float q[4];
+      load4(sp + n * 16, q);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c][n] = q[c];
+    }
+    float v[4][S][S];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Haar<L>::inv(o[c], v[c]);
+#pragma unroll
+    for (int y = 0; y < S; ++y)
+#pragma unroll
+      for (int xx = 0; xx < S; ++xx) {
+        const long long pix = ((long long)b * H + (i * S + y)) * W + (j * S + xx);
+        float p[4];
+        load4(xin + pix * 16 + g * 4, p);
+        float q[4] = {v[0][y][xx] + p[0], v[1][y][xx] + p[1], v[2][y][xx] + p[2], v[3][y][xx] + p[3]};
+        store4(xc + pix * 64 + k * 16 + g * 4, q);
+      }
+  }
+}
+int launch_branch_post(int dt, int L, const void* a, const void* xin, void* xc, int k, int B, int H, int W,
+                       hipStream_t st) {
+  const int S = 1 << L;
+  const int g = grid_for((long long)B * (H / S) * (W / S) * 4);
+#define BP(T_, L_) hipLaunchKernelGGL((branch_post_kernel<T_, L_>), dim3(g), dim3(256), 0, st, (const T_*)a, (const T_*)xin, (T_*)xc, k, B, H, W)
+  if (dt == M2T_F32) { if (L == 1) BP(float, 1); else BP(float, 2); }
+  else { if (L == 1) BP(bf16_t, 1); else BP(bf16_t, 2); }
+#undef BP
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// backward of branch_post: ga = DWT^L(g_xc[chunk k])   (IWT^T = DWT, orthonormal Haar)
+// =======================================================================================
+int launch_branch_post_bwd(int dt, int L, const void* gxc, int k, void* ga, int B, int H, int W, hipStream_t st) {
+  // source = channels k*16.. of the 64-wide g_xc; destination = dense [.,16*4^L]
+  return launch_dwt(dt, L, gxc, 64, k * 16, ga, 16 << (2 * L), 0, B, H, W, 16, false, st);
+}
+
+// =======================================================================================
+// backward of branch_prep<L> for branch k:
+//   g_xin = IWT^L(g_d) + g_xc[chunk k]                 (k >= 1, L >= 1)
+//   g_n[chunk k]     = g_xin / 2 ;   g_xc[chunk k-1] += g_xin / 2
+// and for k = 0 (L = 0):   g_n[chunk 0] = g_d + g_xc[chunk 0]
+// g_n, g_xc: [B][H][W][64]
+// =======================================================================================
+template <typename T, int L>
+__global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restrict__ gd, T* __restrict__ gxc,
+                                                              T* __restrict__ gn, int k, int B, int H, int W) {
+  constexpr int S = Haar<L>::S, N = Haar<L>::N;
+  const int hb = H / S, wb = W / S;
+  const long long total = (long long)B * hb * wb * 4;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int g = (int)(t & 3);
+    long long r = t >> 2;
+    const int j = (int)(r % wb); r /= wb;
+    const int i = (int)(r % hb);
+    const int b = (int)(r / hb);
+    float o[4][N];
+    const T* sp = gd + (((long long)b * hb + i) * wb + j) * (16 * N) + g * 4;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      float q[4];
+      load4(sp + n * 16, q);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c][n] = q[c];
+    }
+    float v[4][S][S];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Haar<L>::inv(o[c], v[c]);
+#pragma unroll
+    for (int y = 0; y < S; ++y)
+#pragma unroll
+      for (int xx = 0; xx < S; ++xx) {
+        const long long pix = ((long long)b * H + (i * S + y)) * W + (j * S + xx);
+        float p[4];
+        load4(gxc + pix * 64 + k * 16 + g * 4, p);
+        float q[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q[c] = v[c][y][xx] + p[c];
+        if (k == 0) {
+          store4(gn + pix * 64 + g * 4, q);
+        } else {
+          float pp[4];
+          load4(gxc + pix * 64 + (k - 1) * 16 + g * 4, pp);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { q[c] *= 0.5f; pp[c] += q[c]; }
+          store4(gn + pix * 64 + k * 16 + g * 4, q);
+          store4(gxc + pix * 64 + (k - 1) * 16 + g * 4, pp);
+        }
+      }
+  }
+}
+int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, int k, int B, int H, int W,
+                           hipStream_t st) {
+  const int S = 1 << L;
+  const int g = grid_for((long long)B * (H / S) * (W / S) * 4);
+#define BP(T_, L_) hipLaunchKernelGGL((branch_prep_bwd_kernel<T_, L_>), dim3(g), dim3(256), 0, st, (const T_*)gd, (T_*)gxc, (T_*)gn, k, B, H, W)
+  if (dt == M2T_F32) { if (L == 0) BP(float, 0); else if (L == 1) BP(float, 1); else BP(float, 2); }
+  else { if (L == 0) BP(bf16_t, 0); else if (L == 1) BP(bf16_t, 1); else BP(bf16_t, 2); }
+#undef BP
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// InstanceNorm backward
+//   g_x = rstd * (g_n - mean_p(g_n) - xhat * mean_p(g_n * xhat)) + g_res
+// stage 1/2: s1[b,c] = sum_p g_n, s2[b,c] = sum_p g_n*xhat ; stage 3: apply (+ residual grad,
+// the "+ x" of the feed-forward conv, :164)
+// =======================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) instnorm_bwd_red1_kernel(const T* __restrict__ gn, const T* __restrict__ x,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                float* __restrict__ part, int P, int nsplit) {
+  // part [B][nsplit][64][2]
+  const int b = blockIdx.y, sp = blockIdx.x;
+  const int cgp = threadIdx.x & 7, pl = threadIdx.x >> 3;
+  const int per = ceil_div(P, nsplit);
+  const int p0 = sp * per, p1 = min(P, p0 + per);
+  float mu[8], rs[8], s1[8], s2[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { mu[c] = mean[b * 64 + cgp * 8 + c]; rs[c] = rstd[b * 64 + cgp * 8 + c]; s1[c] = 0.f; s2[c] = 0.f; }
+  for (int p = p0 + pl; p < p1; p += 32) {
+    float g[8], v[8];
+    load8f(gn + ((long long)b * P + p) * 64 + cgp * 8, g);
+    load8f(x + ((long long)b * P + p) * 64 + cgp * 8, v);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { s1[c] += g[c]; s2[c] += g[c] * ((v[c] - mu[c]) * rs[c]); }
+  }
+  __shared__ float sh[256][8][2];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) { sh[threadIdx.x][c][0] = s1[c]; sh[threadIdx.x][c][1] = s2[c]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int ch = threadIdx.x, g = ch >> 3, c = ch & 7;
+    float a1 = 0.f, a2 = 0.f;
+    for (int l = 0; l < 32; ++l) { a1 += sh[l * 8 + g][c][0]; a2 += sh[l * 8 + g][c][1]; }
+    float* o = part + (((long long)b * nsplit + sp) * 64 + ch) * 2;
+    o[0] = a1; o[1] = a2;
+  }
+}
+__global__ void instnorm_bwd_red2_kernel(const float* __restrict__ part, float* __restrict__ s, int nsplit, float invP) {
+  const int b = blockIdx.x, ch = threadIdx.x;
+  float a1 = 0.f, a2 = 0.f;
+  for (int q = 0; q < nsplit; ++q) {
+    const float* o = part + (((long long)b * nsplit + q) * 64 + ch) * 2;
+    a1 += o[0]; a2 += o[1];
+  }
+  s[(b * 64 + ch) * 2 + 0] = a1 * invP;
+  s[(b * 64 + ch) * 2 + 1] = a2 * invP;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) instnorm_bwd_apply_kernel(const T* __restrict__ gn, const T* __restrict__ x,
+                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                 const float* __restrict__ s, const T* __restrict__ gres,
+                                                                 T* __restrict__ gx, int B, int P) {
+  const long long total = (long long)B * P * 8;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int cgp = (int)(t & 7);
+    const long long pix = t >> 3;
+    const int b = (int)(pix / P);
+    float g[8], v[8], r[8];
+    load8f(gn + pix * 64 + cgp * 8, g);
+    load8f(x + pix * 64 + cgp * 8, v);
+    load8f(gres + pix * 64 + cgp * 8, r);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ch = b * 64 + cgp * 8 + c;
+      const float rs = rstd[ch];
+      const float xh = (v[c] - mean[ch]) * rs;
+      r[c] += rs * (g[c] - s[ch * 2] - xh * s[ch * 2 + 1]);
+    }
+    store8f(gx + pix * 64 + cgp * 8, r);
+  }
+}
+int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean, const float* rstd, const void* gres,
+                        void* gx, float* part, float* s, int B, int P, hipStream_t st) {
+  const int nsplit = M2T_NORM_SPLIT;
+  if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_red1_kernel<float>, dim3(nsplit, B), dim3(256), 0, st, (const float*)gn, (const float*)x, mean, rstd, part, P, nsplit);
+  else hipLaunchKernelGGL(instnorm_bwd_red1_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, part, P, nsplit);
+  M2T_LAUNCH_CHECK();
+  hipLaunchKernelGGL(instnorm_bwd_red2_kernel, dim3(B), dim3(64), 0, st, part, s, nsplit, 1.0f / (float)P);
+  M2T_LAUNCH_CHECK();
+  const int g = grid_for((long long)B * P * 8);
+  if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)gn, (const float*)x, mean, rstd, s, (const float*)gres, (float*)gx, B, P);
+  else hipLaunchKernelGGL(instnorm_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, s, (const bf16_t*)gres, (bf16_t*)gx, B, P);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// elementwise add:  out = a + b   (res + x at :70, and gradient joins)
+// =======================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, long long n8) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n8; t += (long long)gridDim.x * blockDim.x) {
+    float x[8], y[8];
+    load8f(a + t * 8, x);
+    load8f(b + t * 8, y);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[c] += y[c];
+    store8f(o + t * 8, x);
+  }
+}
+int launch_add(int dt, const void* a, const void* b, void* o, long long n, hipStream_t st) {
+  const long long n8 = n / 8;
+  if (dt == M2T_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(grid_for(n8)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)o, n8);
+  else hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid_for(n8)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)o, n8);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// column sums of a [M][N] matrix (bias gradients): out[n] = sum_m a[m][n]; optional
+// un-shuffle gather view (tail bias).  Two stages through `part` [nblk][N].
+// =======================================================================================
+template <typename T, int AMODE>
+__global__ void __launch_bounds__(256) colsum1_kernel(const T* __restrict__ a, int lda, float* __restrict__ part, long long M,
+                                                      int N, int rows_per_block, ShufGeom sg) {
+  // thread: column group of 8 = threadIdx.x % (N/8); row lane = threadIdx.x / (N/8)
+  const int ng = N / 8;
+  const int lanes = 256 / ng;
+  const int cgp = threadIdx.x % ng, rl = threadIdx.x / ng;
+  const long long m0 = (long long)blockIdx.x * rows_per_block;
+  const long long m1 = min(M, m0 + rows_per_block);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (rl < lanes)
+    for (long long m = m0 + rl; m < m1; m += lanes) {
+      const Frag8<T> f = gemm_load_a<T, AMODE>(a, lda, m, cgp * 8, sg);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) s[c] += f.get(c);
+    }
+  __shared__ float sh[256][8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) sh[threadIdx.x][c] = s[c];
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const int g = n >> 3, c = n & 7;
+    float acc = 0.f;
+    for (int l = 0; l < lanes; ++l) acc += sh[l * ng + g][c];
+    part[(long long)blockIdx.x * N + n] = acc;
+  }
+}
+__global__ void colsum2_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int N, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int b = 0; b < nblk; ++b) acc += part[(long long)b * N + n];
+  if (accumulate) out[n] += acc; else out[n] = acc;
+}
+int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* part, int max_part_blocks, float* out,
+                  int accumulate, hipStream_t st, int unshuf, int gH, int gW, int gr, int gC) {
+  if (N % 8 || N / 8 > 256) return m2t_set_error(-2, "colsum: bad N");
+  ShufGeom sg{gH, gW, gr, gC};
+  int nblk = (int)std::min<long long>(max_part_blocks, ceil_divll(M, 64));
+  if (nblk < 1) nblk = 1;
+  const int rpb = (int)ceil_divll(M, nblk);
+  nblk = (int)ceil_divll(M, rpb);
+  if (dt == M2T_F32) {
+    if (unshuf) hipLaunchKernelGGL((colsum1_kernel<float, M2T_A_UNSHUF>), dim3(nblk), dim3(256), 0, st, (const float*)a, lda, part, M, N, rpb, sg);
+    else hipLaunchKernelGGL((colsum1_kernel<float, M2T_A_PLAIN>), dim3(nblk), dim3(256), 0, st, (const float*)a, lda, part, M, N, rpb, sg);
+  } else {
+    if (unshuf) hipLaunchKernelGGL((colsum1_kernel<bf16_t, M2T_A_UNSHUF>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)a, lda, part, M, N, rpb, sg);
+    else hipLaunchKernelGGL((colsum1_kernel<bf16_t, M2T_A_PLAIN>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)a, lda, part, M, N, rpb, sg);
+  }
+  M2T_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum2_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, part, out, nblk, N, accumulate);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// slab reduction for weight gradients: out[perm(e)] = sum_s slab[s][e]
+//   perm 0: identity
+//   perm 1: conv3x3 packed [tap][O][I] -> torch [O][I][3][3]
+//   perm 2: shuffled rows n' = sub*C + c (sub = i*r+j) -> torch row c*r*r + sub; rows of K
+// =======================================================================================
+__global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int ns,
+                                                           long long n, int perm, int p0, int p1, int p2) {
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int s = 0; s < ns; ++s) acc += slab[(long long)s * n + e];
+    long long d = e;
+    if (perm == 1) {           // p0 = O, p1 = I
+      const int i = (int)(e % p1); const int o = (int)((e / p1) % p0); const int tap = (int)(e / ((long long)p0 * p1));
+      d = ((long long)o * p1 + i) * 9 + tap;
+    } else if (perm == 2) {    // p0 = C (64), p1 = r*r, p2 = K
+      const int kk = (int)(e % p2); const int np = (int)(e / p2);
+      const int sub = np / p0, c = np % p0;
+      d = ((long long)c * p1 + sub) * p2 + kk;
+    }
+    out[d] = acc;
+  }
+}
+int launch_reduce_slabs(const float* slab, float* out, int ns, long long n, int perm, int p0, int p1, int p2,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, st, slab, out, ns, n, perm, p0, p1, p2);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// clamp + crop + L1 (+ backward seed)                    (:74-76, train.py:199)
+//   pre  [B][3][Hp][Wp] fp32  (padded-size pre-clamp network output, NCHW)
+//   sr   [B][3][Hs][Ws] fp32  = clamp(pre, 0, R) cropped
+//   loss partial sums of |sr - hr|  -> part[blocks]  (sum finished by loss_finish)
+//   gpre [B][3][Hp][Wp] fp32  = scale * sign(sr - hr) * [0 <= pre <= R] inside the crop, 0 outside
+// =======================================================================================
+__global__ void __launch_bounds__(256) clamp_l1_kernel(const float* __restrict__ pre, const float* __restrict__ hr,
+                                                       float* __restrict__ sr, float* __restrict__ gpre,
+                                                       float* __restrict__ part, int B, int Hp, int Wp, int Hs, int Ws,
+                                                       float R, float gscale) {
+  const long long total = (long long)B * 3 * Hp * Wp;
+  float acc = 0.f;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(t % Wp);
+    long long q = t / Wp;
+    const int y = (int)(q % Hp);
+    const long long bc = q / Hp;
+    float g = 0.f;
+    if (y < Hs && x < Ws) {
+      const float v = pre[t];
+      const float c = fminf(fmaxf(v, 0.f), R);
+      const long long o = (bc * Hs + y) * Ws + x;
+      if (sr) sr[o] = c;
+      if (hr) {
+        const float d = c - hr[o];
+        acc += fabsf(d);
+        const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        g = (v >= 0.f && v <= R) ? sg * gscale : 0.f;
+      }
+    }
+    if (gpre) gpre[t] = g;
+  }
+  acc = wave_sum(acc);
+  __shared__ float sh[4];
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && part) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ void loss_finish_kernel(const float* __restrict__ part, int n, float scale, float* __restrict__ loss) {
+  // single block, deterministic order
+  __shared__ float sh[256];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = sh[0] * scale;
+}
+int launch_clamp_l1(const float* pre, const float* hr, float* sr, float* gpre, float* part, float* loss, int B, int Hp,
+                    int Wp, int Hs, int Ws, float R, float loss_scale, float gscale, hipStream_t st) {
+  const int g = std::min(M2T_LOSS_BLOCKS, grid_for((long long)B * 3 * Hp * Wp));
+  hipLaunchKernelGGL(clamp_l1_kernel, dim3(g), dim3(256), 0, st, pre, hr, sr, gpre, part, B, Hp, Wp, Hs, Ws, R, gscale);
+  M2T_LAUNCH_CHECK();
+  if (loss) {
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, part, g, loss_scale, loss);
+    M2T_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// =======================================================================================
+// fused multi-tensor Adam over the flat parameter buffer   (train.py:81,210)
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+// g is pre-multiplied by gscale (1/world_size after a SUM all-reduce).
+// =======================================================================================
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt, float gscale) {
+  const long long n4 = n / 4;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n4; t += (long long)gridDim.x * blockDim.x) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[t];
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[t];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[t];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[t];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float gi = gg[i] * gscale;
+      mm[i] = b1 * mm[i] + (1.f - b1) * gi;
+      vv[i] = b2 * vv[i] + (1.f - b2) * gi * gi;
+      const float denom = sqrtf(vv[i]) / bc2_sqrt + eps;
+      pp[i] = pp[i] - (lr / bc1) * (mm[i] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[t] = pp;
+    reinterpret_cast<f32x4*>(m)[t] = mm;
+    reinterpret_cast<f32x4*>(v)[t] = vv;
+  }
+  // tail (n not multiple of 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = n4 * 4 + threadIdx.x;
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = p[i] - (lr / bc1) * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                int step, float gscale, hipStream_t st) {
+  const float bc1 = 1.f - powf(b1, (float)step);
+  const float bc2 = 1.f - powf(b2, (float)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, bc1,
+                     sqrtf(bc2), gscale);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// weight packer: ONE launch converts every fp32 master tensor into the element type and
+// layouts the kernels want, driven by a descriptor table built at plan creation.
+// =======================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ master, T* __restrict__ packed,
+                                                   const m2t_pack_desc* __restrict__ descs) {
+  const m2t_pack_desc d = descs[blockIdx.y];
+  const float* s = master + d.src_off;
+  T* o = packed + d.dst_off;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < d.n; e += (long long)gridDim.x * blockDim.x) {
+    long long si = e;
+    switch (d.kind) {
+      case M2T_PACK_COPY: break;
+      case M2T_PACK_TRANSPOSE: {        // src [d0][d1] -> dst [d1][d0]
+        const int r = (int)(e / d.d0), c = (int)(e % d.d0);   // dst row r (0..d1), col c (0..d0)
+        si = (long long)c * d.d1 + r;
+      } break;
+      case M2T_PACK_CONV3: {            // src [O=d0][I=d1][9] -> dst [tap][O][I]
+        const int i = (int)(e % d.d1); const int oo = (int)((e / d.d1) % d.d0); const int tap = (int)(e / ((long long)d.d0 * d.d1));
+        si = ((long long)oo * d.d1 + i) * 9 + tap;
+      } break;
+      case M2T_PACK_CONV3_T: {          // src [O=d0][I=d1][9] -> dst [tap'][I][O], tap' = 8 - tap (flipped kernel)
+        const int oo = (int)(e % d.d0); const int i = (int)((e / d.d0) % d.d1); const int tp = (int)(e / ((long long)d.d0 * d.d1));
+        si = ((long long)oo * d.d1 + i) * 9 + (8 - tp);
+      } break;
+      case M2T_PACK_SHUF_ROWS: {        // src [C*rr][K=d2] (row c*rr+sub) -> dst [sub*C + c][K]; d0 = C, d1 = rr
+        const int kk = (int)(e % d.d2); const int np = (int)(e / d.d2);
+        const int sub = np / d.d0, c = np % d.d0;
+        si = ((long long)c * d.d1 + sub) * d.d2 + kk;
+      } break;
+      case M2T_PACK_SHUF_ROWS_T: {      // src [C*rr][K] -> dst [K][sub*C + c]
+        const int np = (int)(e % ((long long)d.d0 * d.d1)); const int kk = (int)(e / ((long long)d.d0 * d.d1));
+        const int sub = np / d.d0, c = np % d.d0;
+        si = ((long long)c * d.d1 + sub) * d.d2 + kk;
+      } break;
+    }
+    o[e] = from_f<T>(s[si]);
+  }
+}
+int launch_pack(int dt, const float* master, void* packed, const m2t_pack_desc* descs, int ndesc, hipStream_t st) {
+  if (dt == M2T_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(16, ndesc), dim3(256), 0, st, master, (float*)packed, descs);
+  else hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(16, ndesc), dim3(256), 0, st, master, (bf16_t*)packed, descs);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// =======================================================================================
+// layout converters for the operator API / tests: NCHW fp32 <-> NHWC T
+// =======================================================================================
+template <typename T>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int C, int HW, int inverse,
+                                                           float* __restrict__ in_w) {
+  const long long total = (long long)B * C * HW;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    // t indexes NHWC
+    const int c = (int)(t % C);
+    const long long q = t / C;
+    const int p = (int)(q % HW);
+    const int b = (int)(q / HW);
+    const long long s = ((long long)b * C + c) * HW + p;
+    if (!inverse) out[t] = from_f<T>(in[s]); else in_w[s] = to_f(out[t]);
+  }
+}
+int launch_layout(int dt, const float* nchw, void* nhwc, float* nchw_out, int B, int C, int HW, int inverse, hipStream_t st) {
+  const int g = grid_for((long long)B * C * HW);
+  if (dt == M2T_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(g), dim3(256), 0, st, nchw, (float*)nhwc, B, C, HW, inverse, nchw_out);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(g), dim3(256), 0, st, nchw, (bf16_t*)nhwc, B, C, HW, inverse, nchw_out);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}

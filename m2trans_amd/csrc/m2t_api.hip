@@ -1,0 +1,468 @@
+// m2t_api.hip -- the C ABI (include/m2t.h): plan, whole-model forward / backward launch
+// sequences, optimiser and the stand-alone operators.  Host code only; every kernel lives in
+// the k_*.hip files.  The launch sequence restates M2Trans.forward / CFTM.forward
+// (models/M2Trans_network.py:58-76,132-164) and train.py:199-210.
+#include <map>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include "m2t_kernels.h"
+#include "../../include/m2t.h"
+
+static thread_local std::string g_err;
+int m2t_set_hip_error(hipError_t e, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
+  g_err = buf;
+  return (int)e;
+}
+int m2t_set_error(int code, const char* msg) { g_err = msg; return code; }
+
+struct WsTensor { size_t off; size_t n; };   // byte offset, element count
+
+struct m2t_plan {
+  int B, H0, W0, H, W, scale, nb, dt;
+  size_t esz;
+  long long P;                       // padded LR pixels per image
+  int Hs, Ws, Hsp, Wsp;              // SR size (cropped) and padded SR size
+  std::vector<std::string> pnames;
+  std::map<std::string, long long> poff, pnum;
+  long long nparams = 0;
+  std::map<std::string, WsTensor> ws;
+  size_t ws_bytes = 0;
+  std::vector<m2t_pack_desc> descs;
+  std::map<std::string, long long> pk;       // packed weight offsets (elements of T)
+  long long npacked = 0;
+  bool have_seed = false, have_acts = false;
+
+  void add_param(const std::string& n, long long cnt) { pnames.push_back(n); poff[n] = nparams; pnum[n] = cnt; nparams += cnt; }
+  size_t add_ws(const std::string& n, size_t elems, size_t es) {
+    ws_bytes = (ws_bytes + 255) & ~(size_t)255;
+    ws[n] = WsTensor{ws_bytes, elems};
+    ws_bytes += elems * es;
+    return ws[n].off;
+  }
+  long long add_pack(const std::string& n, const std::string& src, int kind, long long cnt, int d0, int d1, int d2) {
+    npacked = (npacked + 7) & ~7LL;
+    m2t_pack_desc d;
+    d.src_off = poff.at(src); d.dst_off = npacked; d.n = cnt; d.kind = kind; d.d0 = d0; d.d1 = d1; d.d2 = d2;
+    descs.push_back(d);
+    pk[n] = npacked;
+    npacked += cnt;
+    return pk[n];
+  }
+};
+
+static const int BR_C[4] = {16, 64, 256, 256};
+static const int BR_L[4] = {0, 1, 2, 2};
+
+extern "C" int m2t_version(void) { return 100; }
+extern "C" const char* m2t_last_error_string(void) { return g_err.c_str(); }
+
+extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale, int n_blocks, int dtype) {
+  if (!out || B < 1 || H0 < 2 || W0 < 2 || (scale != 2 && scale != 3 && scale != 4) || n_blocks < 1 ||
+      (dtype != M2T_F32 && dtype != M2T_BF16))
+    return m2t_set_error(M2T_ERR_ARG, "m2t_plan_create: bad argument");
+  m2t_plan* p = new m2t_plan();
+  p->B = B; p->H0 = H0; p->W0 = W0; p->scale = scale; p->nb = n_blocks; p->dt = dtype;
+  p->esz = (dtype == M2T_F32) ? 4 : 2;
+  p->H = (H0 + 31) / 32 * 32;
+  p->W = (W0 + 31) / 32 * 32;
+  if (p->H - H0 >= H0 || p->W - W0 >= W0) { delete p; return m2t_set_error(M2T_ERR_ARG, "m2t_plan_create: reflect pad needs pad < size"); }
+  p->P = (long long)p->H * p->W;
+  p->Hs = H0 * scale; p->Ws = W0 * scale; p->Hsp = p->H * scale; p->Wsp = p->W * scale;
+  const int s = scale;
+  // ---- parameters: trainable tensors in the reference's registration order ----
+  p->add_param("head.weight", 64 * 3 * 9);
+  p->add_param("head.bias", 64);
+  for (int b = 0; b < n_blocks; ++b) {
+    for (int i = 0; i < 4; ++i) {
+      const int C = BR_C[i];
+      const std::string pre = "body." + std::to_string(b) + ".attn" + std::to_string(i + 1) + ".";
+      p->add_param(pre + "rel_h", 10 * C / 2);
+      p->add_param(pre + "rel_w", 10 * C / 2);
+      p->add_param(pre + "qkv_conv.weight", 3LL * C * C);
+    }
+    const std::string pre = "body." + std::to_string(b) + ".feed_forward.0.";
+    p->add_param(pre + "weight", 64 * 64 * 9);
+    p->add_param(pre + "bias", 64);
+  }
+  if (s == 4) {
+    p->add_param("tail.0.weight", 256 * 64); p->add_param("tail.0.bias", 256);
+    p->add_param("tail.3.weight", 256 * 64); p->add_param("tail.3.bias", 256);
+    p->add_param("tail.6.weight", 3 * 64 * 9);
+  } else {
+    p->add_param("tail.0.weight", 64LL * s * s * 64); p->add_param("tail.0.bias", 64 * s * s);
+    p->add_param("tail.3.weight", 3 * 64 * 9);
+  }
+  // ---- packed weights (element type T) ----
+  for (int b = 0; b < n_blocks; ++b) {
+    for (int i = 0; i < 4; ++i) {
+      const int C = BR_C[i];
+      const std::string pre = "body." + std::to_string(b) + ".attn" + std::to_string(i + 1) + ".";
+      const std::string k = "b" + std::to_string(b) + ".w" + std::to_string(i + 1);
+      p->add_pack(k, pre + "qkv_conv.weight", M2T_PACK_COPY, 3LL * C * C, 0, 0, 0);
+      p->add_pack(k + "T", pre + "qkv_conv.weight", M2T_PACK_TRANSPOSE, 3LL * C * C, 3 * C, C, 0);
+    }
+    const std::string pre = "body." + std::to_string(b) + ".feed_forward.0.weight";
+    p->add_pack("b" + std::to_string(b) + ".wf", pre, M2T_PACK_CONV3, 64 * 64 * 9, 64, 64, 0);
+    p->add_pack("b" + std::to_string(b) + ".wfT", pre, M2T_PACK_CONV3_T, 64 * 64 * 9, 64, 64, 0);
+  }
+  {
+    const int r0 = (s == 4) ? 2 : s;
+    p->add_pack("t0", "tail.0.weight", M2T_PACK_SHUF_ROWS, 64LL * r0 * r0 * 64, 64, r0 * r0, 64);
+    p->add_pack("t0T", "tail.0.weight", M2T_PACK_SHUF_ROWS_T, 64LL * r0 * r0 * 64, 64, r0 * r0, 64);
+    if (s == 4) {
+      p->add_pack("t3", "tail.3.weight", M2T_PACK_SHUF_ROWS, 256 * 64, 64, 4, 64);
+      p->add_pack("t3T", "tail.3.weight", M2T_PACK_SHUF_ROWS_T, 256 * 64, 64, 4, 64);
+    }
+  }
+  // ---- workspace ----
+  const size_t es = p->esz;
+  const long long BP = (long long)B * p->P;
+  p->add_ws("pack_descs", p->descs.size() * sizeof(m2t_pack_desc), 1);
+  p->add_ws("packed", p->npacked, es);
+  for (int b = 0; b <= n_blocks; ++b) p->add_ws("X" + std::to_string(b), BP * 64, es);
+  for (int b = 0; b < n_blocks; ++b) {
+    const std::string k = "b" + std::to_string(b) + ".";
+    p->add_ws(k + "mean", B * 64, 4);
+    p->add_ws(k + "rstd", B * 64, 4);
+    p->add_ws(k + "xc", BP * 64, es);
+    for (int i = 0; i < 4; ++i) {
+      p->add_ws(k + "d" + std::to_string(i + 1), BP * 16, es);
+      p->add_ws(k + "qkv" + std::to_string(i + 1), BP * 48, es);
+    }
+  }
+  p->add_ws("xin", BP * 16, es);
+  p->add_ws("a", BP * 16, es);
+  p->add_ws("norm_part", (size_t)B * M2T_NORM_SPLIT * 64 * 3, 4);
+  p->add_ws("norm_s", (size_t)B * 64 * 2, 4);
+  const int r0 = (s == 4) ? 2 : s;
+  p->add_ws("t1pre", BP * r0 * r0 * 64, es);
+  if (s == 4) p->add_ws("t2pre", BP * 16 * 64, es);
+  p->add_ws("srpre", (size_t)B * 3 * p->Hsp * p->Wsp, 4);
+  p->add_ws("loss_part", M2T_LOSS_BLOCKS, 4);
+  // backward
+  p->add_ws("gpre", (size_t)B * 3 * p->Hsp * p->Wsp, 4);
+  if (s == 4) p->add_ws("g_t2pre", BP * 16 * 64, es);
+  p->add_ws("g_t1pre", BP * r0 * r0 * 64, es);
+  p->add_ws("gT", BP * 64, es);
+  p->add_ws("gA", BP * 64, es);
+  p->add_ws("gB", BP * 64, es);
+  p->add_ws("gxc", BP * 64, es);
+  p->add_ws("gn", BP * 64, es);
+  p->add_ws("ga", BP * 16, es);
+  p->add_ws("gd", BP * 16, es);
+  p->add_ws("gqkv", BP * 48, es);
+  p->add_ws("win", BP * 50, es);
+  p->add_ws("rel_part", 128 * 10 * 256, 4);
+  p->add_ws("slabs", (size_t)256 * 9 * 64 * 64, 4);
+  p->add_ws("col_part", (size_t)256 * 768, 4);
+  p->ws_bytes = (p->ws_bytes + 255) & ~(size_t)255;
+  *out = p;
+  return 0;
+}
+extern "C" void m2t_plan_destroy(m2t_plan* p) { delete p; }
+
+extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
+  if (!p || !key) return -1;
+  const std::string k(key);
+  if (k == "workspace_bytes") return (long long)p->ws_bytes;
+  if (k == "num_params") return p->nparams;
+  if (k == "num_param_tensors") return (long long)p->pnames.size();
+  if (k == "padded_h") return p->H;
+  if (k == "padded_w") return p->W;
+  if (k.rfind("param:", 0) == 0) { auto it = p->poff.find(k.substr(6)); return it == p->poff.end() ? -1 : it->second; }
+  if (k.rfind("numel:", 0) == 0) { auto it = p->pnum.find(k.substr(6)); return it == p->pnum.end() ? -1 : it->second; }
+  if (k.rfind("ws:", 0) == 0) { auto it = p->ws.find(k.substr(3)); return it == p->ws.end() ? -1 : (long long)it->second.off; }
+  if (k.rfind("wsn:", 0) == 0) { auto it = p->ws.find(k.substr(4)); return it == p->ws.end() ? -1 : (long long)it->second.n; }
+  if (k.rfind("packed:", 0) == 0) { auto it = p->pk.find(k.substr(7)); return it == p->pk.end() ? -1 : it->second; }
+  return -1;
+}
+
+#define WSP(name) ((char*)workspace + p->ws.at(name).off)
+#define CK(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
+
+extern "C" int m2t_plan_init_workspace(m2t_plan* p, void* workspace, void* stream) {
+  if (!p || !workspace) return m2t_set_error(M2T_ERR_ARG, "m2t_plan_init_workspace: null");
+  hipError_t e = hipMemcpyAsync(WSP("pack_descs"), p->descs.data(), p->descs.size() * sizeof(m2t_pack_desc),
+                                hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+  e = hipStreamSynchronize((hipStream_t)stream);   // the host table may be freed/moved afterwards
+  if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+  p->have_acts = p->have_seed = false;
+  return 0;
+}
+
+static inline char* packed_ptr(const m2t_plan* p, void* workspace, const std::string& k) {
+  return (char*)workspace + p->ws.at("packed").off + p->pk.at(k) * p->esz;
+}
+
+extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, float* sr, float rgb_range,
+                           int keep_activations, void* workspace, void* stream) {
+  if (!p || !params || !x || !workspace) return m2t_set_error(M2T_ERR_ARG, "m2t_forward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = p->dt, B = p->B, H = p->H, W = p->W, s = p->scale;
+  const long long BP = (long long)B * p->P;
+  (void)keep_activations;   // v1 keeps every activation in the workspace either way
+  CK(launch_pack(dt, params, WSP("packed"), (const m2t_pack_desc*)WSP("pack_descs"), (int)p->descs.size(), st));
+  CK(launch_head_conv_fwd(dt, x, params + p->poff.at("head.weight"), params + p->poff.at("head.bias"), WSP("X0"), B,
+                          p->H0, p->W0, H, W, st));
+  for (int b = 0; b < p->nb; ++b) {
+    const std::string k = "b" + std::to_string(b) + ".";
+    const std::string pre = "body." + std::to_string(b) + ".";
+    void* X = WSP("X" + std::to_string(b));
+    float* mean = (float*)WSP(k + "mean");
+    float* rstd = (float*)WSP(k + "rstd");
+    void* xc = WSP(k + "xc");
+    CK(launch_instnorm_stats(dt, X, mean, rstd, (float*)WSP("norm_part"), B, (int)p->P, st));
+    for (int i = 0; i < 4; ++i) {
+      const int C = BR_C[i], L = BR_L[i];
+      const int h = H >> L, w = W >> L;
+      const long long M = (long long)B * h * w;
+      const std::string an = pre + "attn" + std::to_string(i + 1) + ".";
+      void* d = WSP(k + "d" + std::to_string(i + 1));
+      void* qkv = WSP(k + "qkv" + std::to_string(i + 1));
+      CK(launch_branch_prep(dt, L, X, mean, rstd, xc, i, WSP("xin"), d, B, H, W, st));
+      m2t_gemm_args ga{};
+      ga.A = d; ga.lda = C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1));
+      ga.Y = qkv; ga.ldy = 3 * C; ga.M = M; ga.N = 3 * C; ga.K = C;
+      CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st));
+      const float* rh = params + p->poff.at(an + "rel_h");
+      const float* rw = params + p->poff.at(an + "rel_w");
+      if (i == 0) {
+        // x1 = attn1(x1) + x1 written straight into the concat buffer (:139,163)
+        CK(launch_window_attn_fwd(dt, qkv, rh, rw, xc, 64, 0, d, 16, B, h, w, C, st));
+      } else {
+        CK(launch_window_attn_fwd(dt, qkv, rh, rw, WSP("a"), C, 0, nullptr, 0, B, h, w, C, st));
+        CK(launch_branch_post(dt, L, WSP("a"), WSP("xin"), xc, i, B, H, W, st));
+      }
+    }
+    // x = feed_forward(xc) + x (:164); the last block also folds in `res + x` (:70)
+    CK(launch_conv3x3_c64(dt, xc, packed_ptr(p, workspace, k + "wf"), params + p->poff.at(pre + "feed_forward.0.bias"), X,
+                          (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st));
+  }
+  void* Y = WSP("X" + std::to_string(p->nb));
+  const int r0 = (s == 4) ? 2 : s;
+  {
+    m2t_gemm_args ga{};
+    ga.A = Y; ga.lda = 64; ga.W = packed_ptr(p, workspace, "t0"); ga.Y = WSP("t1pre"); ga.ldy = 64;
+    ga.bias = params + p->poff.at("tail.0.bias"); ga.M = BP; ga.N = 64 * r0 * r0; ga.K = 64;
+    ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
+    CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_BIAS_SHUF, ga, st));
+  }
+  const void* last_pre = WSP("t1pre");
+  if (s == 4) {
+    m2t_gemm_args ga{};
+    ga.A = WSP("t1pre"); ga.lda = 64; ga.W = packed_ptr(p, workspace, "t3"); ga.Y = WSP("t2pre"); ga.ldy = 64;
+    ga.bias = params + p->poff.at("tail.3.bias"); ga.M = BP * 4; ga.N = 256; ga.K = 64;
+    ga.H = 2 * H; ga.Wd = 2 * W; ga.r = 2; ga.C = 64;
+    CK(launch_gemm_nt(dt, M2T_A_GELU, M2T_E_BIAS_SHUF, ga, st));
+    last_pre = WSP("t2pre");
+  }
+  const float* wlast = params + p->poff.at(s == 4 ? "tail.6.weight" : "tail.3.weight");
+  CK(launch_final_conv_fwd(dt, last_pre, wlast, (float*)WSP("srpre"), B, p->Hsp, p->Wsp, st));
+  if (sr)
+    CK(launch_clamp_l1((const float*)WSP("srpre"), nullptr, sr, nullptr, nullptr, nullptr, B, p->Hsp, p->Wsp, p->Hs,
+                       p->Ws, rgb_range, 0.f, 0.f, st));
+  p->have_acts = true;
+  p->have_seed = false;
+  return 0;
+}
+
+extern "C" int m2t_l1_loss(m2t_plan* p, const float* hr, float lambda_l1, double divisor, float rgb_range,
+                           float* loss_out, void* workspace, void* stream) {
+  if (!p || !hr || !workspace) return m2t_set_error(M2T_ERR_ARG, "m2t_l1_loss: null argument");
+  if (!p->have_acts) return m2t_set_error(M2T_ERR_STATE, "m2t_l1_loss: call m2t_forward first");
+  const float sc = (float)((double)lambda_l1 / divisor);
+  CK(launch_clamp_l1((const float*)WSP("srpre"), hr, nullptr, (float*)WSP("gpre"), (float*)WSP("loss_part"), loss_out,
+                     p->B, p->Hsp, p->Wsp, p->Hs, p->Ws, rgb_range, sc, sc, (hipStream_t)stream));
+  p->have_seed = true;
+  return 0;
+}
+
+// upstream gradient -> gradient of the padded pre-clamp output (clamp mask, zero outside the crop)
+__global__ void __launch_bounds__(256) seed_from_grad_kernel(const float* __restrict__ pre, const float* __restrict__ gsr,
+                                                             float* __restrict__ gpre, int B, int Hp, int Wp, int Hs, int Ws, float R) {
+  const long long total = (long long)B * 3 * Hp * Wp;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(t % Wp);
+    long long q = t / Wp;
+    const int y = (int)(q % Hp);
+    const long long bc = q / Hp;
+    float g = 0.f;
+    if (y < Hs && x < Ws) {
+      const float v = pre[t];
+      if (v >= 0.f && v <= R) g = gsr[(bc * Hs + y) * Ws + x];
+    }
+    gpre[t] = g;
+  }
+}
+extern "C" int m2t_set_output_grad(m2t_plan* p, const float* g_sr, float rgb_range, void* workspace, void* stream) {
+  if (!p || !g_sr || !workspace) return m2t_set_error(M2T_ERR_ARG, "m2t_set_output_grad: null argument");
+  if (!p->have_acts) return m2t_set_error(M2T_ERR_STATE, "m2t_set_output_grad: call m2t_forward first");
+  const long long total = (long long)p->B * 3 * p->Hsp * p->Wsp;
+  hipLaunchKernelGGL(seed_from_grad_kernel, dim3((unsigned)std::min<long long>(ceil_divll(total, 256), 4096)), dim3(256), 0,
+                     (hipStream_t)stream, (const float*)WSP("srpre"), g_sr, (float*)WSP("gpre"), p->B, p->Hsp, p->Wsp,
+                     p->Hs, p->Ws, rgb_range);
+  M2T_LAUNCH_CHECK();
+  p->have_seed = true;
+  return 0;
+}
+
+extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, float* grads, void* workspace,
+                            void* stream) {
+  if (!p || !params || !x || !grads || !workspace) return m2t_set_error(M2T_ERR_ARG, "m2t_backward: null argument");
+  if (!p->have_acts || !p->have_seed)
+    return m2t_set_error(M2T_ERR_STATE, "m2t_backward: needs m2t_forward and a seed (m2t_l1_loss / m2t_set_output_grad)");
+  hipStream_t st = (hipStream_t)stream;
+  const int dt = p->dt, B = p->B, H = p->H, W = p->W, s = p->scale;
+  const long long BP = (long long)B * p->P;
+  float* slabs = (float*)WSP("slabs");
+  float* colp = (float*)WSP("col_part");
+  const float* gpre = (const float*)WSP("gpre");
+  int ns = 0;
+  const int r0 = (s == 4) ? 2 : s;
+  // ---- tail ----
+  const std::string wl = (s == 4) ? "tail.6.weight" : "tail.3.weight";
+  const void* last_pre = (s == 4) ? WSP("t2pre") : WSP("t1pre");
+  void* g_last = (s == 4) ? WSP("g_t2pre") : WSP("g_t1pre");
+  CK(launch_final_conv_wgrad(dt, gpre, last_pre, slabs, &ns, B, p->Hsp, p->Wsp, st));
+  CK(launch_reduce_slabs(slabs, grads + p->poff.at(wl), ns, 3 * 64 * 9, 0, 0, 0, 0, st));
+  CK(launch_final_conv_dgrad(dt, gpre, params + p->poff.at(wl), last_pre, g_last, B, p->Hsp, p->Wsp, st));
+  if (s == 4) {
+    // tail.3: u = gelu(t1pre) W3^T + b3, shuffled into t2pre
+    m2t_wgrad_args wa{};
+    wa.G = WSP("g_t2pre"); wa.gmode = M2T_A_UNSHUF; wa.X = WSP("t1pre"); wa.ldx = 64; wa.xmode = M2T_A_GELU;
+    wa.slabs = slabs; wa.M = BP * 4; wa.N = 256; wa.K = 64; wa.H = 2 * H; wa.Wd = 2 * W; wa.r = 2; wa.C = 64;
+    CK(launch_wgrad_tn(dt, wa, &ns, st));
+    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64, st));
+    // bias: column sums in shuffled order, then permute through a 1-slab "reduction"
+    CK(launch_colsum(dt, WSP("g_t2pre"), 0, BP * 4, 256, colp, 256, slabs, 0, st, 1, 2 * H, 2 * W, 2, 64));
+    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.3.bias"), 1, 256, 2, 64, 4, 1, st));
+    m2t_gemm_args ga{};
+    ga.A = WSP("g_t2pre"); ga.W = packed_ptr(p, workspace, "t3T"); ga.Y = WSP("g_t1pre"); ga.ldy = 64;
+    ga.aux = WSP("t1pre"); ga.ldaux = 64; ga.M = BP * 4; ga.N = 64; ga.K = 256;
+    ga.H = 2 * H; ga.Wd = 2 * W; ga.r = 2; ga.C = 64;
+    CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_GELU_GRAD, ga, st));
+  }
+  void* Y = WSP("X" + std::to_string(p->nb));
+  {
+    const int N0 = 64 * r0 * r0;
+    m2t_wgrad_args wa{};
+    wa.G = WSP("g_t1pre"); wa.gmode = M2T_A_UNSHUF; wa.X = Y; wa.ldx = 64; wa.xmode = M2T_A_PLAIN;
+    wa.slabs = slabs; wa.M = BP; wa.N = N0; wa.K = 64; wa.H = H; wa.Wd = W; wa.r = r0; wa.C = 64;
+    CK(launch_wgrad_tn(dt, wa, &ns, st));
+    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.0.weight"), ns, (long long)N0 * 64, 2, 64, r0 * r0, 64, st));
+    CK(launch_colsum(dt, WSP("g_t1pre"), 0, BP, N0, colp, 256, slabs, 0, st, 1, H, W, r0, 64));
+    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.0.bias"), 1, N0, 2, 64, r0 * r0, 1, st));
+    m2t_gemm_args ga{};
+    ga.A = WSP("g_t1pre"); ga.W = packed_ptr(p, workspace, "t0T"); ga.Y = WSP("gT"); ga.ldy = 64;
+    ga.M = BP; ga.N = 64; ga.K = N0; ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
+    CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_PLAIN, ga, st));
+  }
+  // ---- body, last block first.  gy = gradient of X[b+1] ----
+  void* gy = WSP("gT");
+  void* gnext[2] = {WSP("gA"), WSP("gB")};
+  for (int b = p->nb - 1; b >= 0; --b) {
+    const std::string k = "b" + std::to_string(b) + ".";
+    const std::string pre = "body." + std::to_string(b) + ".";
+    void* X = WSP("X" + std::to_string(b));
+    float* mean = (float*)WSP(k + "mean");
+    float* rstd = (float*)WSP(k + "rstd");
+    void* xc = WSP(k + "xc");
+    void* gxc = WSP("gxc");
+    void* gn = WSP("gn");
+    // feed_forward conv: weight / bias / data gradients
+    CK(launch_conv3x3_c64_wgrad(dt, xc, gy, slabs, &ns, B, H, W, st));
+    CK(launch_reduce_slabs(slabs, grads + p->poff.at(pre + "feed_forward.0.weight"), ns, 9 * 64 * 64, 1, 64, 64, 0, st));
+    CK(launch_colsum(dt, gy, 64, BP, 64, colp, 256, grads + p->poff.at(pre + "feed_forward.0.bias"), 0, st));
+    CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st));
+    for (int i = 3; i >= 0; --i) {
+      const int C = BR_C[i], L = BR_L[i];
+      const int h = H >> L, w = W >> L;
+      const long long M = (long long)B * h * w;
+      const std::string an = pre + "attn" + std::to_string(i + 1) + ".";
+      const void* d = WSP(k + "d" + std::to_string(i + 1));
+      const void* qkv = WSP(k + "qkv" + std::to_string(i + 1));
+      const float* rh = params + p->poff.at(an + "rel_h");
+      const float* rw = params + p->poff.at(an + "rel_w");
+      float* grh = grads + p->poff.at(an + "rel_h");
+      float* grw = grads + p->poff.at(an + "rel_w");
+      if (i == 0) {
+        CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 0, WSP("gqkv"), WSP("win"), (float*)WSP("rel_part"), grh, grw, B, h, w, C, st));
+      } else {
+        CK(launch_branch_post_bwd(dt, L, gxc, i, WSP("ga"), B, H, W, st));
+        CK(launch_window_attn_bwd(dt, qkv, rh, rw, WSP("ga"), C, 0, WSP("gqkv"), WSP("win"), (float*)WSP("rel_part"), grh, grw, B, h, w, C, st));
+      }
+      m2t_wgrad_args wa{};
+      wa.G = WSP("gqkv"); wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = d; wa.ldx = C; wa.xmode = M2T_A_PLAIN;
+      wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = 1; wa.Wd = 1; wa.r = 1; wa.C = 64;
+      CK(launch_wgrad_tn(dt, wa, &ns, st));
+      CK(launch_reduce_slabs(slabs, grads + p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0, st));
+      m2t_gemm_args ga{};
+      ga.A = WSP("gqkv"); ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
+      ga.Y = WSP("gd"); ga.ldy = C; ga.M = M; ga.N = C; ga.K = 3 * C; ga.H = 1; ga.Wd = 1; ga.r = 1; ga.C = 64;
+      CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st));
+      CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st));
+    }
+    void* gx = gnext[b & 1];
+    CK(launch_instnorm_bwd(dt, gn, X, mean, rstd, gy, gx, (float*)WSP("norm_part"), (float*)WSP("norm_s"), B, (int)p->P, st));
+    gy = gx;
+  }
+  // head: g(res) = g(X0) from the chain + g(Y) from `res + x`
+  CK(launch_add(dt, gy, WSP("gT"), WSP("gxc"), BP * 64, st));
+  CK(launch_head_conv_wgrad(dt, x, WSP("gxc"), slabs, &ns, B, p->H0, p->W0, H, W, st));
+  CK(launch_reduce_slabs(slabs, grads + p->poff.at("head.weight"), ns, 64 * 27, 0, 0, 0, 0, st));
+  CK(launch_colsum(dt, WSP("gxc"), 64, BP, 64, colp, 256, grads + p->poff.at("head.bias"), 0, st));
+  p->have_seed = false;
+  return 0;
+}
+
+extern "C" int m2t_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                             float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step < 1)
+    return m2t_set_error(M2T_ERR_ARG, "m2t_adam_step: bad argument");
+  return launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
+}
+
+// ---- stand-alone operators ---------------------------------------------------------------
+extern "C" int m2t_dwt(int dtype, int levels, const void* src, void* dst, int B, int H, int W, int C, void* stream) {
+  return launch_dwt(dtype, levels, src, C, 0, dst, C << (2 * levels), 0, B, H, W, C, false, (hipStream_t)stream);
+}
+extern "C" int m2t_iwt(int dtype, int levels, const void* src, void* dst, int B, int H, int W, int C, void* stream) {
+  // src [B][H/S][W/S][C * 4^l] -> dst [B][H][W][C]
+  return launch_dwt(dtype, levels, src, C << (2 * levels), 0, dst, C, 0, B, H, W, C, true, (hipStream_t)stream);
+}
+extern "C" int m2t_pixel_shuffle(const float* in, float* out, int B, int C, int H, int W, int r, void* stream) {
+  return launch_pixel_shuffle_nchw(in, out, B, C, H, W, r, 0, (hipStream_t)stream);
+}
+extern "C" int m2t_pixel_unshuffle(const float* in, float* out, int B, int C, int H, int W, int r, void* stream) {
+  // in [B][C][H*r][W*r] -> out [B][C*r*r][H][W]
+  return launch_pixel_shuffle_nchw(in, out, B, C, H, W, r, 1, (hipStream_t)stream);
+}
+extern "C" int m2t_to_nhwc(int dtype, const float* nchw, void* nhwc, int B, int C, int HW, void* stream) {
+  return launch_layout(dtype, nchw, nhwc, nullptr, B, C, HW, 0, (hipStream_t)stream);
+}
+extern "C" int m2t_to_nchw(int dtype, const void* nhwc, float* nchw, int B, int C, int HW, void* stream) {
+  return launch_layout(dtype, nullptr, const_cast<void*>(nhwc), nchw, B, C, HW, 1, (hipStream_t)stream);
+}
+extern "C" int m2t_window_attention_fwd(int dtype, const void* qkv, const float* rel_h, const float* rel_w, void* out,
+                                        int B, int h, int w, int C, void* stream) {
+  return launch_window_attn_fwd(dtype, qkv, rel_h, rel_w, out, C, 0, nullptr, 0, B, h, w, C, (hipStream_t)stream);
+}
+extern "C" size_t m2t_window_attention_bwd_scratch_bytes(int dtype, int B, int h, int w, int C) {
+  const size_t es = (dtype == M2T_F32) ? 4 : 2;
+  const size_t nwin = (size_t)B * (h / 8) * (w / 8);
+  return nwin * 100 * 2 * C * es + 256 + (size_t)128 * 10 * C * 4;
+}
+extern "C" int m2t_window_attention_bwd(int dtype, const void* qkv, const float* rel_h, const float* rel_w,
+                                        const void* gout, void* gqkv, float* grel_h, float* grel_w, void* scratch, int B,
+                                        int h, int w, int C, void* stream) {
+  const size_t es = (dtype == M2T_F32) ? 4 : 2;
+  const size_t nwin = (size_t)B * (h / 8) * (w / 8);
+  size_t woff = (nwin * 100 * 2 * C * es + 255) & ~(size_t)255;
+  return launch_window_attn_bwd(dtype, qkv, rel_h, rel_w, gout, C, 0, gqkv, scratch, (float*)((char*)scratch + woff),
+                                grel_h, grel_w, B, h, w, C, (hipStream_t)stream);
+}

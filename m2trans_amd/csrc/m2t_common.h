@@ -1,0 +1,175 @@
+// m2t_common.h -- shared device helpers for the gfx950 (MI355X, CDNA4) kernels.
+//
+// Conventions used by every kernel in this directory
+//   * activations live in HBM as NHWC ("pixel-major": [B][H][W][C], channels contiguous)
+//     in element type T = float (parity mode) or __bf16 (throughput mode);
+//   * all accumulation, statistics, softmax and loss arithmetic is fp32;
+//   * contractions run on the matrix cores through ONE abstraction, a 16x16x32 tile
+//     product: one v_mfma_f32_16x16x32_bf16 for bf16, eight v_mfma_f32_16x16x4_f32 for
+//     f32 (exact fp32, a k-ordered fmaf chain).  Both consume the same per-lane operand
+//     shape, "8 consecutive k for (row|col = lane&15), k-group = lane>>4", so a kernel is
+//     written once and instantiated for both element types.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define M2T_WAVE 64
+
+enum m2t_dtype { M2T_F32 = 0, M2T_BF16 = 1 };
+
+// ---------------------------------------------------------------------------------------
+// 8-element operand fragment
+// ---------------------------------------------------------------------------------------
+template <typename T> struct Frag8;
+
+template <> struct __attribute__((aligned(16))) Frag8<float> {
+  float v[8];
+  __device__ __forceinline__ float get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+  __device__ __forceinline__ float v_elem(int i) const { return v[i]; }
+};
+template <> struct __attribute__((aligned(16))) Frag8<bf16_t> {
+  bf16x8 v;
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+  __device__ __forceinline__ bf16_t v_elem(int i) const { return v[i]; }
+};
+
+template <typename T> __device__ __forceinline__ Frag8<T> frag_zero() {
+  Frag8<T> f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.set(i, 0.f);
+  return f;
+}
+
+// 8 consecutive elements from global or LDS (p must be 16-byte aligned)
+__device__ __forceinline__ Frag8<float> load8(const float* p) {
+  Frag8<float> f;
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+  return f;
+}
+__device__ __forceinline__ Frag8<bf16_t> load8(const bf16_t* p) {
+  Frag8<bf16_t> f;
+  f.v = *reinterpret_cast<const bf16x8*>(p);
+  return f;
+}
+__device__ __forceinline__ void store8(float* p, const Frag8<float>& f) {
+  f32x4 a = {f.v[0], f.v[1], f.v[2], f.v[3]};
+  f32x4 b = {f.v[4], f.v[5], f.v[6], f.v[7]};
+  *reinterpret_cast<f32x4*>(p) = a;
+  *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+__device__ __forceinline__ void store8(bf16_t* p, const Frag8<bf16_t>& f) {
+  *reinterpret_cast<bf16x8*>(p) = f.v;
+}
+
+// 4 consecutive elements
+__device__ __forceinline__ void load4(const float* p, float (&o)[4]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3];
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&o)[4]) {
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);
+  o[0] = (float)a[0]; o[1] = (float)a[1]; o[2] = (float)a[2]; o[3] = (float)a[3];
+}
+__device__ __forceinline__ void store4(float* p, const float (&o)[4]) {
+  f32x4 a = {o[0], o[1], o[2], o[3]};
+  *reinterpret_cast<f32x4*>(p) = a;
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float (&o)[4]) {
+  bf16x4 a = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+  *reinterpret_cast<bf16x4*>(p) = a;
+}
+
+template <typename T> __device__ __forceinline__ void load8f(const T* p, float (&o)[8]) {
+  const Frag8<T> f = load8(p);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = f.get(i);
+}
+template <typename T> __device__ __forceinline__ void store8f(T* p, const float (&o)[8]) {
+  Frag8<T> f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f.set(i, o[i]);
+  store8(p, f);
+}
+// 16 consecutive elements from fp32 registers
+template <typename T> __device__ __forceinline__ void store16f(T* p, const float (&o)[16]) {
+  float a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a[i] = o[i]; b[i] = o[8 + i]; }
+  store8f(p, a);
+  store8f(p + 8, b);
+}
+template <typename T> __device__ __forceinline__ void load16f(const T* p, float (&o)[16]) {
+  float a[8], b[8];
+  load8f(p, a);
+  load8f(p + 8, b);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { o[i] = a[i]; o[8 + i] = b[i]; }
+}
+
+__device__ __forceinline__ float to_f(float x) { return x; }
+__device__ __forceinline__ float to_f(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f(float x) { return (T)x; }
+
+// ---------------------------------------------------------------------------------------
+// 16x16x32 tile product:  D[i][j] += sum_k A[i][k] * B[k][j]
+//   lane l supplies A[i = l&15][k = 8*(l>>4) + 0..7]  and  B[k = 8*(l>>4) + 0..7][j = l&15]
+//   lane l receives D[i = 4*(l>>4) + r][j = l&15] in acc[r], r = 0..3
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag8<bf16_t>& a, const Frag8<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag8<float>& a, const Frag8<float>& b) {
+  // eight exact-fp32 16x16x4 products; product j contracts over the four k = 8g + j, g = 0..3
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// misc math
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {   // torch 'reflect' (no edge repeat)
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// host-side launch check
+#define M2T_LAUNCH_CHECK()                                  \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return m2t_set_hip_error(e__, __FILE__, __LINE__); \
+  } while (0)
+
+int m2t_set_hip_error(hipError_t e, const char* file, int line);
+int m2t_set_error(int code, const char* msg);
+
+__host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline long long ceil_divll(long long a, long long b) { return (a + b - 1) / b; }

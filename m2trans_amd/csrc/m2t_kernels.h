@@ -1,0 +1,91 @@
+// m2t_kernels.h -- internal launcher prototypes shared by the .hip files and the C-ABI layer.
+#pragma once
+#include <algorithm>
+#include "m2t_common.h"
+
+#define M2T_NORM_SPLIT 32     // pixel splits per image in the InstanceNorm reductions
+#define M2T_LOSS_BLOCKS 1024  // partial sums of the L1 loss
+#define M2T_MAX_SLABS 64      // split-M slabs of a weight-gradient GEMM
+
+enum m2t_pack_kind {
+  M2T_PACK_COPY = 0, M2T_PACK_TRANSPOSE = 1, M2T_PACK_CONV3 = 2, M2T_PACK_CONV3_T = 3,
+  M2T_PACK_SHUF_ROWS = 4, M2T_PACK_SHUF_ROWS_T = 5
+};
+struct m2t_pack_desc {
+  long long src_off, dst_off, n;
+  int kind, d0, d1, d2;
+};
+
+// ---- k_pointwise.hip --------------------------------------------------------------------
+int launch_dwt(int dt, int L, const void* src, int lds_, int c0, void* dst, int ldd, int d0, int B, int H, int W,
+               int C, bool inverse, hipStream_t st);
+int launch_pixel_shuffle_nchw(const float* in, float* out, int B, int C, int H, int W, int r, int inverse, hipStream_t st);
+int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float* part, int B, int P, hipStream_t st);
+int launch_branch_prep(int dt, int L, const void* x, const float* mean, const float* rstd, const void* xc, int k,
+                       void* xin, void* d, int B, int H, int W, hipStream_t st);
+int launch_branch_post(int dt, int L, const void* a, const void* xin, void* xc, int k, int B, int H, int W, hipStream_t st);
+int launch_branch_post_bwd(int dt, int L, const void* gxc, int k, void* ga, int B, int H, int W, hipStream_t st);
+int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, int k, int B, int H, int W, hipStream_t st);
+int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean, const float* rstd, const void* gres,
+                        void* gx, float* part, float* s, int B, int P, hipStream_t st);
+int launch_add(int dt, const void* a, const void* b, void* o, long long n, hipStream_t st);
+int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* part, int max_part_blocks, float* out,
+                  int accumulate, hipStream_t st, int unshuf = 0, int gH = 0, int gW = 0, int gr = 1, int gC = 64);
+int launch_reduce_slabs(const float* slab, float* out, int ns, long long n, int perm, int p0, int p1, int p2, hipStream_t st);
+int launch_clamp_l1(const float* pre, const float* hr, float* sr, float* gpre, float* part, float* loss, int B, int Hp,
+                    int Wp, int Hs, int Ws, float R, float loss_scale, float gscale, hipStream_t st);
+int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+                int step, float gscale, hipStream_t st);
+int launch_pack(int dt, const float* master, void* packed, const m2t_pack_desc* descs, int ndesc, hipStream_t st);
+int launch_layout(int dt, const float* nchw, void* nhwc, float* nchw_out, int B, int C, int HW, int inverse, hipStream_t st);
+
+// ---- k_gemm.hip -------------------------------------------------------------------------
+// Y[M][N] = A[M][K] * W[N][K]^T  with A-side and epilogue variants
+enum m2t_gemm_a { M2T_A_PLAIN = 0, M2T_A_GELU = 1, M2T_A_UNSHUF = 2 };
+enum m2t_gemm_epi { M2T_E_PLAIN = 0, M2T_E_BIAS = 1, M2T_E_BIAS_SHUF = 2, M2T_E_GELU_GRAD = 3 };
+struct m2t_gemm_args {
+  const void* A; int lda;       // A rows (or, UNSHUF: the [B][H*r][W*r][C] tensor)
+  const void* W;                // [N][K] element type T
+  void* Y; int ldy;             // output (or, SHUF: the [B][H*r][W*r][C] tensor)
+  const float* bias;            // [N] fp32 (E_BIAS*)
+  const void* aux; int ldaux;   // E_GELU_GRAD: pre-activation tensor, same shape as Y
+  long long M; int N, K;
+  int H, Wd, r, C;              // shuffle geometry: rows m = (b, h, w) over [B][H][Wd]; C channels after shuffle
+};
+int launch_gemm_nt(int dt, int amode, int emode, const m2t_gemm_args& a, hipStream_t st);
+// dW[N][K] (fp32 slabs) = sum_m G[m][N]^T X[m][K];  G/X side variants as above
+struct m2t_wgrad_args {
+  const void* G; int ldg; int gmode;   // M2T_A_PLAIN or M2T_A_UNSHUF
+  const void* X; int ldx; int xmode;   // M2T_A_PLAIN or M2T_A_GELU
+  float* slabs;                        // [nslab][N][K]
+  long long M; int N, K;
+  int H, Wd, r, C;
+};
+int launch_wgrad_tn(int dt, const m2t_wgrad_args& a, int* nslab_out, hipStream_t st);
+
+// ---- k_conv.hip -------------------------------------------------------------------------
+int launch_head_conv_fwd(int dt, const float* x, const float* w, const float* b, void* out, int B, int H0, int W0,
+                         int H, int W, hipStream_t st);
+int launch_head_conv_wgrad(int dt, const float* x, const void* gout, float* slabs, int* nslab, int B, int H0, int W0,
+                           int H, int W, hipStream_t st);
+// 64->64 3x3, zero padding.  wp: packed [9][64 out][64 in] (T). y = conv(x) + bias + res1 + res2 (each optional)
+int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias, const void* res1, const void* res2,
+                       void* y, int B, int H, int W, hipStream_t st);
+int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, int* nslab, int B, int H, int W,
+                             hipStream_t st);
+// tail conv 64->3, reflect padding, input = GELU(tpre); output NCHW fp32 [B][3][H][W]
+int launch_final_conv_fwd(int dt, const void* tpre, const float* w, float* out, int B, int H, int W, hipStream_t st);
+int launch_final_conv_dgrad(int dt, const float* gout, const float* w, const void* tpre, void* gtpre, int B, int H, int W,
+                            hipStream_t st);
+int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* slabs, int* nslab, int B, int H, int W,
+                            hipStream_t st);
+
+// ---- k_attn.hip -------------------------------------------------------------------------
+// qkv [B][h][w][3C] (q | k | v), rel_h/rel_w fp32 [10][C/2];  out rows at ldo (+ optional residual rows at ldr)
+int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0,
+                           const void* res, int ldr, int B, int h, int w, int C, hipStream_t st);
+// gout [B][h][w][ldg] (channels gc0..gc0+C) -> gqkv [B][h][w][3C]; per-window dK/dV scratch `win` [B*L][100][2C] (T);
+// rel-pos gradient slabs
+int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
+                           int gc0, void* gqkv, void* win, float* rel_part, float* grel_h, float* grel_w, int B, int h,
+                           int w, int C, hipStream_t st);

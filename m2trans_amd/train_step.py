@@ -1,0 +1,109 @@
+"""The training step of the reference (train.py:173-214, setup :76-82,358), driven on MI355X.
+
+``TrainStep`` restates the hot loop body
+
+    optimizer.zero_grad(); sr = model(lr); loss = L1Loss()(sr, hr) * lambda_l1 (+ const clip term);
+    loss.backward(); optimizer.step()
+
+as five C-ABI calls on one stream (forward, loss+seed, backward, fused Adam; plus ONE RCCL
+all-reduce of the flat gradient bucket when world_size > 1), with no host synchronisation:
+the loss stays on the device (the reference's three ``float(loss)`` syncs per step,
+train.py:212-214, are left to the caller's logging cadence).
+
+Data parallelism (replaces nn.DataParallel, train.py:73): one process per GPU, persistent
+replicas, equal shards of the global batch; each rank divides its L1 sum by the GLOBAL element
+count, so SUM-all-reduced gradients equal the full-batch gradient.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .M2Trans_network import M2Trans
+
+
+def cosine_lr(epoch: int, lr0: float = 1e-4, eta_min: float = 1e-6, t_max: float = 200.0) -> float:
+    """CosineAnnealingLR(optimizer, float(epochs), eta_min) evaluated at `epoch` scheduler steps
+    (train.py:82,358; the scheduler is stepped once per epoch)."""
+    return eta_min + 0.5 * (lr0 - eta_min) * (1.0 + math.cos(math.pi * epoch / t_max))
+
+
+class TrainStep:
+    def __init__(self, model: M2Trans, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 lambda_l1: float = 1.0, process_group=None, world_size: Optional[int] = None,
+                 grad_bucket_dtype: torch.dtype = torch.float32):
+        self.model = model
+        self.lr = float(lr)
+        self.betas = (float(betas[0]), float(betas[1]))
+        self.eps = float(eps)
+        self.lambda_l1 = float(lambda_l1)
+        self.pg = process_group
+        if world_size is None:
+            world_size = torch.distributed.get_world_size(process_group) if (
+                torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        self.world_size = int(world_size)
+        self.step_count = 0
+        flat = model.flat_params
+        if not flat.is_cuda:
+            raise _lib.M2TError("TrainStep needs the model on a HIP device (model.to('cuda'))")
+        self.grads = model.attach_flat_grads()
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.grad_bucket_dtype = grad_bucket_dtype
+
+    def set_lr(self, lr: float):
+        self.lr = float(lr)
+
+    # -- pieces (also used by tests) -------------------------------------------------------
+    def forward_backward(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
+        """forward + L1 + backward into model.flat_grads; returns the device loss tensor
+        (this rank's share of the global mean)."""
+        m = self.model
+        lib = _lib.load()
+        plan = m._plan_for(lr_img)
+        lr_img = lr_img.contiguous().float()
+        hr_img = hr_img.contiguous().float()
+        B = lr_img.shape[0]
+        if tuple(hr_img.shape) != (B, 3, lr_img.shape[2] * m.scale, lr_img.shape[3] * m.scale):
+            raise _lib.M2TError("hr shape must be [B,3,H*scale,W*scale]")
+        divisor = float(hr_img.numel()) * self.world_size      # global mean (equal shards)
+        plan.gen += 1
+        with torch.cuda.device(lr_img.device):
+            st = _lib.stream_ptr()
+            ws = _lib.ptr(plan.workspace)
+            _lib.check(lib.m2t_forward(plan.handle, _lib.ptr(m.flat_params), _lib.ptr(lr_img), None,
+                                       float(m.rgb_range), 1, ws, st), "m2t_forward")
+            _lib.check(lib.m2t_l1_loss(plan.handle, _lib.ptr(hr_img), self.lambda_l1, divisor, float(m.rgb_range),
+                                       _lib.ptr(self.loss), ws, st), "m2t_l1_loss")
+            _lib.check(lib.m2t_backward(plan.handle, _lib.ptr(m.flat_params), _lib.ptr(lr_img), _lib.ptr(self.grads),
+                                        ws, st), "m2t_backward")
+        return self.loss
+
+    def all_reduce_grads(self):
+        if self.world_size > 1:
+            if self.grad_bucket_dtype == torch.float32:
+                torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            else:
+                b = self.grads.to(self.grad_bucket_dtype)
+                torch.distributed.all_reduce(b, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+                self.grads.copy_(b)
+
+    def optimizer_step(self):
+        self.step_count += 1
+        lib = _lib.load()
+        with torch.cuda.device(self.grads.device):
+            _lib.check(lib.m2t_adam_step(_lib.ptr(self.model.flat_params), _lib.ptr(self.grads), _lib.ptr(self.exp_avg),
+                                         _lib.ptr(self.exp_avg_sq), self.grads.numel(), self.lr, self.betas[0],
+                                         self.betas[1], self.eps, self.step_count, 1.0, _lib.stream_ptr()),
+                       "m2t_adam_step")
+
+    # -- the step ----------------------------------------------------------------------------
+    def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
+        loss = self.forward_backward(lr_img, hr_img)
+        self.all_reduce_grads()
+        self.optimizer_step()
+        return loss

@@ -194,10 +194,13 @@ def window_attention_core(q: Tensor, k: Tensor, v: Tensor, rel_h: Tensor, rel_w:
     return out.reshape(B, C, h, w)                         # :332
 
 
-def tblock(x: Tensor, p: Params, prefix: str) -> Tensor:
-    """TBlock.forward (models/M2Trans_network.py:290-340), sr=1, no pad branch."""
+def tblock(x: Tensor, p: Params, prefix: str, cap=None, cap_key: str = "") -> Tensor:
+    """TBlock.forward (models/M2Trans_network.py:290-340), sr=1, no pad branch.
+    ``cap`` (optional dict) records intermediates for the kernel-level parity tests."""
     wq = p[prefix + "qkv_conv.weight"]
     qkv = F.conv2d(x, wq)                                  # :307
+    if cap is not None:
+        cap[cap_key] = qkv
     q, k, v = torch.chunk(qkv, 3, dim=1)                   # :308
     return window_attention_core(q, k, v, p[prefix + "rel_h"], p[prefix + "rel_w"])
 
@@ -213,17 +216,23 @@ def instance_norm(x: Tensor, eps: float = 1e-5) -> Tensor:
     return (x - mu) / torch.sqrt(var + eps)
 
 
-def cftm(x: Tensor, p: Params, prefix: str) -> Tensor:
+def cftm(x: Tensor, p: Params, prefix: str, cap=None, ck: str = "") -> Tensor:
     """CFTM.forward, norm branch (models/M2Trans_network.py:132-164)."""
     x1, x2, x3, x4 = torch.chunk(instance_norm(x), 4, dim=1)
-    x1 = tblock(x1, p, prefix + "attn1.") + x1
+    d1 = x1
+    x1 = tblock(d1, p, prefix + "attn1.", cap, ck + "qkv1") + x1
     x2 = (x2 + x1) / 2.0
-    x2 = iwt(tblock(dwt(x2), p, prefix + "attn2.")) + x2
+    d2 = dwt(x2)
+    x2 = iwt(tblock(d2, p, prefix + "attn2.", cap, ck + "qkv2")) + x2
     x3 = (x3 + x2) / 2.0
-    x3 = iwt(iwt(tblock(dwt(dwt(x3)), p, prefix + "attn3."))) + x3
+    d3 = dwt(dwt(x3))
+    x3 = iwt(iwt(tblock(d3, p, prefix + "attn3.", cap, ck + "qkv3"))) + x3
     x4 = (x4 + x3) / 2.0
-    x4 = iwt(iwt(tblock(dwt(dwt(x4)), p, prefix + "attn4."))) + x4
+    d4 = dwt(dwt(x4))
+    x4 = iwt(iwt(tblock(d4, p, prefix + "attn4.", cap, ck + "qkv4"))) + x4
     xc = torch.cat((x1, x2, x3, x4), dim=1)
+    if cap is not None:
+        cap[ck + "d1"], cap[ck + "d2"], cap[ck + "d3"], cap[ck + "d4"], cap[ck + "xc"] = d1, d2, d3, d4, xc
     return F.conv2d(xc, p[prefix + "feed_forward.0.weight"], p[prefix + "feed_forward.0.bias"],
                     padding=1) + x                          # zero padding (:124-126,164)
 
@@ -241,27 +250,38 @@ def conv3x3_reflect(x: Tensor, w: Tensor, b=None) -> Tensor:
     return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b)
 
 
-def tail(x: Tensor, p: Params, scale: int) -> Tensor:
+def tail(x: Tensor, p: Params, scale: int, cap=None) -> Tensor:
     """models/M2Trans_network.py:41-56."""
     if scale == 4:
-        x = F.gelu(F.pixel_shuffle(F.conv2d(x, p["tail.0.weight"], p["tail.0.bias"]), 2))
-        x = F.gelu(F.pixel_shuffle(F.conv2d(x, p["tail.3.weight"], p["tail.3.bias"]), 2))
-        return conv3x3_reflect(x, p["tail.6.weight"])
-    x = F.gelu(F.pixel_shuffle(F.conv2d(x, p["tail.0.weight"], p["tail.0.bias"]), scale))
-    return conv3x3_reflect(x, p["tail.3.weight"])
+        t1 = F.pixel_shuffle(F.conv2d(x, p["tail.0.weight"], p["tail.0.bias"]), 2)
+        t2 = F.pixel_shuffle(F.conv2d(F.gelu(t1), p["tail.3.weight"], p["tail.3.bias"]), 2)
+        if cap is not None:
+            cap["t1pre"], cap["t2pre"] = t1, t2
+        return conv3x3_reflect(F.gelu(t2), p["tail.6.weight"])
+    t1 = F.pixel_shuffle(F.conv2d(x, p["tail.0.weight"], p["tail.0.bias"]), scale)
+    if cap is not None:
+        cap["t1pre"] = t1
+    return conv3x3_reflect(F.gelu(t1), p["tail.3.weight"])
 
 
 def forward(x: Tensor, p: Params, scale: int, n_blocks: int, rgb_range: float = 1.0,
-            return_preclamp: bool = False) -> Tensor:
-    """M2Trans.forward (models/M2Trans_network.py:58-76)."""
+            return_preclamp: bool = False, cap=None) -> Tensor:
+    """M2Trans.forward (models/M2Trans_network.py:58-76).  ``cap`` (optional dict) collects the
+    intermediates under the names of the HIP workspace tensors (NCHW here)."""
     H, W = x.shape[-2:]
     x = pad_to_multiple(x)
     res = conv3x3_reflect(x, p["head.weight"], p["head.bias"])   # :63
     y = res
     for b in range(n_blocks):
-        y = cftm(y, p, f"body.{b}.")
+        if cap is not None:
+            cap[f"X{b}"] = y
+        y = cftm(y, p, f"body.{b}.", cap, f"b{b}.")
     y = res + y                                                  # :70
-    y = tail(y, p, scale)                                        # :72
+    if cap is not None:
+        cap[f"X{n_blocks}"] = y
+    y = tail(y, p, scale, cap)                                   # :72
+    if cap is not None:
+        cap["srpre"] = y
     if return_preclamp:
         return y[:, :, : H * scale, : W * scale]
     y = torch.clamp(y, 0.0, rgb_range)                           # :74

@@ -1,0 +1,47 @@
+"""Helpers shared by the -m gpu parity tests (HIP path vs the CPU oracle)."""
+from __future__ import annotations
+
+import types
+
+import torch
+
+from oracle import m2trans_oracle as O
+
+
+def make_args(scale=4, n_blocks=8, compute_dtype="fp32"):
+    return types.SimpleNamespace(n_feats=64, scale=scale, rgb_range=1.0, n_blocks=n_blocks, colors=3,
+                                 compute_dtype=compute_dtype)
+
+
+def build_model(scale, n_blocks, compute_dtype="fp32", params=None, device="cuda"):
+    from m2trans_amd.M2Trans_network import create_model
+    model = create_model(make_args(scale, n_blocks, compute_dtype))
+    if params is None:
+        params = O.closed_form_params(64, scale, n_blocks)
+    torch.nn.Module.load_state_dict(model, {k: v.clone() for k, v in params.items()}, strict=True)
+    return model.to(device), params
+
+
+def nchw_to_nhwc(t: torch.Tensor) -> torch.Tensor:
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nhwc_to_nchw(t: torch.Tensor) -> torch.Tensor:
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rms_rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-30))
+
+
+def ws_nchw(plan, name, B, H, W, C):
+    """Workspace tensor (NHWC in the plan's dtype) -> float32 NCHW on the CPU."""
+    return nhwc_to_nchw(plan.ws_tensor(name).view(B, H, W, C).float()).cpu()
