@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--scale", type=int, default=4)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--cpu-baseline-batch", type=int, default=2)
     return ap.parse_args()
 
@@ -49,11 +50,23 @@ def synthetic_batch(B, h, scale, rank, step, device):
     return lr, hr
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: min(affinity mask, cgroup cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(args):
     """The CPU oracle (plain PyTorch restatement pinned to the reference, oracle/) timed on the
     host cores on a bounded sample: the same x4 128x128 train step at a small batch."""
     from oracle import m2trans_oracle as O
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
     B = args.cpu_baseline_batch
     p = O.closed_form_params(64, args.scale, 8)
@@ -69,10 +82,12 @@ def cpu_baseline(args):
         for k in names:
             p[k], m[k], v[k] = O.adam_update(p[k], gr[k], m[k], v[k], step, 1e-4)
 
+    tw = time.perf_counter()
     one(1)                          # warm-up
+    tw = time.perf_counter() - tw
     t0 = time.perf_counter()
     n = 0
-    while n < 3 or (time.perf_counter() - t0 < 10.0 and n < 8):
+    while n < 1 or (n < 3 and tw < 15.0) or (time.perf_counter() - t0 < 10.0 and n < 8 and tw < 4.0):
         n += 1
         one(n + 1)
     dt = (time.perf_counter() - t0) / n
@@ -109,16 +124,24 @@ def main():
     B = args.batch
     batches = [synthetic_batch(B, args.lr_size, args.scale, rank, s, device) for s in range(2)]
 
+    from m2trans_amd import profile as m2t_profile
+    dominant_mask = 0
     for s in range(args.warmup):
+        if rank == 0 and not args.no_kernel_events and s == args.warmup - 1:
+            m2t_profile.enable()      # last warm-up step: time every category to find the dominant kernel
         ts.step(*batches[s % 2])
     torch.cuda.synchronize()
+    if rank == 0 and not args.no_kernel_events and args.warmup > 0:
+        tt = m2t_profile.read_all()
+        top = max(range(len(m2t_profile.CATS)), key=lambda i: tt[m2t_profile.CATS[i]][0])
+        dominant_mask = 1 << top
+        m2t_profile.enable(0)
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    prof = _lib.load()
-    have_prof = hasattr(prof, "m2t_profile_enable")
-    if have_prof:
-        prof.m2t_profile_enable(1)
+    if rank == 0 and not args.no_kernel_events:
+        # HIP events on the launch stream around the dominant kernel only (keeps the timed region honest)
+        m2t_profile.enable(dominant_mask or m2t_profile.ALL_MASK)
     t0 = time.perf_counter()
     for s in range(args.steps):
         ts.step(*batches[s % 2])
@@ -133,10 +156,10 @@ def main():
         dt = float(t)
     loss = float(ts.loss)
     roofline = None
-    if have_prof:
-        from m2trans_amd.profile import roofline_report
-        roofline = roofline_report(args, B)
-        prof.m2t_profile_enable(0)
+    if rank == 0 and not args.no_kernel_events:
+        roofline = m2t_profile.roofline_report(B, args.lr_size, args.scale, args.dtype, args.steps,
+                                               os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+        m2t_profile.enable(0)
 
     if rank == 0:
         out = {

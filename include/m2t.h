@@ -76,6 +76,11 @@ int m2t_backward(m2t_plan* p, const float* params, const float* x, float* grads,
 int m2t_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                   float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
 
+/* ---- measurement: per-kernel-category timing with HIP events recorded on the launch stream.
+ * category ids are listed in m2trans_amd/profile.py; mask bit i enables category i; 0 = off. */
+int m2t_profile_enable(unsigned long long category_mask);
+int m2t_profile_read(int category, double* total_ms, long long* launches);
+
 /* ---- operators (NHWC tensors in `dtype` unless stated) ---------------------------------- */
 /* DWT.forward / IWT.forward (models/M2Trans_network.py:198-237), `levels` in {1,2} applied
  * back-to-back; bit-exact in float32.  src [B,H,W,C] <-> dst [B,H/2^l,W/2^l,C*4^l]. */

@@ -28,6 +28,8 @@ SIGNATURES = {
     "m2t_set_output_grad": (_i, [_vp, _vp, _f, _vp, _vp]),
     "m2t_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "m2t_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f, _vp]),
+    "m2t_profile_enable": (_i, [C.c_ulonglong]),
+    "m2t_profile_read": (_i, [_i, C.POINTER(_d), C.POINTER(_ll)]),
     "m2t_dwt": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "m2t_iwt": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "m2t_pixel_shuffle": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

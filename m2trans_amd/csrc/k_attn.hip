@@ -15,27 +15,9 @@
 #include "m2t_kernels.h"
 
 #define WA_NK 100
-#define WA_KT 7          // key tiles (112 keys)
-#define WA_KP 136        // transposed row length (128 keys + 8 pad)
+#define WA_KT 7          // key tiles that can hold real keys (112)
+#define WA_KR 128        // key rows staged (4 contraction chunks of 32)
 #define WA_QP 72         // 64 queries + 8 pad
-
-template <typename T> __device__ __forceinline__ Frag8<T> load4x2(const T* p0, const T* p1);
-template <> __device__ __forceinline__ Frag8<float> load4x2(const float* p0, const float* p1) {
-  Frag8<float> f;
-  const f32x4 a = *reinterpret_cast<const f32x4*>(p0);
-  const f32x4 b = *reinterpret_cast<const f32x4*>(p1);
-  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
-  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
-  return f;
-}
-template <> __device__ __forceinline__ Frag8<bf16_t> load4x2(const bf16_t* p0, const bf16_t* p1) {
-  Frag8<bf16_t> f;
-  const bf16x4 a = *reinterpret_cast<const bf16x4*>(p0);
-  const bf16x4 b = *reinterpret_cast<const bf16x4*>(p1);
-  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
-  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
-  return f;
-}
 
 struct WinGeom {
   int h, w, nw, nh;
@@ -61,12 +43,13 @@ __device__ __forceinline__ WinGeom make_geom(int h, int w) {
   return g;
 }
 
-// stage K^ chunk (keys x CW channels, row-major, rel-pos added, pad keys / pad channels = 0)
+// stage the K^ chunk row-major: 128 key rows x CW channels; real keys get k + rel-pos
+// (zero-padded phantom keys = rel-pos alone), rows >= 100 and channels >= CC are zero
 template <typename T, int C, int CC, int CW>
 __device__ __forceinline__ void stage_khat(T (*Ks)[CW + 8], const T* __restrict__ qkv, const float* __restrict__ rel_h,
                                            const float* __restrict__ rel_w, const WinGeom& gm, int c0, int tid) {
   constexpr int VEC = CW / 8;
-  for (int idx = tid; idx < WA_KT * 16 * VEC; idx += 256) {
+  for (int idx = tid; idx < WA_KR * VEC; idx += 256) {
     const int cv = idx % VEC, key = idx / VEC;
     const int c = cv * 8;
     float v[8];
@@ -84,12 +67,12 @@ __device__ __forceinline__ void stage_khat(T (*Ks)[CW + 8], const T* __restrict_
     store8f(&Ks[key][c], v);
   }
 }
-// stage a row-major chunk of keys x CW channels from channel offset `coff` of qkv (V rows), zero outside
+// stage a row-major chunk of 128 key rows x CW channels from channel offset `coff` of qkv (V), zero outside
 template <typename T, int C, int CC, int CW>
 __device__ __forceinline__ void stage_keys_rows(T (*Vs)[CW + 8], const T* __restrict__ qkv, int coff, const WinGeom& gm,
                                                 int c0, int tid) {
   constexpr int VEC = CW / 8;
-  for (int idx = tid; idx < WA_KT * 16 * VEC; idx += 256) {
+  for (int idx = tid; idx < WA_KR * VEC; idx += 256) {
     const int cv = idx % VEC, key = idx / VEC;
     const int c = cv * 8;
     Frag8<T> f = frag_zero<T>();
@@ -98,50 +81,17 @@ __device__ __forceinline__ void stage_keys_rows(T (*Vs)[CW + 8], const T* __rest
     store8(&Vs[key][c], f);
   }
 }
-// stage TRANSPOSED key-side chunk: dst[c][key] for keys < 100 (pad keys must be pre-zeroed);
-// with_rel adds the relative-position embedding (K^)
-template <typename T, int C, int CC, bool WITH_REL>
-__device__ __forceinline__ void stage_keys_T(T (*dst)[WA_KP], const T* __restrict__ qkv, int coff,
-                                             const float* __restrict__ rel_h, const float* __restrict__ rel_w,
-                                             const WinGeom& gm, int c0, int tid) {
-  constexpr int VEC = CC / 8;
-  for (int idx = tid; idx < 128 * VEC; idx += 256) {
-    const int key = idx & 127, cv = idx >> 7;
-    if (key >= WA_NK) continue;
-    const int c = cv * 8;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    long long pix;
-    if (gm.key_pixel(key, pix)) load8f(qkv + pix * (3 * C) + coff + c0 + c, v);
-    if (WITH_REL) {
-      const int kr = key / 10, kc = key - kr * 10;
-      const int cc = c0 + c;
-      const float* rp = (cc < C / 2) ? (rel_h + kr * (C / 2) + cc) : (rel_w + kc * (C / 2) + (cc - C / 2));
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += rp[e];
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dst[c + e][key] = from_f<T>(v[e]);
-  }
-}
-// stage TRANSPOSED query-side chunk: dst[c][q] = src[query pixel][coff + c0 + c]
-template <typename T, int CC>
-__device__ __forceinline__ void stage_queries_T(T (*dst)[WA_QP], const T* __restrict__ src, int ld, int coff,
-                                                const WinGeom& gm, int c0, int tid) {
-  constexpr int VEC = CC / 8;
+// stage a row-major chunk of the 64 query rows x CW channels: dst[q][c] = src[query pixel][coff + c0 + c]
+template <typename T, int CC, int CW>
+__device__ __forceinline__ void stage_query_rows(T (*dst)[CW + 8], const T* __restrict__ src, int ld, int coff,
+                                                 const WinGeom& gm, int c0, int tid) {
+  constexpr int VEC = CW / 8;
   for (int idx = tid; idx < 64 * VEC; idx += 256) {
-    const int q = idx & 63, cv = idx >> 6;
-    const Frag8<T> f = load8(src + gm.query_pixel(q) * ld + coff + c0 + cv * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dst[cv * 8 + e][q] = f.v_elem(e);
+    const int cv = idx % VEC, q = idx / VEC;
+    Frag8<T> f = frag_zero<T>();
+    if (cv * 8 < CC) f = load8(src + gm.query_pixel(q) * ld + coff + c0 + cv * 8);
+    store8(&dst[q][cv * 8], f);
   }
-}
-
-// row permutation of a 64-row operand so that a lane's accumulators over the 4 row tiles
-// are 16 consecutive rows (16 g + 4 mt + r); identity when there is a single tile
-template <int NT> __device__ __forceinline__ int perm_row(int mt, int i) {
-  return (NT == 4) ? (16 * (i >> 2) + 4 * mt + (i & 3)) : i;
 }
 
 // =======================================================================================
@@ -155,19 +105,13 @@ __global__ void __launch_bounds__(256) window_attn_fwd_kernel(const T* __restric
   constexpr int CW = (CC < 32) ? 32 : CC;     // staged width (MFMA k-chunk is 32)
   constexpr int NCH = C / CC;
   constexpr int NT = CC / 16;
-  __shared__ __attribute__((aligned(16))) T Ks[WA_KT * 16][CW + 8];
-  __shared__ __attribute__((aligned(16))) T VT[CC][WA_KP];
+  constexpr int LD = CW + 8;
+  __shared__ __attribute__((aligned(16))) T Ks[WA_KR][LD];   // K^ chunk, then the V chunk (row-major [key][c])
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const WinGeom gm = make_geom(h, w);
   const int q = 16 * wv + lr;
   const long long qpix = gm.query_pixel(q);
-
-  // zero the key padding of VT once (keys 100..135 are never written by the stagers)
-  for (int idx = tid; idx < CC * (WA_KP - WA_NK); idx += 256) {
-    const int r = idx / (WA_KP - WA_NK), k = WA_NK + idx % (WA_KP - WA_NK);
-    VT[r][k] = from_f<T>(0.f);
-  }
 
   // ---- S^T = K^ Q^T ----
   f32x4 s[WA_KT];
@@ -226,12 +170,12 @@ __global__ void __launch_bounds__(256) window_attn_fwd_kernel(const T* __restric
       pf[c4].set(j, (t < WA_KT) ? s[t < WA_KT ? t : 0][j & 3] * inv : 0.f);
     }
 
-  // ---- O^T = V^T P^T, 64 output channels at a time ----
+  // ---- O^T = V^T P^T, one channel chunk at a time; V^T fragments by transposing LDS reads ----
 #pragma unroll 1
   for (int ch = 0; ch < NCH; ++ch) {
     const int c0 = ch * CC;
     __syncthreads();
-    stage_keys_T<T, C, CC, false>(VT, qkv, 2 * C, nullptr, nullptr, gm, c0, tid);
+    stage_keys_rows<T, C, CC, CW>(Ks, qkv, 2 * C, gm, c0, tid);
     __syncthreads();
     f32x4 o[NT];
 #pragma unroll
@@ -240,33 +184,21 @@ __global__ void __launch_bounds__(256) window_attn_fwd_kernel(const T* __restric
     for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
       for (int mt = 0; mt < NT; ++mt) {
-        const int d = perm_row<NT>(mt, lr);
-        const Frag8<T> vf = load4x2(&VT[d][32 * c4 + 4 * g], &VT[d][32 * c4 + 16 + 4 * g]);
+        const Frag8<T> vf = load8_tr(&Ks[32 * c4 + 4 * g][16 * mt], &Ks[32 * c4 + 16 + 4 * g][16 * mt], LD, lane);
         mma16(o[mt], vf, pf[c4]);
       }
-    // lane (q, g): NT == 4 -> channels c0 + 16 g + 4 mt + r ; NT == 1 -> c0 + 4 g + r
-    if (NT == 4) {
-      float v[16];
+    // lane (q, g) holds channels c0 + 16 mt + 4 g + r
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[4 * mt + r] = o[mt][r];
-      if (res) {
-        float p[16];
-        load16f(res + qpix * ldr + c0 + 16 * g, p);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += p[e];
-      }
-      store16f(out + qpix * ldo + oc0 + c0 + 16 * g, v);
-    } else {
-      float v[4] = {o[0][0], o[0][1], o[0][2], o[0][3]};
+    for (int mt = 0; mt < NT; ++mt) {
+      float v[4] = {o[mt][0], o[mt][1], o[mt][2], o[mt][3]};
+      const int cc = c0 + 16 * mt + 4 * g;
       if (res) {
         float p[4];
-        load4(res + qpix * ldr + c0 + 4 * g, p);
+        load4(res + qpix * ldr + cc, p);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += p[e];
       }
-      store4(out + qpix * ldo + oc0 + c0 + 4 * g, v);
+      store4(out + qpix * ldo + oc0 + cc, v);
     }
   }
 }
@@ -275,6 +207,7 @@ int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const fl
                            const void* res, int ldr, int B, int h, int w, int C, hipStream_t st) {
   if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn: h,w must be multiples of 8");
   const int nwin = B * (h / 8) * (w / 8);
+  M2TProfScope ps(C == 16 ? M2T_PROF_ATTN_FWD_16 : (C == 64 ? M2T_PROF_ATTN_FWD_64 : M2T_PROF_ATTN_FWD_256), st);
 #define GO(T_, C_) hipLaunchKernelGGL((window_attn_fwd_kernel<T_, C_>), dim3(nwin), dim3(256), 0, st, (const T_*)qkv, rel_h, rel_w, (T_*)out, ldo, oc0, (const T_*)res, ldr, h, w)
   if (dt == M2T_F32) {
     if (C == 16) GO(float, 16); else if (C == 64) GO(float, 64); else if (C == 256) GO(float, 256);
@@ -294,27 +227,30 @@ int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const fl
 //   dq = dS K^ ; dK^ = dS^T q ; dV = P^T dO
 // dq goes straight to gqkv[..., 0:C]; dK^ / dV go to the window-major scratch `win`
 // [B*L][100][2C] (dK^ | dV) that halo_gather sums over the <= 4 windows covering a pixel.
+// The relative-position gradient of the window (dK^ summed over key columns / rows, phantom
+// keys included) is reduced from the fp32 accumulators and written to relw [B*L][10][C].
 // =======================================================================================
 template <typename T, int C>
 __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rel_h,
                                                               const float* __restrict__ rel_w, const T* __restrict__ go,
                                                               int ldg, int gc0, T* __restrict__ gqkv, T* __restrict__ win,
-                                                              int h, int w) {
+                                                              float* __restrict__ relw, int h, int w) {
   constexpr int CC = (C < 64) ? C : 64;
   constexpr int CW = (CC < 32) ? 32 : CC;
   constexpr int NCH = C / CC;
   constexpr int NT = CC / 16;
+  constexpr int LD = CW + 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // region A (phase 1): Ks, Vs row-major [112][CW+8];  (phase 2): KT[CC][136], DOT[CC][72], QT[CC][72]
-  // region B: PT[112][72], DST[112][72]
-  constexpr size_t szA1 = 2 * sizeof(T) * (WA_KT * 16) * (CW + 8);
-  constexpr size_t szA2 = sizeof(T) * CC * (WA_KP + 2 * WA_QP);
-  constexpr size_t szA = (szA1 > szA2 ? szA1 : szA2);
-  T(*Ks)[CW + 8] = reinterpret_cast<T(*)[CW + 8]>(smem);
-  T(*Vs)[CW + 8] = reinterpret_cast<T(*)[CW + 8]>(smem + sizeof(T) * (WA_KT * 16) * (CW + 8));
-  T(*KT)[WA_KP] = reinterpret_cast<T(*)[WA_KP]>(smem);
-  T(*DOT)[WA_QP] = reinterpret_cast<T(*)[WA_QP]>(smem + sizeof(T) * CC * WA_KP);
-  T(*QT)[WA_QP] = reinterpret_cast<T(*)[WA_QP]>(smem + sizeof(T) * CC * (WA_KP + WA_QP));
+  // region A: Ks [128][LD] | Vs [128][LD] (phase 1)  /  Ks | DOs [64][LD] | Qs [64][LD] (phase 2)
+  //           / KA fp32 [112][CC+1] (rel-pos reduction, aliases Ks after the chunk's products)
+  // region B: PT [112][72], DST [112][72]   ([key][query])
+  constexpr size_t szK = sizeof(T) * WA_KR * LD;
+  constexpr size_t szA = 2 * szK;
+  T(*Ks)[LD] = reinterpret_cast<T(*)[LD]>(smem);
+  T(*Vs)[LD] = reinterpret_cast<T(*)[LD]>(smem + szK);
+  T(*DOs)[LD] = reinterpret_cast<T(*)[LD]>(smem + szK);
+  T(*Qs)[LD] = reinterpret_cast<T(*)[LD]>(smem + szK + sizeof(T) * 64 * LD);
+  float(*KA)[CC + 1] = reinterpret_cast<float(*)[CC + 1]>(smem);
   T(*PT)[WA_QP] = reinterpret_cast<T(*)[WA_QP]>(smem + szA);
   T(*DST)[WA_QP] = reinterpret_cast<T(*)[WA_QP]>(smem + szA + sizeof(T) * (WA_KT * 16) * WA_QP);
 
@@ -407,24 +343,18 @@ __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restric
       const int t = 2 * c4 + (j >> 2);
       dsf[c4].set(j, (t < WA_KT) ? dp[t < WA_KT ? t : 0][j & 3] : 0.f);
     }
-  __syncthreads();   // phase-1 reads of Ks/Vs done; PT/DST visible after the next barrier too
-  // zero the key padding of KT once
-  for (int idx = tid; idx < CC * (WA_KP - WA_NK); idx += 256) {
-    const int r = idx / (WA_KP - WA_NK), k = WA_NK + idx % (WA_KP - WA_NK);
-    KT[r][k] = from_f<T>(0.f);
-  }
   const long long wbase = (long long)blockIdx.x * WA_NK * (2 * C);
 
-  // ---- phase 2: per 64-channel chunk: dq^T = K^^T dS^T ; dV^T = dO^T P ; dK^^T = q^T dS ----
+  // ---- phase 2: per channel chunk: dq^T = K^^T dS^T ; dV^T = dO^T P ; dK^^T = q^T dS ----
 #pragma unroll 1
   for (int ch = 0; ch < NCH; ++ch) {
     const int c0 = ch * CC;
-    if (ch > 0) __syncthreads();
-    stage_keys_T<T, C, CC, true>(KT, qkv, C, rel_h, rel_w, gm, c0, tid);
-    stage_queries_T<T, CC>(DOT, go, ldg, gc0, gm, c0, tid);
-    stage_queries_T<T, CC>(QT, qkv, 3 * C, 0, gm, c0, tid);
+    __syncthreads();   // phase-1 / previous chunk's LDS reads (incl. KA) are done; PT/DST are written
+    stage_khat<T, C, CC, CW>(Ks, qkv, rel_h, rel_w, gm, c0, tid);
+    stage_query_rows<T, CC, CW>(DOs, go, ldg, gc0, gm, c0, tid);
+    stage_query_rows<T, CC, CW>(Qs, qkv, 3 * C, 0, gm, c0, tid);
     __syncthreads();
-    // dq for this wave's 16 queries
+    // dq for this wave's 16 queries: A = K^ read transposed (rows = channels, contraction = keys)
     {
       f32x4 o[NT];
 #pragma unroll
@@ -433,61 +363,75 @@ __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restric
       for (int c4 = 0; c4 < 4; ++c4)
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) {
-          const int d = perm_row<NT>(mt, lr);
-          const Frag8<T> kf = load4x2(&KT[d][32 * c4 + 4 * g], &KT[d][32 * c4 + 16 + 4 * g]);
+          const Frag8<T> kf = load8_tr(&Ks[32 * c4 + 4 * g][16 * mt], &Ks[32 * c4 + 16 + 4 * g][16 * mt], LD, lane);
           mma16(o[mt], kf, dsf[c4]);
         }
-      if (NT == 4) {
-        float v[16];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[4 * mt + r] = o[mt][r];
-        store16f(gqkv + qpix * (3 * C) + c0 + 16 * g, v);
-      } else {
-        float v[4] = {o[0][0], o[0][1], o[0][2], o[0][3]};
-        store4(gqkv + qpix * (3 * C) + c0 + 4 * g, v);
+      for (int mt = 0; mt < NT; ++mt) {
+        float v[4] = {o[mt][0], o[mt][1], o[mt][2], o[mt][3]};
+        store4(gqkv + qpix * (3 * C) + c0 + 16 * mt + 4 * g, v);
       }
     }
-    // dV^T and dK^^T: wave wv owns key tiles wv and wv + 4
+    // dV^T and dK^^T: wave wv owns key tiles wv and wv + 4; A = dO / q read transposed
+    // (rows = channels, contraction = queries), B = P^T / dS^T rows
+    f32x4 akk[2][NT];
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const int t = wv + 4 * tt;
-      if (t >= WA_KT) break;
-      f32x4 av[NT], ak[NT];
+      f32x4 av[NT];
 #pragma unroll
-      for (int mt = 0; mt < NT; ++mt) { av[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; ak[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      for (int mt = 0; mt < NT; ++mt) { av[mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; akk[tt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      if (t < WA_KT) {
 #pragma unroll
-      for (int kc = 0; kc < 2; ++kc) {
-        const Frag8<T> pfr = load8(&PT[16 * t + lr][32 * kc + 8 * g]);     // B: cols = keys, k = queries
-        const Frag8<T> dfr = load8(&DST[16 * t + lr][32 * kc + 8 * g]);
+        for (int kc = 0; kc < 2; ++kc) {
+          const Frag8<T> pfr = load8(&PT[16 * t + lr][32 * kc + 8 * g]);     // B: cols = keys, k = queries
+          const Frag8<T> dfr = load8(&DST[16 * t + lr][32 * kc + 8 * g]);
 #pragma unroll
-        for (int mt = 0; mt < NT; ++mt) {
-          const int d = perm_row<NT>(mt, lr);
-          const Frag8<T> gof = load8(&DOT[d][32 * kc + 8 * g]);            // A: rows = channels
-          mma16(av[mt], gof, pfr);
-          const Frag8<T> qf = load8(&QT[d][32 * kc + 8 * g]);
-          mma16(ak[mt], qf, dfr);
+          for (int mt = 0; mt < NT; ++mt) {
+            const Frag8<T> gof = load8_tr(&DOs[32 * kc + 8 * g][16 * mt], &DOs[32 * kc + 8 * g + 4][16 * mt], LD, lane);
+            mma16(av[mt], gof, pfr);
+            const Frag8<T> qf = load8_tr(&Qs[32 * kc + 8 * g][16 * mt], &Qs[32 * kc + 8 * g + 4][16 * mt], LD, lane);
+            mma16(akk[tt][mt], qf, dfr);
+          }
+        }
+        const int key = 16 * t + lr;
+        if (key < WA_NK) {
+          T* wp = win + wbase + (long long)key * (2 * C);
+#pragma unroll
+          for (int mt = 0; mt < NT; ++mt) {
+            float v[4] = {akk[tt][mt][0], akk[tt][mt][1], akk[tt][mt][2], akk[tt][mt][3]};
+            float u[4] = {av[mt][0], av[mt][1], av[mt][2], av[mt][3]};
+            store4(wp + c0 + 16 * mt + 4 * g, v);
+            store4(wp + C + c0 + 16 * mt + 4 * g, u);
+          }
         }
       }
-      const int key = 16 * t + lr;
-      if (key < WA_NK) {
-        T* wp = win + wbase + (long long)key * (2 * C);
-        if (NT == 4) {
-          float v[16], u[16];
+    }
+    // rel-pos gradient: dK^ tile to LDS in fp32, then ordered sums over key columns / rows
+    __syncthreads();
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt)
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = wv + 4 * tt;
+      if (t < WA_KT) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[4 * mt + r] = ak[mt][r]; u[4 * mt + r] = av[mt][r]; }
-          store16f(wp + c0 + 16 * g, v);
-          store16f(wp + C + c0 + 16 * g, u);
-        } else {
-          float v[4] = {ak[0][0], ak[0][1], ak[0][2], ak[0][3]};
-          float u[4] = {av[0][0], av[0][1], av[0][2], av[0][3]};
-          store4(wp + c0 + 4 * g, v);
-          store4(wp + C + c0 + 4 * g, u);
-        }
+        for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) KA[16 * t + lr][16 * mt + 4 * g + r] = akk[tt][mt][r];
       }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 10 * CC; idx += 256) {
+      const int i = idx / CC, c = idx - i * CC;
+      const int cc = c0 + c;
+      float a = 0.f;
+      if (cc < C / 2) {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) a += KA[i * 10 + j][c];      // row embedding: sum over columns
+      } else {
+#pragma unroll
+        for (int j = 0; j < 10; ++j) a += KA[j * 10 + i][c];      // column embedding: sum over rows
+      }
+      relw[((long long)blockIdx.x * 10 + i) * C + cc] = a;
     }
   }
 }
@@ -530,51 +474,30 @@ __global__ void __launch_bounds__(256) halo_gather_kernel(const T* __restrict__ 
   }
 }
 
-// relative-position gradients from the dK^ half of `win`:
-//   part[blk][i][c]:  c <  C/2 : sum over windows, cols of dK^[(i, col)][c]   (rel_h row i)
-//                     c >= C/2 : sum over windows, rows of dK^[(row, i)][c]   (rel_w col i)
-template <typename T>
-__global__ void __launch_bounds__(256) rel_reduce1_kernel(const T* __restrict__ win, float* __restrict__ part, int nwin, int C,
-                                                          int win_per_block) {
-  extern __shared__ float sh[];     // [nsub][10][C]
-  const int nsub = 256 / C > 0 ? 256 / C : 1;
-  const int c = threadIdx.x % C, sub = threadIdx.x / C;
-  const int w0 = blockIdx.x * win_per_block, w1 = min(nwin, w0 + win_per_block);
-  float acc[10];
-#pragma unroll
-  for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-  if (sub < nsub)
-    for (int wi = w0 + sub; wi < w1; wi += nsub) {
-      const T* wp = win + (long long)wi * WA_NK * (2 * C) + c;
-      if (c < C / 2) {
-#pragma unroll
-        for (int i = 0; i < 10; ++i)
-#pragma unroll
-          for (int j = 0; j < 10; ++j) acc[i] += to_f(wp[(i * 10 + j) * (2 * C)]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 10; ++i)
-#pragma unroll
-          for (int j = 0; j < 10; ++j) acc[i] += to_f(wp[(j * 10 + i) * (2 * C)]);
-      }
-    }
-  if (sub < nsub) {
-#pragma unroll
-    for (int i = 0; i < 10; ++i) sh[(sub * 10 + i) * C + c] = acc[i];
+// relative-position gradients: sum the per-window partials relw [nwin][10*C] over the windows
+// (two deterministic stages), then scatter to the torch layouts rel_h [1][10][1][C/2], rel_w [1][1][10][C/2]
+__global__ void __launch_bounds__(256) rel_reduce1_kernel(const float* __restrict__ relw, float* __restrict__ part, int nwin,
+                                                          int ncol, int win_per_split) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= ncol) return;
+  const int w0 = blockIdx.y * win_per_split, w1 = min(nwin, w0 + win_per_split);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int wi = w0;
+  for (; wi + 3 < w1; wi += 4) {
+    a0 += relw[(long long)wi * ncol + col];
+    a1 += relw[(long long)(wi + 1) * ncol + col];
+    a2 += relw[(long long)(wi + 2) * ncol + col];
+    a3 += relw[(long long)(wi + 3) * ncol + col];
   }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < 10 * C; idx += 256) {
-    float a = 0.f;
-    for (int s2 = 0; s2 < nsub; ++s2) a += sh[s2 * 10 * C + idx];
-    part[(long long)blockIdx.x * 10 * C + idx] = a;
-  }
+  for (; wi < w1; ++wi) a0 += relw[(long long)wi * ncol + col];
+  part[(long long)blockIdx.y * ncol + col] = (a0 + a1) + (a2 + a3);
 }
-__global__ void rel_reduce2_kernel(const float* __restrict__ part, float* __restrict__ grel_h, float* __restrict__ grel_w, int nblk,
-                                   int C) {
+__global__ void __launch_bounds__(256) rel_reduce2_kernel(const float* __restrict__ part, float* __restrict__ grel_h,
+                                                          float* __restrict__ grel_w, int nsplit, int C) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= 10 * C) return;
   float a = 0.f;
-  for (int b = 0; b < nblk; ++b) a += part[(long long)b * 10 * C + idx];
+  for (int b = 0; b < nsplit; ++b) a += part[(long long)b * 10 * C + idx];
   const int i = idx / C, c = idx % C;
   if (c < C / 2) grel_h[i * (C / 2) + c] = a;        // torch rel_h [1][10][1][C/2]
   else grel_w[i * (C / 2) + (c - C / 2)] = a;        // torch rel_w [1][1][10][C/2]
@@ -583,25 +506,25 @@ __global__ void rel_reduce2_kernel(const float* __restrict__ part, float* __rest
 template <typename T, int C> static size_t attn_bwd_smem() {
   constexpr int CC = (C < 64) ? C : 64;
   constexpr int CW = (CC < 32) ? 32 : CC;
-  const size_t szA1 = 2 * sizeof(T) * (WA_KT * 16) * (CW + 8);
-  const size_t szA2 = sizeof(T) * CC * (WA_KP + 2 * WA_QP);
-  return std::max(szA1, szA2) + 2 * sizeof(T) * (WA_KT * 16) * WA_QP;
+  return 2 * sizeof(T) * WA_KR * (CW + 8) + 2 * sizeof(T) * (WA_KT * 16) * WA_QP;
 }
 
 template <typename T>
 static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const float* rel_w, const T* gout, int ldg, int gc0,
-                                    T* gqkv, T* win, float* rel_part, float* grel_h, float* grel_w, int B, int h, int w,
-                                    int C, hipStream_t st) {
+                                    T* gqkv, T* win, float* relw, float* rel_part, float* grel_h, float* grel_w, int B,
+                                    int h, int w, int C, hipStream_t st) {
   const int nwin = B * (h / 8) * (w / 8);
 #define GO(C_)                                                                                                     \
   {                                                                                                                \
     const size_t sh = attn_bwd_smem<T, C_>();                                                                      \
     (void)hipFuncSetAttribute((const void*)window_attn_bwd_kernel<T, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-    hipLaunchKernelGGL((window_attn_bwd_kernel<T, C_>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, h, w); \
+    hipLaunchKernelGGL((window_attn_bwd_kernel<T, C_>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, h, w); \
   }
+  m2t_prof_begin(C == 16 ? M2T_PROF_ATTN_BWD_16 : (C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256), st);
   if (C == 16) GO(16) else if (C == 64) GO(64) else if (C == 256) GO(256)
   else return m2t_set_error(-2, "window_attn_bwd: C must be 16, 64 or 256");
 #undef GO
+  m2t_prof_end(C == 16 ? M2T_PROF_ATTN_BWD_16 : (C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256), st);
   M2T_LAUNCH_CHECK();
   {
     const long long total = (long long)B * h * w * (2 * C / 8);
@@ -610,22 +533,21 @@ static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const floa
     M2T_LAUNCH_CHECK();
   }
   {
-    int nblk = std::min(nwin, 128);
-    const int wpb = ceil_div(nwin, nblk);
-    nblk = ceil_div(nwin, wpb);
-    const int nsub = std::max(1, 256 / C);
-    hipLaunchKernelGGL(rel_reduce1_kernel<T>, dim3(nblk), dim3(256), sizeof(float) * nsub * 10 * C, st, win, rel_part, nwin, C, wpb);
+    int nsplit = std::min(nwin, 32);
+    const int wps = ceil_div(nwin, nsplit);
+    nsplit = ceil_div(nwin, wps);
+    hipLaunchKernelGGL(rel_reduce1_kernel, dim3(ceil_div(10 * C, 256), nsplit), dim3(256), 0, st, relw, rel_part, nwin, 10 * C, wps);
     M2T_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rel_reduce2_kernel, dim3(ceil_div(10 * C, 256)), dim3(256), 0, st, rel_part, grel_h, grel_w, nblk, C);
+    hipLaunchKernelGGL(rel_reduce2_kernel, dim3(ceil_div(10 * C, 256)), dim3(256), 0, st, rel_part, grel_h, grel_w, nsplit, C);
     M2T_LAUNCH_CHECK();
   }
   return 0;
 }
 int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
-                           int gc0, void* gqkv, void* win, float* rel_part, float* grel_h, float* grel_w, int B, int h,
-                           int w, int C, hipStream_t st) {
+                           int gc0, void* gqkv, void* win, float* relw, float* rel_part, float* grel_h, float* grel_w,
+                           int B, int h, int w, int C, hipStream_t st) {
   if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn_bwd: h,w must be multiples of 8");
   if (dt == M2T_F32)
-    return launch_window_attn_bwd_t<float>((const float*)qkv, rel_h, rel_w, (const float*)gout, ldg, gc0, (float*)gqkv, (float*)win, rel_part, grel_h, grel_w, B, h, w, C, st);
-  return launch_window_attn_bwd_t<bf16_t>((const bf16_t*)qkv, rel_h, rel_w, (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, rel_part, grel_h, grel_w, B, h, w, C, st);
+    return launch_window_attn_bwd_t<float>((const float*)qkv, rel_h, rel_w, (const float*)gout, ldg, gc0, (float*)gqkv, (float*)win, relw, rel_part, grel_h, grel_w, B, h, w, C, st);
+  return launch_window_attn_bwd_t<bf16_t>((const bf16_t*)qkv, rel_h, rel_w, (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, rel_part, grel_h, grel_w, B, h, w, C, st);
 }

@@ -137,78 +137,82 @@ int launch_gemm_nt(int dt, int amode, int emode, const m2t_gemm_args& a, hipStre
 }
 
 // =======================================================================================
-// wgrad_tn: dW[n][k] = sum_m G[m][n] X[m][k]
-// grid (N/64, K/64, nslab); each block sweeps its M range 64 rows at a time, staging both
-// operands TRANSPOSED in LDS ([n][m] and [k][m]) so the contraction index m is lane-contiguous.
+// wgrad_tn: dW[n][k] = sum_m G[m][n] X[m][k]   (+ optional db[n] = sum_m G[m][n])
+// grid (N/64, K/64, nslab).  A workgroup sweeps its M range 128 rows at a time: both operand
+// tiles are copied ROW-major into LDS with 16-byte vectors (next tile's global loads are in
+// flight while the current one is multiplied) and the contraction-major fragments come from
+// the transposing LDS read (ds_read_b64_tr_b16; scalar gather in fp32 parity mode).
+// Wave w owns output rows n = 16 w .. 16 w + 15 of the 64 x 64 tile.  The bias gradient rides
+// along as one extra tile product against an all-ones operand (no second pass over G).
 // =======================================================================================
-#define WG_BM 64
-#define WG_LDT (WG_BM + 8)
-
-// transposed staging of a [64 rows][64 cols] operand tile: dst[col][row]
-template <typename T, int MODE>
-__device__ __forceinline__ void wg_stage(T (*dst)[WG_LDT], const T* __restrict__ src, int ld, long long mbase, long long mend,
-                                         int c0, int cmax, const ShufGeom& sg, int tid) {
-  if (sizeof(T) == 4) {
-    // one row per item: 64 rows x 8 vecs = 512 items, row fastest across lanes
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int idx = tid + it * 256;
-      const int row = idx & 63, cv = idx >> 6;
-      const long long m = mbase + row;
-      const int c = c0 + cv * 8;
-      Frag8<T> f = frag_zero<T>();
-      if (m < mend && c < cmax) f = gemm_load_a<T, MODE>(src, ld, m, c, sg);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dst[cv * 8 + e][row] = f.v_elem(e);
-    }
-  } else {
-    // two rows per item packed into one dword: 32 row-pairs x 8 vecs = 256 items
-    const int rp = tid & 31, cv = tid >> 5;
-    const long long m = mbase + 2 * rp;
-    const int c = c0 + cv * 8;
-    Frag8<T> f0 = frag_zero<T>(), f1 = frag_zero<T>();
-    if (c < cmax) {
-      if (m < mend) f0 = gemm_load_a<T, MODE>(src, ld, m, c, sg);
-      if (m + 1 < mend) f1 = gemm_load_a<T, MODE>(src, ld, m + 1, c, sg);
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      T* p = &dst[cv * 8 + e][2 * rp];
-      p[0] = f0.v_elem(e);
-      p[1] = f1.v_elem(e);
-    }
-  }
-}
+#define WG_BM 128
+#define WG_LD 72
 
 template <typename T, int GMODE, int XMODE>
 __global__ void __launch_bounds__(256)
 wgrad_tn_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ X, int ldx, float* __restrict__ slabs,
-                long long M, int N, int K, long long rows_per_slab, ShufGeom sg) {
-  __shared__ __attribute__((aligned(16))) T GT[64][WG_LDT];
-  __shared__ __attribute__((aligned(16))) T XT[64][WG_LDT];
+                float* __restrict__ bias_slabs, long long M, int N, int K, long long rows_per_slab, ShufGeom sg) {
+  __shared__ __attribute__((aligned(16))) T Gs[WG_BM][WG_LD];
+  __shared__ __attribute__((aligned(16))) T Xs[WG_BM][WG_LD];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
   const long long mb = (long long)blockIdx.z * rows_per_slab;
   const long long me = min(M, mb + rows_per_slab);
-  f32x4 acc[4];
+  const int nkt = min(4, (K - k0 + 15) / 16);          // live 16-column tiles of this k block
+  const bool wave_live = (n0 + 16 * wv) < N;
+  const bool do_bias = (bias_slabs != nullptr) && (blockIdx.y == 0);
+  f32x4 acc[4], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (long long ms = mb; ms < me; ms += WG_BM) {
-    wg_stage<T, GMODE>(GT, G, ldg, ms, me, n0, N, sg, tid);
-    wg_stage<T, XMODE>(XT, X, ldx, ms, me, k0, K, sg, tid);
-    __syncthreads();
+  Frag8<T> ones;
 #pragma unroll
-    for (int ch = 0; ch < 2; ++ch) {
-      const Frag8<T> gf = load8(&GT[16 * wv + lr][ch * 32 + g * 8]);
+  for (int e = 0; e < 8; ++e) ones.set(e, 1.0f);
+
+  // each thread stages 4 + 4 vectors per step: row = idx >> 3, vec = idx & 7
+  Frag8<T> rg[4], rx[4];
+  auto fetch = [&](long long ms) {
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) {
-        const Frag8<T> xf = load8(&XT[16 * kt + lr][ch * 32 + g * 8]);
-        mma16(acc[kt], gf, xf);
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx >> 3, cv = idx & 7;
+      const long long m = ms + row;
+      rg[it] = frag_zero<T>();
+      rx[it] = frag_zero<T>();
+      if (m < me) {
+        if (n0 + cv * 8 < N) rg[it] = gemm_load_a<T, GMODE>(G, ldg, m, n0 + cv * 8, sg);
+        if (k0 + cv * 8 < K) rx[it] = gemm_load_a<T, XMODE>(X, ldx, m, k0 + cv * 8, sg);
       }
     }
+  };
+  fetch(mb);
+  for (long long ms = mb; ms < me; ms += WG_BM) {
     __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 256;
+      const int row = idx >> 3, cv = idx & 7;
+      store8(&Gs[row][cv * 8], rg[it]);
+      store8(&Xs[row][cv * 8], rx[it]);
+    }
+    __syncthreads();
+    if (ms + WG_BM < me) fetch(ms + WG_BM);
+    if (wave_live) {
+#pragma unroll
+      for (int ch = 0; ch < WG_BM / 32; ++ch) {
+        const Frag8<T> gf = load8_tr(&Gs[32 * ch + 8 * g][16 * wv], &Gs[32 * ch + 8 * g + 4][16 * wv], WG_LD, lane);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          if (kt < nkt) {
+            const Frag8<T> xf = load8_tr(&Xs[32 * ch + 8 * g][16 * kt], &Xs[32 * ch + 8 * g + 4][16 * kt], WG_LD, lane);
+            mma16(acc[kt], gf, xf);
+          }
+        }
+        if (do_bias) mma16(accb, gf, ones);
+      }
+    }
   }
+  if (!wave_live) return;
   float* out = slabs + (long long)blockIdx.z * N * K;
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt) {
@@ -219,13 +223,20 @@ wgrad_tn_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ X, int l
       if (n < N && k < K) out[(long long)n * K + k] = acc[kt][r];
     }
   }
+  if (do_bias && lr == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 16 * wv + 4 * g + r;
+      if (n < N) bias_slabs[(long long)blockIdx.z * N + n] = accb[r];
+    }
+  }
 }
 
 template <typename T>
 static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_t st) {
   if (a.K % 8 || a.N % 8) return m2t_set_error(-2, "wgrad_tn: N,K must be multiples of 8");
   const int tn = ceil_div(a.N, 64), tk = ceil_div(a.K, 64);
-  // enough slabs to fill the chip, rows per slab a multiple of the 64-row step
+  // enough slabs to fill the chip; rows per slab a multiple of the 128-row step
   long long want = std::max<long long>(1, 512 / (tn * tk));
   int nslab = (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want, ceil_divll(a.M, WG_BM)));
   long long rps = ceil_divll(ceil_divll(a.M, nslab), WG_BM) * WG_BM;
@@ -234,7 +245,7 @@ static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_
   dim3 grid(tn, tk, nslab);
 #define GO(GM, XM)                                                                                               \
   hipLaunchKernelGGL((wgrad_tn_kernel<T, GM, XM>), grid, dim3(256), 0, st, (const T*)a.G, a.ldg, (const T*)a.X, \
-                     a.ldx, a.slabs, a.M, a.N, a.K, rps, sg)
+                     a.ldx, a.slabs, a.bias_slabs, a.M, a.N, a.K, rps, sg)
   if (a.gmode == M2T_A_PLAIN && a.xmode == M2T_A_PLAIN) GO(M2T_A_PLAIN, M2T_A_PLAIN);
   else if (a.gmode == M2T_A_UNSHUF && a.xmode == M2T_A_PLAIN) GO(M2T_A_UNSHUF, M2T_A_PLAIN);
   else if (a.gmode == M2T_A_UNSHUF && a.xmode == M2T_A_GELU) GO(M2T_A_UNSHUF, M2T_A_GELU);

@@ -645,12 +645,22 @@ __global__ void __launch_bounds__(256) colsum1_kernel(const T* __restrict__ a, i
     part[(long long)blockIdx.x * N + n] = acc;
   }
 }
-__global__ void colsum2_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int N, int accumulate) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+__global__ void __launch_bounds__(256) colsum2_kernel(const float* __restrict__ part, float* __restrict__ out, int nblk, int N,
+                                                      int accumulate) {
+  // 32 columns x 8 lanes per block; each lane sums every 8th partial, then an ordered 8-way combine
+  const int n = blockIdx.x * 32 + (threadIdx.x & 31), ln = threadIdx.x >> 5;
   float acc = 0.f;
-  for (int b = 0; b < nblk; ++b) acc += part[(long long)b * N + n];
-  if (accumulate) out[n] += acc; else out[n] = acc;
+  if (n < N)
+    for (int b = ln; b < nblk; b += 8) acc += part[(long long)b * N + n];
+  __shared__ float sh[8][32];
+  sh[ln][threadIdx.x & 31] = acc;
+  __syncthreads();
+  if (ln == 0 && n < N) {
+    float a = 0.f;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) a += sh[l][threadIdx.x & 31];
+    if (accumulate) out[n] += a; else out[n] = a;
+  }
 }
 int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* part, int max_part_blocks, float* out,
                   int accumulate, hipStream_t st, int unshuf, int gH, int gW, int gr, int gC) {
@@ -668,7 +678,7 @@ int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* par
     else hipLaunchKernelGGL((colsum1_kernel<bf16_t, M2T_A_PLAIN>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)a, lda, part, M, N, rpb, sg);
   }
   M2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum2_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, part, out, nblk, N, accumulate);
+  hipLaunchKernelGGL(colsum2_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, st, part, out, nblk, N, accumulate);
   M2T_LAUNCH_CHECK();
   return 0;
 }
@@ -683,6 +693,7 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
                                                            long long n, int perm, int p0, int p1, int p2) {
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
     float acc = 0.f;
+#pragma unroll 8
     for (int s = 0; s < ns; ++s) acc += slab[(long long)s * n + e];
     long long d = e;
     if (perm == 1) {           // p0 = O, p1 = I

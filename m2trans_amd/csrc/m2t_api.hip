@@ -19,6 +19,55 @@ int m2t_set_hip_error(hipError_t e, const char* file, int line) {
 }
 int m2t_set_error(int code, const char* msg) { g_err = msg; return code; }
 
+// ---- optional per-kernel timing with HIP events on the launch stream -------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int cat; };
+struct ProfState {
+  unsigned long long mask = 0;
+  std::vector<ProfRec> pool;
+  size_t used = 0;
+  hipEvent_t pending = nullptr;
+} g_prof;
+}
+void m2t_prof_begin(int cat, hipStream_t st) {
+  if (!((g_prof.mask >> cat) & 1ull) || g_prof.used >= g_prof.pool.size()) return;
+  ProfRec& r = g_prof.pool[g_prof.used];
+  r.cat = cat;
+  (void)hipEventRecord(r.a, st);
+}
+void m2t_prof_end(int cat, hipStream_t st) {
+  if (!((g_prof.mask >> cat) & 1ull) || g_prof.used >= g_prof.pool.size()) return;
+  (void)hipEventRecord(g_prof.pool[g_prof.used].b, st);
+  ++g_prof.used;
+}
+extern "C" int m2t_profile_enable(unsigned long long category_mask) {
+  if (category_mask && g_prof.pool.empty()) {
+    g_prof.pool.resize(16384);
+    for (auto& r : g_prof.pool) {
+      if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess)
+        return m2t_set_error(M2T_ERR_STATE, "m2t_profile_enable: hipEventCreate failed");
+    }
+  }
+  g_prof.mask = category_mask;
+  g_prof.used = 0;
+  return 0;
+}
+// total milliseconds and launch count of one category since m2t_profile_enable; the caller must
+// have synchronised the stream
+extern "C" int m2t_profile_read(int cat, double* total_ms, long long* count) {
+  double t = 0.0; long long n = 0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    if (g_prof.pool[i].cat != cat) continue;
+    float ms = 0.f;
+    hipError_t e = hipEventElapsedTime(&ms, g_prof.pool[i].a, g_prof.pool[i].b);
+    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+    t += ms; ++n;
+  }
+  if (total_ms) *total_ms = t;
+  if (count) *count = n;
+  return 0;
+}
+
 struct WsTensor { size_t off; size_t n; };   // byte offset, element count
 
 struct m2t_plan {
@@ -156,7 +205,8 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("gd", BP * 16, es);
   p->add_ws("gqkv", BP * 48, es);
   p->add_ws("win", BP * 50, es);
-  p->add_ws("rel_part", 128 * 10 * 256, 4);
+  p->add_ws("relw", (size_t)(BP / 64) * 10 * 16, 4);
+  p->add_ws("rel_part", 32 * 10 * 256, 4);
   p->add_ws("slabs", (size_t)256 * 9 * 64 * 64, 4);
   p->add_ws("col_part", (size_t)256 * 768, 4);
   p->ws_bytes = (p->ws_bytes + 255) & ~(size_t)255;
@@ -228,7 +278,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
       m2t_gemm_args ga{};
       ga.A = d; ga.lda = C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1));
       ga.Y = qkv; ga.ldy = 3 * C; ga.M = M; ga.N = 3 * C; ga.K = C;
-      CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st));
+      { M2TProfScope ps(M2T_PROF_GEMM_QKV, st); CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st)); }
       const float* rh = params + p->poff.at(an + "rel_h");
       const float* rw = params + p->poff.at(an + "rel_w");
       if (i == 0) {
@@ -240,8 +290,9 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
       }
     }
     // x = feed_forward(xc) + x (:164); the last block also folds in `res + x` (:70)
-    CK(launch_conv3x3_c64(dt, xc, packed_ptr(p, workspace, k + "wf"), params + p->poff.at(pre + "feed_forward.0.bias"), X,
-                          (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st));
+    { M2TProfScope ps(M2T_PROF_CONV3_FWD, st);
+      CK(launch_conv3x3_c64(dt, xc, packed_ptr(p, workspace, k + "wf"), params + p->poff.at(pre + "feed_forward.0.bias"), X,
+                            (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st)); }
   }
   void* Y = WSP("X" + std::to_string(p->nb));
   const int r0 = (s == 4) ? 2 : s;
@@ -250,7 +301,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     ga.A = Y; ga.lda = 64; ga.W = packed_ptr(p, workspace, "t0"); ga.Y = WSP("t1pre"); ga.ldy = 64;
     ga.bias = params + p->poff.at("tail.0.bias"); ga.M = BP; ga.N = 64 * r0 * r0; ga.K = 64;
     ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
-    CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_BIAS_SHUF, ga, st));
+    { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_BIAS_SHUF, ga, st)); }
   }
   const void* last_pre = WSP("t1pre");
   if (s == 4) {
@@ -258,11 +309,11 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     ga.A = WSP("t1pre"); ga.lda = 64; ga.W = packed_ptr(p, workspace, "t3"); ga.Y = WSP("t2pre"); ga.ldy = 64;
     ga.bias = params + p->poff.at("tail.3.bias"); ga.M = BP * 4; ga.N = 256; ga.K = 64;
     ga.H = 2 * H; ga.Wd = 2 * W; ga.r = 2; ga.C = 64;
-    CK(launch_gemm_nt(dt, M2T_A_GELU, M2T_E_BIAS_SHUF, ga, st));
+    { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_GELU, M2T_E_BIAS_SHUF, ga, st)); }
     last_pre = WSP("t2pre");
   }
   const float* wlast = params + p->poff.at(s == 4 ? "tail.6.weight" : "tail.3.weight");
-  CK(launch_final_conv_fwd(dt, last_pre, wlast, (float*)WSP("srpre"), B, p->Hsp, p->Wsp, st));
+  { M2TProfScope ps(M2T_PROF_FINAL_FWD, st); CK(launch_final_conv_fwd(dt, last_pre, wlast, (float*)WSP("srpre"), B, p->Hsp, p->Wsp, st)); }
   if (sr)
     CK(launch_clamp_l1((const float*)WSP("srpre"), nullptr, sr, nullptr, nullptr, nullptr, B, p->Hsp, p->Wsp, p->Hs,
                        p->Ws, rgb_range, 0.f, 0.f, st));
@@ -328,39 +379,37 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   const std::string wl = (s == 4) ? "tail.6.weight" : "tail.3.weight";
   const void* last_pre = (s == 4) ? WSP("t2pre") : WSP("t1pre");
   void* g_last = (s == 4) ? WSP("g_t2pre") : WSP("g_t1pre");
-  CK(launch_final_conv_wgrad(dt, gpre, last_pre, slabs, &ns, B, p->Hsp, p->Wsp, st));
+  { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, st); CK(launch_final_conv_wgrad(dt, gpre, last_pre, slabs, &ns, B, p->Hsp, p->Wsp, st)); }
   CK(launch_reduce_slabs(slabs, grads + p->poff.at(wl), ns, 3 * 64 * 9, 0, 0, 0, 0, st));
-  CK(launch_final_conv_dgrad(dt, gpre, params + p->poff.at(wl), last_pre, g_last, B, p->Hsp, p->Wsp, st));
+  { M2TProfScope ps(M2T_PROF_FINAL_DGRAD, st); CK(launch_final_conv_dgrad(dt, gpre, params + p->poff.at(wl), last_pre, g_last, B, p->Hsp, p->Wsp, st)); }
   if (s == 4) {
     // tail.3: u = gelu(t1pre) W3^T + b3, shuffled into t2pre
     m2t_wgrad_args wa{};
     wa.G = WSP("g_t2pre"); wa.gmode = M2T_A_UNSHUF; wa.X = WSP("t1pre"); wa.ldx = 64; wa.xmode = M2T_A_GELU;
-    wa.slabs = slabs; wa.M = BP * 4; wa.N = 256; wa.K = 64; wa.H = 2 * H; wa.Wd = 2 * W; wa.r = 2; wa.C = 64;
-    CK(launch_wgrad_tn(dt, wa, &ns, st));
+    wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP * 4; wa.N = 256; wa.K = 64; wa.H = 2 * H; wa.Wd = 2 * W; wa.r = 2; wa.C = 64;
+    { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, st); CK(launch_wgrad_tn(dt, wa, &ns, st)); }
     CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64, st));
-    // bias: column sums in shuffled order, then permute through a 1-slab "reduction"
-    CK(launch_colsum(dt, WSP("g_t2pre"), 0, BP * 4, 256, colp, 256, slabs, 0, st, 1, 2 * H, 2 * W, 2, 64));
-    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.3.bias"), 1, 256, 2, 64, 4, 1, st));
+    // bias gradient rode along in the wgrad kernel (shuffled column order -> torch order)
+    CK(launch_reduce_slabs(colp, grads + p->poff.at("tail.3.bias"), ns, 256, 2, 64, 4, 1, st));
     m2t_gemm_args ga{};
     ga.A = WSP("g_t2pre"); ga.W = packed_ptr(p, workspace, "t3T"); ga.Y = WSP("g_t1pre"); ga.ldy = 64;
     ga.aux = WSP("t1pre"); ga.ldaux = 64; ga.M = BP * 4; ga.N = 64; ga.K = 256;
     ga.H = 2 * H; ga.Wd = 2 * W; ga.r = 2; ga.C = 64;
-    CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_GELU_GRAD, ga, st));
+    { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_GELU_GRAD, ga, st)); }
   }
   void* Y = WSP("X" + std::to_string(p->nb));
   {
     const int N0 = 64 * r0 * r0;
     m2t_wgrad_args wa{};
     wa.G = WSP("g_t1pre"); wa.gmode = M2T_A_UNSHUF; wa.X = Y; wa.ldx = 64; wa.xmode = M2T_A_PLAIN;
-    wa.slabs = slabs; wa.M = BP; wa.N = N0; wa.K = 64; wa.H = H; wa.Wd = W; wa.r = r0; wa.C = 64;
-    CK(launch_wgrad_tn(dt, wa, &ns, st));
+    wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = N0; wa.K = 64; wa.H = H; wa.Wd = W; wa.r = r0; wa.C = 64;
+    { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, st); CK(launch_wgrad_tn(dt, wa, &ns, st)); }
     CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.0.weight"), ns, (long long)N0 * 64, 2, 64, r0 * r0, 64, st));
-    CK(launch_colsum(dt, WSP("g_t1pre"), 0, BP, N0, colp, 256, slabs, 0, st, 1, H, W, r0, 64));
-    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.0.bias"), 1, N0, 2, 64, r0 * r0, 1, st));
+    CK(launch_reduce_slabs(colp, grads + p->poff.at("tail.0.bias"), ns, N0, 2, 64, r0 * r0, 1, st));
     m2t_gemm_args ga{};
     ga.A = WSP("g_t1pre"); ga.W = packed_ptr(p, workspace, "t0T"); ga.Y = WSP("gT"); ga.ldy = 64;
     ga.M = BP; ga.N = 64; ga.K = N0; ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
-    CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_PLAIN, ga, st));
+    { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_PLAIN, ga, st)); }
   }
   // ---- body, last block first.  gy = gradient of X[b+1] ----
   void* gy = WSP("gT");
@@ -375,10 +424,10 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     void* gxc = WSP("gxc");
     void* gn = WSP("gn");
     // feed_forward conv: weight / bias / data gradients
-    CK(launch_conv3x3_c64_wgrad(dt, xc, gy, slabs, &ns, B, H, W, st));
+    { M2TProfScope ps(M2T_PROF_CONV3_WGRAD, st); CK(launch_conv3x3_c64_wgrad(dt, xc, gy, slabs, &ns, B, H, W, st)); }
     CK(launch_reduce_slabs(slabs, grads + p->poff.at(pre + "feed_forward.0.weight"), ns, 9 * 64 * 64, 1, 64, 64, 0, st));
     CK(launch_colsum(dt, gy, 64, BP, 64, colp, 256, grads + p->poff.at(pre + "feed_forward.0.bias"), 0, st));
-    CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st));
+    { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st)); }
     for (int i = 3; i >= 0; --i) {
       const int C = BR_C[i], L = BR_L[i];
       const int h = H >> L, w = W >> L;
@@ -391,20 +440,20 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       float* grh = grads + p->poff.at(an + "rel_h");
       float* grw = grads + p->poff.at(an + "rel_w");
       if (i == 0) {
-        CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 0, WSP("gqkv"), WSP("win"), (float*)WSP("rel_part"), grh, grw, B, h, w, C, st));
+        CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 0, WSP("gqkv"), WSP("win"), (float*)WSP("relw"), (float*)WSP("rel_part"), grh, grw, B, h, w, C, st));
       } else {
         CK(launch_branch_post_bwd(dt, L, gxc, i, WSP("ga"), B, H, W, st));
-        CK(launch_window_attn_bwd(dt, qkv, rh, rw, WSP("ga"), C, 0, WSP("gqkv"), WSP("win"), (float*)WSP("rel_part"), grh, grw, B, h, w, C, st));
+        CK(launch_window_attn_bwd(dt, qkv, rh, rw, WSP("ga"), C, 0, WSP("gqkv"), WSP("win"), (float*)WSP("relw"), (float*)WSP("rel_part"), grh, grw, B, h, w, C, st));
       }
       m2t_wgrad_args wa{};
       wa.G = WSP("gqkv"); wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = d; wa.ldx = C; wa.xmode = M2T_A_PLAIN;
       wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = 1; wa.Wd = 1; wa.r = 1; wa.C = 64;
-      CK(launch_wgrad_tn(dt, wa, &ns, st));
+      { M2TProfScope ps(M2T_PROF_WGRAD_QKV, st); CK(launch_wgrad_tn(dt, wa, &ns, st)); }
       CK(launch_reduce_slabs(slabs, grads + p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0, st));
       m2t_gemm_args ga{};
       ga.A = WSP("gqkv"); ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
       ga.Y = WSP("gd"); ga.ldy = C; ga.M = M; ga.N = C; ga.K = 3 * C; ga.H = 1; ga.Wd = 1; ga.r = 1; ga.C = 64;
-      CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st));
+      { M2TProfScope ps(M2T_PROF_GEMM_QKV_DGRAD, st); CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st)); }
       CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st));
     }
     void* gx = gnext[b & 1];
@@ -455,14 +504,15 @@ extern "C" int m2t_window_attention_fwd(int dtype, const void* qkv, const float*
 extern "C" size_t m2t_window_attention_bwd_scratch_bytes(int dtype, int B, int h, int w, int C) {
   const size_t es = (dtype == M2T_F32) ? 4 : 2;
   const size_t nwin = (size_t)B * (h / 8) * (w / 8);
-  return nwin * 100 * 2 * C * es + 256 + (size_t)128 * 10 * C * 4;
+  return ((nwin * 100 * 2 * C * es + 255) & ~(size_t)255) + ((nwin * 10 * C * 4 + 255) & ~(size_t)255) + (size_t)32 * 10 * C * 4;
 }
 extern "C" int m2t_window_attention_bwd(int dtype, const void* qkv, const float* rel_h, const float* rel_w,
                                         const void* gout, void* gqkv, float* grel_h, float* grel_w, void* scratch, int B,
                                         int h, int w, int C, void* stream) {
   const size_t es = (dtype == M2T_F32) ? 4 : 2;
   const size_t nwin = (size_t)B * (h / 8) * (w / 8);
-  size_t woff = (nwin * 100 * 2 * C * es + 255) & ~(size_t)255;
+  const size_t woff = (nwin * 100 * 2 * C * es + 255) & ~(size_t)255;
+  const size_t roff = woff + ((nwin * 10 * C * 4 + 255) & ~(size_t)255);
   return launch_window_attn_bwd(dtype, qkv, rel_h, rel_w, gout, C, 0, gqkv, scratch, (float*)((char*)scratch + woff),
-                                grel_h, grel_w, B, h, w, C, (hipStream_t)stream);
+                                (float*)((char*)scratch + roff), grel_h, grel_w, B, h, w, C, (hipStream_t)stream);
 }

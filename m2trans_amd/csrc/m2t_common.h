@@ -155,6 +155,36 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {   // torch 'reflect' 
   return i;
 }
 
+// ---------------------------------------------------------------------------------------
+// Transposed operand read (bf16): ds_read_b64_tr_b16.
+// The tile sits ROW-major in LDS as [contraction index][row|col index] (exactly as it was
+// copied from HBM with 16-byte vectors); the hardware hands lane (i = lane&15, g = lane>>4)
+// the column i of four consecutive LDS rows.  Two reads give the 8-element operand:
+//   elements 0..3 = rows r0 + 0..3, elements 4..7 = rows r1 + 0..3, all at column c0 + i.
+// p0 / p1 point at &tile[r0][c0] / &tile[r1][c0]; ld = row stride in elements (multiple of 4).
+// EXEC must be all ones (every lane of the wave calls this).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ Frag8<bf16_t> load8_tr(const bf16_t* p0, const bf16_t* p1, int ld, int lane) {
+  const int i = lane & 15, q = i >> 2, pp = i & 3;
+  typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p0 + q * ld + 4 * pp));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p1 + q * ld + 4 * pp));
+  Frag8<bf16_t> f;
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+// fp32 has no transposing read: gather the 8 elements one by one (parity mode only)
+__device__ __forceinline__ Frag8<float> load8_tr(const float* p0, const float* p1, int ld, int lane) {
+  const int i = lane & 15;
+  Frag8<float> f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f.v[e] = p0[e * ld + i];
+    f.v[4 + e] = p1[e * ld + i];
+  }
+  return f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -5,7 +5,7 @@
 
 #define M2T_NORM_SPLIT 32     // pixel splits per image in the InstanceNorm reductions
 #define M2T_LOSS_BLOCKS 1024  // partial sums of the L1 loss
-#define M2T_MAX_SLABS 64      // split-M slabs of a weight-gradient GEMM
+#define M2T_MAX_SLABS 256     // split-M slabs of a weight-gradient GEMM
 
 enum m2t_pack_kind {
   M2T_PACK_COPY = 0, M2T_PACK_TRANSPOSE = 1, M2T_PACK_CONV3 = 2, M2T_PACK_CONV3_T = 3,
@@ -14,6 +14,23 @@ enum m2t_pack_kind {
 struct m2t_pack_desc {
   long long src_off, dst_off, n;
   int kind, d0, d1, d2;
+};
+
+// ---- in-library kernel timing (HIP events on the launch stream; off by default) -----------
+enum m2t_prof_cat {
+  M2T_PROF_ATTN_FWD_16 = 0, M2T_PROF_ATTN_FWD_64, M2T_PROF_ATTN_FWD_256,
+  M2T_PROF_ATTN_BWD_16, M2T_PROF_ATTN_BWD_64, M2T_PROF_ATTN_BWD_256,
+  M2T_PROF_CONV3_FWD, M2T_PROF_CONV3_DGRAD, M2T_PROF_CONV3_WGRAD,
+  M2T_PROF_GEMM_QKV, M2T_PROF_GEMM_QKV_DGRAD, M2T_PROF_WGRAD_QKV,
+  M2T_PROF_TAIL_GEMM, M2T_PROF_TAIL_WGRAD, M2T_PROF_FINAL_FWD, M2T_PROF_FINAL_DGRAD, M2T_PROF_FINAL_WGRAD,
+  M2T_PROF_NCAT
+};
+void m2t_prof_begin(int cat, hipStream_t st);
+void m2t_prof_end(int cat, hipStream_t st);
+struct M2TProfScope {
+  int cat; hipStream_t st;
+  M2TProfScope(int c, hipStream_t s) : cat(c), st(s) { m2t_prof_begin(cat, st); }
+  ~M2TProfScope() { m2t_prof_end(cat, st); }
 };
 
 // ---- k_pointwise.hip --------------------------------------------------------------------
@@ -58,6 +75,7 @@ struct m2t_wgrad_args {
   const void* G; int ldg; int gmode;   // M2T_A_PLAIN or M2T_A_UNSHUF
   const void* X; int ldx; int xmode;   // M2T_A_PLAIN or M2T_A_GELU
   float* slabs;                        // [nslab][N][K]
+  float* bias_slabs;                   // optional [nslab][N]: column sums of G (bias gradient)
   long long M; int N, K;
   int H, Wd, r, C;
 };
@@ -87,5 +105,5 @@ int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const fl
 // gout [B][h][w][ldg] (channels gc0..gc0+C) -> gqkv [B][h][w][3C]; per-window dK/dV scratch `win` [B*L][100][2C] (T);
 // rel-pos gradient slabs
 int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
-                           int gc0, void* gqkv, void* win, float* rel_part, float* grel_h, float* grel_w, int B, int h,
-                           int w, int C, hipStream_t st);
+                           int gc0, void* gqkv, void* win, float* relw, float* rel_part, float* grel_h, float* grel_w,
+                           int B, int h, int w, int C, hipStream_t st);

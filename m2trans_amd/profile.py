@@ -1,0 +1,134 @@
+"""Kernel-category timing (HIP events inside libm2t.so) and the roofline arithmetic used by
+bench.py.  Category ids mirror `enum m2t_prof_cat` in csrc/m2t_kernels.h.
+
+Algorithmic work per launch (per-unit figure x units per launch):
+  window attention fwd : 2 products x 2*64*100*C FLOP per window           = 25 600 C FLOP/window
+                         bytes: read q|k|v (3C) + write out (C) per pixel   = 4 C es B/pixel
+  window attention bwd : 5 products (S, dP, dq, dK, dV)                     = 64 000 C FLOP/window
+                         bytes: read qkv (3C) + gO (C), write gqkv (3C)     = 7 C es B/pixel
+  conv3x3 64->64       : 2*64*576 FLOP/pixel; bytes: in + out (+ residual)  = 128..192 es B/pixel
+  1x1 GEMMs            : 2*K*N FLOP/row; bytes (K + N) es B/row
+  tail conv 64->3      : 2*64*27 FLOP/HR pixel; bytes 64 es (+ 3*4 out) B/HR pixel
+Peaks (MI355X_MICROARCH.md): HBM 8.0 TB/s; dense MFMA 2.5 PFLOP/s bf16, 157.3 TFLOP/s fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+from . import _lib
+
+CATS = ["attn_fwd_c16", "attn_fwd_c64", "attn_fwd_c256", "attn_bwd_c16", "attn_bwd_c64", "attn_bwd_c256",
+        "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "gemm_qkv", "gemm_qkv_dgrad", "wgrad_qkv",
+        "tail_gemm", "tail_wgrad", "final_conv_fwd", "final_conv_dgrad", "final_conv_wgrad"]
+KERNEL_OF = {
+    "attn_fwd_c16": "window_attn_fwd_kernel<C=16>", "attn_fwd_c64": "window_attn_fwd_kernel<C=64>",
+    "attn_fwd_c256": "window_attn_fwd_kernel<C=256>", "attn_bwd_c16": "window_attn_bwd_kernel<C=16>",
+    "attn_bwd_c64": "window_attn_bwd_kernel<C=64>", "attn_bwd_c256": "window_attn_bwd_kernel<C=256>",
+    "conv3x3_fwd": "conv3x3_c64_kernel (forward)", "conv3x3_dgrad": "conv3x3_c64_kernel (data gradient)",
+    "conv3x3_wgrad": "conv3x3_c64_wgrad_kernel", "gemm_qkv": "gemm_nt_kernel (qkv projections)",
+    "gemm_qkv_dgrad": "gemm_nt_kernel (qkv data gradients)", "wgrad_qkv": "wgrad_tn_kernel (qkv weight gradients)",
+    "tail_gemm": "gemm_nt_kernel (tail 1x1 + pixel shuffle, fwd+dgrad)", "tail_wgrad": "wgrad_tn_kernel (tail)",
+    "final_conv_fwd": "final_conv_fwd_kernel", "final_conv_dgrad": "final_conv_dgrad_kernel",
+    "final_conv_wgrad": "final_conv_wgrad_kernel",
+}
+HBM_PEAK_GBS = 8000.0
+MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
+ALL_MASK = (1 << len(CATS)) - 1
+
+
+def enable(mask: int = ALL_MASK):
+    _lib.check(_lib.load().m2t_profile_enable(C.c_ulonglong(mask)), "m2t_profile_enable")
+
+
+def read_all():
+    lib = _lib.load()
+    out = {}
+    for i, name in enumerate(CATS):
+        ms, n = C.c_double(0.0), C.c_longlong(0)
+        _lib.check(lib.m2t_profile_read(i, C.byref(ms), C.byref(n)), "m2t_profile_read")
+        out[name] = (ms.value, n.value)
+    return out
+
+
+def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8):
+    """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr."""
+    es = 2 if dtype == "bf16" else 4
+    H = W = (lr + 31) // 32 * 32
+    P = H * W
+    nb = n_blocks
+    w = {}
+    br = [(16, 0), (64, 1), (256, 2), (256, 2)]
+
+    def add(cat, fl, by, n):
+        f0, b0, n0 = w.get(cat, (0.0, 0.0, 0))
+        w[cat] = (f0 + fl, b0 + by, n0 + n)
+
+    for C_, L in br:
+        M = B * P // (4 ** L)
+        win = M // 64
+        add(f"attn_fwd_c{C_}", nb * win * 25600.0 * C_, nb * M * (4 * C_ + (C_ if C_ == 16 else 0)) * es, nb)
+        add(f"attn_bwd_c{C_}", nb * win * 64000.0 * C_, nb * M * 7 * C_ * es, nb)
+        add("gemm_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
+        add("gemm_qkv_dgrad", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
+        add("wgrad_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
+    conv_fl = 2.0 * B * P * 64 * 576
+    add("conv3x3_fwd", nb * conv_fl, nb * B * P * 64 * es * 3, nb)
+    add("conv3x3_dgrad", nb * conv_fl, nb * B * P * 64 * es * 2, nb)
+    add("conv3x3_wgrad", nb * conv_fl, nb * B * P * 64 * es * 2, nb)
+    if scale == 4:
+        # tail.0: M=BP, K=64, N=256 ; tail.3: M=4BP ; each: fwd + dgrad GEMM and a wgrad
+        for M in (B * P, 4 * B * P):
+            add("tail_gemm", 2 * 2.0 * M * 64 * 256, 2 * M * (64 + 256) * es, 2)
+            add("tail_wgrad", 2.0 * M * 64 * 256, M * (64 + 256) * es, 1)
+        HR = 16 * B * P
+    else:
+        r2 = scale * scale
+        M = B * P
+        add("tail_gemm", 2 * 2.0 * M * 64 * 64 * r2, 2 * M * (64 + 64 * r2) * es, 2)
+        add("tail_wgrad", 2.0 * M * 64 * 64 * r2, M * (64 + 64 * r2) * es, 1)
+        HR = r2 * B * P
+    fin = 2.0 * HR * 64 * 27
+    add("final_conv_fwd", fin, HR * (64 * es + 12), 1)
+    add("final_conv_dgrad", fin, HR * (2 * 64 * es + 12), 1)
+    add("final_conv_wgrad", fin, HR * (64 * es + 12), 1)
+    return w
+
+
+def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_file: str | None = None):
+    """Roofline object for the dominant (largest total time) kernel category measured in the
+    timed region, plus a compact table of the others."""
+    t = read_all()
+    work = algorithmic_work(B, lr, scale, dtype)
+    traffic = {}
+    if pmc_file and os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get("traffic_bytes_per_launch", {})
+        except Exception:
+            traffic = {}
+    rows = []
+    for name, (ms, n) in t.items():
+        if n == 0 or name not in work:
+            continue
+        fl, by, nl = work[name]
+        fl_l, by_l = fl / nl, by / nl                  # per launch
+        avg_s = ms / n * 1e-3
+        t_hbm = by_l / (HBM_PEAK_GBS * 1e9)
+        t_mfma = fl_l / (MFMA_PEAK_TF[dtype] * 1e12)
+        bound = "hbm" if t_hbm >= t_mfma else "mfma"
+        if bound == "hbm":
+            ach, peak, unit = by_l / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            ach, peak, unit = fl_l / avg_s / 1e12, MFMA_PEAK_TF[dtype], "TFLOP/s"
+        rows.append({"kernel": KERNEL_OF[name], "category": name, "bound": bound, "achieved": round(ach, 2),
+                     "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic.get(name),
+                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": n, "total_ms": round(ms, 3),
+                     "hbm_GBs": round(by_l / avg_s / 1e9, 1), "mfma_TFs": round(fl_l / avg_s / 1e12, 2)})
+    if not rows:
+        return None
+    rows.sort(key=lambda r: -r["total_ms"])
+    top = dict(rows[0])
+    top["others"] = [{k: r[k] for k in ("category", "bound", "frac", "avg_launch_us", "total_ms", "hbm_GBs", "mfma_TFs")}
+                     for r in rows[1:]]
+    return top
