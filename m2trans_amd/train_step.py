@@ -22,6 +22,7 @@ from typing import Optional
 import torch
 
 from . import _lib
+from .dist import GradBucket, global_divisor
 from .M2Trans_network import M2Trans
 
 
@@ -53,7 +54,7 @@ class TrainStep:
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self.loss = torch.zeros(1, dtype=torch.float32, device=flat.device)
-        self.grad_bucket_dtype = grad_bucket_dtype
+        self.bucket = GradBucket(self.grads, process_group, grad_bucket_dtype) if self.world_size > 1 else None
 
     def set_lr(self, lr: float):
         self.lr = float(lr)
@@ -70,7 +71,7 @@ class TrainStep:
         B = lr_img.shape[0]
         if tuple(hr_img.shape) != (B, 3, lr_img.shape[2] * m.scale, lr_img.shape[3] * m.scale):
             raise _lib.M2TError("hr shape must be [B,3,H*scale,W*scale]")
-        divisor = float(hr_img.numel()) * self.world_size      # global mean (equal shards)
+        divisor = global_divisor(hr_img.numel(), self.world_size)      # global mean (equal shards)
         plan.gen += 1
         with torch.cuda.device(lr_img.device):
             st = _lib.stream_ptr()
@@ -84,13 +85,8 @@ class TrainStep:
         return self.loss
 
     def all_reduce_grads(self):
-        if self.world_size > 1:
-            if self.grad_bucket_dtype == torch.float32:
-                torch.distributed.all_reduce(self.grads, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-            else:
-                b = self.grads.to(self.grad_bucket_dtype)
-                torch.distributed.all_reduce(b, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-                self.grads.copy_(b)
+        if self.bucket is not None:
+            self.bucket.all_reduce()
 
     def optimizer_step(self):
         self.step_count += 1

@@ -201,6 +201,19 @@ def main():
     np.savez_compressed(os.path.join(out_dir, "psnr.npz"), psnr=np.array(ps_ref))
     report.append(f"PSNR(Y) {ps_ref:.6f} dB matches utils.calc_psnr")
 
+    # ---- 7. seed-33 initial weights of the REAL reference (train.py:40-48) -----------------
+    args4 = types.SimpleNamespace(n_feats=64, scale=4, rgb_range=1.0, n_blocks=8, colors=3)
+    torch.manual_seed(33)
+    ref0 = mod.create_model(args4)
+    sd0 = ref0.state_dict()
+    names0 = list(sd0.keys())
+    np.savez_compressed(os.path.join(out_dir, "init_seed33_x4.npz"),
+                        names=np.array(names0),
+                        sums=np.array([float(sd0[k].double().sum()) for k in names0]),
+                        abs_sums=np.array([float(sd0[k].double().abs().sum()) for k in names0]),
+                        body3_attn2_rel_w=sd0["body.3.attn2.rel_w"].numpy())
+    report.append("seed-33 init checksums of the reference written (init_seed33_x4.npz)")
+
     with open(os.path.join(HERE, "PINNING.txt"), "w") as f:
         f.write("oracle/m2trans_oracle.py checked against /root/reference "
                 "(models/M2Trans_network.py, utils.py) by oracle/pin_against_reference.py\n")

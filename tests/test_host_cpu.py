@@ -1,0 +1,201 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every declared symbol, the host-side
+mirror of the reference interface (state_dict, init, loaders, errors), and the data-parallel
+exchange over gloo (world_size 2)."""
+import ctypes as C
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import m2trans_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(scale=4, nb=8):
+    return types.SimpleNamespace(n_feats=64, scale=scale, rgb_range=1.0, n_blocks=nb, colors=3)
+
+
+def test_library_exports_every_declared_symbol():
+    from m2trans_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "m2t.h")).read()
+    declared = set(re.findall(r"\b(m2t_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/m2t.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.m2t_version() >= 100
+
+
+def test_plan_layout_matches_module_and_oracle_inventory():
+    from m2trans_amd import _lib
+    from m2trans_amd.M2Trans_network import create_model
+    lib = _lib.load()
+    for scale in (2, 3, 4):
+        m = create_model(_args(scale))
+        shapes = O.param_shapes(64, scale, 8)
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(shapes.keys())
+        assert all(tuple(sd[k].shape) == shapes[k] for k in sd)
+        h = C.c_void_p()
+        _lib.check(lib.m2t_plan_create(C.byref(h), 2, 40, 56, scale, 8, _lib.F32))
+        assert lib.m2t_plan_query(h, b"num_params") == m.flat_params.numel()
+        assert lib.m2t_plan_query(h, b"padded_h") == 64 and lib.m2t_plan_query(h, b"padded_w") == 64
+        for n, (o, k) in m.param_offsets().items():
+            assert lib.m2t_plan_query(h, ("param:" + n).encode()) == o
+            assert lib.m2t_plan_query(h, ("numel:" + n).encode()) == k
+        assert lib.m2t_plan_query(h, b"ws:no_such_tensor") == -1
+        lib.m2t_plan_destroy(h)
+
+
+def test_plan_argument_errors_are_reported():
+    from m2trans_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.m2t_plan_create(C.byref(h), 1, 32, 32, 5, 8, 0) < 0          # bad scale
+    assert b"bad argument" in lib.m2t_last_error_string()
+    assert lib.m2t_plan_create(C.byref(h), 1, 16, 64, 4, 8, 0) < 0          # reflect pad 16 -> 32 needs pad < size
+    with pytest.raises(_lib.M2TError):
+        _lib.check(lib.m2t_plan_create(C.byref(h), 0, 32, 32, 4, 8, 0), "plan")
+
+
+def test_parameters_are_views_of_one_flat_buffer_and_survive_apply():
+    from m2trans_amd.M2Trans_network import create_model
+    m = create_model(_args(4, 2))
+    flat = m.flat_params
+    base = flat.data_ptr()
+    for (n, p), (o, k, s) in zip(m._trainable(), m._slots):
+        assert p.data_ptr() == base + 4 * o and p.numel() == k
+    m = m.float()                                  # _apply re-flattens
+    flat2 = m.flat_params
+    for (n, p), (o, k, s) in zip(m._trainable(), m._slots):
+        assert p.data_ptr() == flat2.data_ptr() + 4 * o
+    g = m.attach_flat_grads()
+    for (n, p), (o, k, s) in zip(m._trainable(), m._slots):
+        assert p.grad.data_ptr() == g.data_ptr() + 4 * o
+    assert not m.sub_mean.weight.requires_grad and not m.add_mean.bias.requires_grad
+
+
+def test_seed_33_init_checksums_match_reference_fixture(golden_dir):
+    """Same torch seed -> same initial weights as the reference (fixture written by
+    oracle/pin_against_reference.py from the real reference under seed 33)."""
+    from m2trans_amd.M2Trans_network import create_model
+    g = np.load(os.path.join(golden_dir, "init_seed33_x4.npz"))
+    torch.manual_seed(33)
+    m = create_model(_args(4, 8))
+    sd = m.state_dict()
+    names = [str(s) for s in g["names"]]
+    assert names == list(sd.keys())
+    sums = np.array([float(sd[k].double().sum()) for k in names])
+    asums = np.array([float(sd[k].double().abs().sum()) for k in names])
+    assert np.allclose(sums, g["sums"], rtol=0, atol=1e-9)
+    assert np.allclose(asums, g["abs_sums"], rtol=0, atol=1e-9)
+    assert torch.equal(sd["body.3.attn2.rel_w"], torch.from_numpy(g["body3_attn2_rel_w"]))
+
+
+def test_load_state_dict_reference_semantics():
+    from m2trans_amd.M2Trans_network import create_model
+    m4 = create_model(_args(4, 1))
+    m2 = create_model(_args(2, 1))
+    sd4 = {("module." + k): v.clone() for k, v in m4.state_dict().items()}   # DataParallel prefix (train.py:73,345)
+    m4b = create_model(_args(4, 1))
+    m4b.load_state_dict(sd4, strict=True)
+    for k, v in m4.state_dict().items():
+        assert torch.equal(v, m4b.state_dict()[k])
+    m2.load_state_dict(m4.state_dict())            # tail mismatch tolerated (M2Trans_network.py:96-98)
+    assert torch.equal(m2.state_dict()["head.weight"], m4.state_dict()["head.weight"])
+    bad = dict(m4.state_dict())
+    bad["head.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        m4b.load_state_dict(bad)
+    with pytest.raises(KeyError):
+        m4b.load_state_dict({"nope": torch.zeros(1)}, strict=True)
+
+
+def test_forward_refuses_cpu_tensors():
+    from m2trans_amd._lib import M2TError
+    from m2trans_amd.M2Trans_network import create_model
+    with pytest.raises(M2TError):
+        create_model(_args(4, 1))(torch.zeros(1, 3, 32, 32))
+
+
+def test_cosine_lr_matches_oracle():
+    from m2trans_amd.train_step import cosine_lr
+    for e in (0, 1, 57, 200):
+        assert abs(cosine_lr(e) - O.cosine_lr(e)) < 1e-15
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "m2trans_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("# oracle", ""), fn
+
+
+# ---- data parallel over gloo, world_size 2 ---------------------------------------------------
+def _dp_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from m2trans_amd.dist import GradBucket, global_divisor, shard_size, broadcast_params
+        from m2trans_amd.M2Trans_network import create_model
+        torch.set_num_threads(2)
+        scale, nb, Bg, H, W = 4, 1, 4, 32, 32
+        B = shard_size(Bg, world)
+        p = O.closed_form_params(64, scale, nb)
+        model = create_model(_args(scale, nb))          # CPU: only used for the flat layout
+        torch.nn.Module.load_state_dict(model, {k: v.clone() for k, v in p.items()}, strict=True)
+        flat = model.flat_params
+        if rank == 1:
+            flat.add_(1.0)                               # diverge, then re-sync from rank 0
+        broadcast_params(flat, 0)
+        x = O.closed_form_image(Bg, 3, H, W)
+        hr = O.closed_form_image(Bg, 3, H * scale, W * scale, phase=0.7)
+        xs, hs = x[rank * B:(rank + 1) * B], hr[rank * B:(rank + 1) * B]
+        pr = {k: v for k, v in p.items()}
+        _, _, g = O.l1_loss_and_grads(xs, hs, pr, scale, nb, loss_divisor=global_divisor(hs.numel(), world))
+        grads = model.attach_flat_grads()
+        for n, (o, k) in model.param_offsets().items():
+            grads[o:o + k].copy_(g[n].reshape(-1))
+        GradBucket(grads).all_reduce()
+        _, _, gfull = O.l1_loss_and_grads(x, hr, p, scale, nb)
+        worst = 0.0
+        for n, (o, k) in model.param_offsets().items():
+            want = gfull[n].reshape(-1)
+            worst = max(worst, float((grads[o:o + k] - want).abs().max() / (want.abs().max() + 1e-30)))
+        # bf16 wire format: looser, but still the same gradient
+        grads2 = grads.clone()
+        GradBucket(grads2, comm_dtype=torch.bfloat16).all_reduce()
+        wire = float((grads2 / world - grads).abs().max() / grads.abs().max())
+        ret[rank] = (worst, wire, float(flat.sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_sum_of_shard_grads_equals_full_batch_grad_gloo():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29600 + os.getpid() % 200
+    mp.spawn(_dp_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        worst, wire, psum = ret[r]
+        assert worst < 2e-4, worst          # fp32 sharded-sum vs full-batch gradient
+        assert wire < 2e-2, wire            # bf16 bucket
+    assert ret[0][2] == ret[1][2]           # replicas hold identical weights after the broadcast
+
+
+def test_shard_size_rejects_uneven_batches():
+    from m2trans_amd.dist import shard_size
+    assert shard_size(256, 8) == 32
+    with pytest.raises(ValueError):
+        shard_size(10, 4)
