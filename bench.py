@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--all-kernel-events", action="store_true", help="time every kernel category in the timed region (adds ~8%% overhead)")
+    ap.add_argument("--no-side-stream", action="store_true", help="run the whole backward on one stream")
     ap.add_argument("--cpu-baseline-batch", type=int, default=2)
     return ap.parse_args()
 
@@ -123,6 +125,9 @@ def main():
     ts = TrainStep(model, lr=1e-4, lambda_l1=1.0, process_group=pg, world_size=world)
     B = args.batch
     batches = [synthetic_batch(B, args.lr_size, args.scale, rank, s, device) for s in range(2)]
+    if args.no_side_stream:
+        plan = model._plan_for(batches[0][0])
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"side_stream", 0), "m2t_set_option")
 
     from m2trans_amd import profile as m2t_profile
     dominant_mask = 0
@@ -141,7 +146,7 @@ def main():
     torch.cuda.synchronize()
     if rank == 0 and not args.no_kernel_events:
         # HIP events on the launch stream around the dominant kernel only (keeps the timed region honest)
-        m2t_profile.enable(dominant_mask or m2t_profile.ALL_MASK)
+        m2t_profile.enable(m2t_profile.ALL_MASK if args.all_kernel_events else (dominant_mask or m2t_profile.ALL_MASK))
     t0 = time.perf_counter()
     for s in range(args.steps):
         ts.step(*batches[s % 2])

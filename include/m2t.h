@@ -51,6 +51,8 @@ void m2t_plan_destroy(m2t_plan* p);
  * "ws:<tensor>" (byte offset of a workspace tensor, e.g. "ws:b0.qkv3"), "wsn:<tensor>" (elements).
  * Returns -1 for an unknown key. */
 long long m2t_plan_query(const m2t_plan* p, const char* key);
+/* options: "side_stream" 1/0 -- run parameter-gradient kernels of m2t_backward on a second stream (default 1). */
+int m2t_set_option(m2t_plan* p, const char* key, long long value);
 /* one-time initialisation of the workspace (uploads the weight-packing table). */
 int m2t_plan_init_workspace(m2t_plan* p, void* workspace, void* stream);
 

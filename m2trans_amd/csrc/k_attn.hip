@@ -511,8 +511,7 @@ template <typename T, int C> static size_t attn_bwd_smem() {
 
 template <typename T>
 static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const float* rel_w, const T* gout, int ldg, int gc0,
-                                    T* gqkv, T* win, float* relw, float* rel_part, float* grel_h, float* grel_w, int B,
-                                    int h, int w, int C, hipStream_t st) {
+                                    T* gqkv, T* win, float* relw, int B, int h, int w, int C, hipStream_t st) {
   const int nwin = B * (h / 8) * (w / 8);
 #define GO(C_)                                                                                                     \
   {                                                                                                                \
@@ -532,22 +531,22 @@ static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const floa
     hipLaunchKernelGGL(halo_gather_kernel<T>, dim3(g), dim3(256), 0, st, win, gqkv, B, h, w, C);
     M2T_LAUNCH_CHECK();
   }
-  {
-    int nsplit = std::min(nwin, 32);
-    const int wps = ceil_div(nwin, nsplit);
-    nsplit = ceil_div(nwin, wps);
-    hipLaunchKernelGGL(rel_reduce1_kernel, dim3(ceil_div(10 * C, 256), nsplit), dim3(256), 0, st, relw, rel_part, nwin, 10 * C, wps);
-    M2T_LAUNCH_CHECK();
-    hipLaunchKernelGGL(rel_reduce2_kernel, dim3(ceil_div(10 * C, 256)), dim3(256), 0, st, rel_part, grel_h, grel_w, nsplit, C);
-    M2T_LAUNCH_CHECK();
-  }
+  return 0;
+}
+int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st) {
+  int nsplit = std::min(nwin, 32);
+  const int wps = ceil_div(nwin, nsplit);
+  nsplit = ceil_div(nwin, wps);
+  hipLaunchKernelGGL(rel_reduce1_kernel, dim3(ceil_div(10 * C, 256), nsplit), dim3(256), 0, st, relw, rel_part, nwin, 10 * C, wps);
+  M2T_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rel_reduce2_kernel, dim3(ceil_div(10 * C, 256)), dim3(256), 0, st, rel_part, grel_h, grel_w, nsplit, C);
+  M2T_LAUNCH_CHECK();
   return 0;
 }
 int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
-                           int gc0, void* gqkv, void* win, float* relw, float* rel_part, float* grel_h, float* grel_w,
-                           int B, int h, int w, int C, hipStream_t st) {
+                           int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st) {
   if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn_bwd: h,w must be multiples of 8");
   if (dt == M2T_F32)
-    return launch_window_attn_bwd_t<float>((const float*)qkv, rel_h, rel_w, (const float*)gout, ldg, gc0, (float*)gqkv, (float*)win, relw, rel_part, grel_h, grel_w, B, h, w, C, st);
-  return launch_window_attn_bwd_t<bf16_t>((const bf16_t*)qkv, rel_h, rel_w, (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, rel_part, grel_h, grel_w, B, h, w, C, st);
+    return launch_window_attn_bwd_t<float>((const float*)qkv, rel_h, rel_w, (const float*)gout, ldg, gc0, (float*)gqkv, (float*)win, relw, B, h, w, C, st);
+  return launch_window_attn_bwd_t<bf16_t>((const bf16_t*)qkv, rel_h, rel_w, (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, B, h, w, C, st);
 }

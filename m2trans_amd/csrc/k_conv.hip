@@ -335,21 +335,31 @@ int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs
 
 // =======================================================================================
 // tail conv 64 -> 3, reflect padding, no bias; input = GELU(tpre) applied while staging.
-// Workgroup = 16 x 16 output pixels, one pixel per thread, 3 accumulators; the weights are
-// wave-uniform (scalar loads).  Output NCHW fp32.
+// N = 3 is too thin for a direct MFMA mapping, so the 9 taps are folded into the N axis:
+//     Y[p][(tap,oc)] = sum_ic act[p][ic] * w[oc][ic][tap]          (K = 64, N = 27 -> 32)
+//     out[o][oc]     = sum_tap Y[o + off(tap)][(tap,oc)]            (9 shifted adds from LDS)
+// and symmetrically for the data gradient (K = 27 -> 32 gathered gradient taps, N = 64) and the
+// weight gradient (contraction over the tile's halo pixels, transposing LDS reads).
+// Workgroup = 16 x 16 output pixels (+1 halo).  Output / gradient tensors are NCHW fp32.
 // =======================================================================================
 #define FC_T 16
+#define FC_HP ((FC_T + 2) * (FC_T + 2))   // 324 halo pixels
+#define FC_HPP 352                        // padded to 11 contraction chunks of 32
 #define FC_LD 72
 
+// halo tile of GELU(tpre) (reflect addressing), rows >= 324 zero
 template <typename T>
 __device__ __forceinline__ void final_stage_act(T (*As)[FC_LD], const T* __restrict__ tb, int y0, int x0, int H, int W, int tid) {
-  for (int idx = tid; idx < (FC_T + 2) * (FC_T + 2) * 8; idx += 256) {
+  for (int idx = tid; idx < FC_HPP * 8; idx += 256) {
     const int cv = idx & 7, p = idx >> 3;
-    const int py = p / (FC_T + 2), px = p - py * (FC_T + 2);
-    const int gy = reflect_idx(y0 + py - 1, H), gx = reflect_idx(x0 + px - 1, W);
-    Frag8<T> f = load8(tb + ((long long)gy * W + gx) * 64 + cv * 8);
+    Frag8<T> f = frag_zero<T>();
+    if (p < FC_HP) {
+      const int py = p / (FC_T + 2), px = p - py * (FC_T + 2);
+      const int gy = reflect_idx(y0 + py - 1, H), gx = reflect_idx(x0 + px - 1, W);
+      f = load8(tb + ((long long)gy * W + gx) * 64 + cv * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f.set(e, gelu_erf(f.get(e)));
+      for (int e = 0; e < 8; ++e) f.set(e, gelu_erf(f.get(e)));
+    }
     store8(&As[p][cv * 8], f);
   }
 }
@@ -357,29 +367,60 @@ __device__ __forceinline__ void final_stage_act(T (*As)[FC_LD], const T* __restr
 template <typename T>
 __global__ void __launch_bounds__(256) final_conv_fwd_kernel(const T* __restrict__ tpre, const float* __restrict__ w,
                                                              float* __restrict__ out, int H, int W) {
-  __shared__ __attribute__((aligned(16))) T As[(FC_T + 2) * (FC_T + 2)][FC_LD];
-  const int tid = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T(*As)[FC_LD] = reinterpret_cast<T(*)[FC_LD]>(smem);                                   // [352][72]
+  constexpr size_t szAY = (sizeof(T) * FC_HPP * FC_LD > sizeof(float) * 336 * 33) ? sizeof(T) * FC_HPP * FC_LD : sizeof(float) * 336 * 33;
+  T(*Ws)[FC_LD] = reinterpret_cast<T(*)[FC_LD]>(smem + szAY);      // [32][72]
+  float(*Ys)[33] = reinterpret_cast<float(*)[33]>(smem);   // [336][33] fp32, ALIASES As once the products are done
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
   const int x0 = blockIdx.x * FC_T, y0 = blockIdx.y * FC_T, b = blockIdx.z;
   final_stage_act<T>(As, tpre + (long long)b * H * W * 64, y0, x0, H, W, tid);
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const int n = i >> 6, ic = i & 63;              // n = tap*3 + oc
+    float v = 0.f;
+    if (n < 27) v = w[((n % 3) * 64 + ic) * 9 + n / 3];
+    Ws[n][ic] = from_f<T>(v);
+  }
+  __syncthreads();
+  // Y^T tile products: rows n (2 tiles), cols = halo pixels (21 tiles of 16: wave wv takes wv, wv+4, ...)
+  f32x4 acc[6][2];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int mt = wv + 4 * j;
+    if (mt < 21) {
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        const Frag8<T> xf = load8(&As[16 * mt + lr][32 * kc + 8 * g]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const Frag8<T> wf = load8(&Ws[16 * nt + lr][32 * kc + 8 * g]);
+          mma16(acc[j][nt], wf, xf);
+        }
+      }
+    }
+  }
+  __syncthreads();      // every wave is done reading As: its memory becomes the Y tile
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int mt = wv + 4 * j;
+    if (mt < 21) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ys[16 * mt + lr][16 * nt + 4 * g + r] = acc[j][nt][r];
+    }
+  }
   __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll 1
+#pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
-    const T* ap = &As[(ty + ky) * (FC_T + 2) + tx + kx][0];
-#pragma unroll
-    for (int cv = 0; cv < 8; ++cv) {
-      float v[8];
-      load8f(ap + cv * 8, v);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int ic = cv * 8 + e;
-        a0 = fmaf(v[e], w[(0 * 64 + ic) * 9 + tap], a0);
-        a1 = fmaf(v[e], w[(1 * 64 + ic) * 9 + tap], a1);
-        a2 = fmaf(v[e], w[(2 * 64 + ic) * 9 + tap], a2);
-      }
-    }
+    const float* yp = &Ys[(ty + ky) * (FC_T + 2) + tx + kx][tap * 3];
+    a0 += yp[0]; a1 += yp[1]; a2 += yp[2];
   }
   const long long hw = (long long)H * W;
   const long long o = (long long)b * 3 * hw + (long long)(y0 + ty) * W + x0 + tx;
@@ -387,56 +428,68 @@ __global__ void __launch_bounds__(256) final_conv_fwd_kernel(const T* __restrict
   out[o + hw] = a1;
   out[o + 2 * hw] = a2;
 }
+template <typename T> static size_t final_fwd_smem() {
+  const size_t a = sizeof(T) * FC_HPP * FC_LD, y = sizeof(float) * 336 * 33;   // Ys aliases As; Ws sits behind the larger of the two
+  return std::max(a, y) + sizeof(T) * 32 * FC_LD;
+}
 int launch_final_conv_fwd(int dt, const void* tpre, const float* w, float* out, int B, int H, int W, hipStream_t st) {
   if (H % FC_T || W % FC_T) return m2t_set_error(-2, "final_conv: H,W must be multiples of 16");
   dim3 grid(W / FC_T, H / FC_T, B);
-  if (dt == M2T_F32) hipLaunchKernelGGL(final_conv_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)tpre, w, out, H, W);
-  else hipLaunchKernelGGL(final_conv_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)tpre, w, out, H, W);
+  if (dt == M2T_F32) {
+    const size_t sh = final_fwd_smem<float>();
+    (void)hipFuncSetAttribute((const void*)final_conv_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(final_conv_fwd_kernel<float>, grid, dim3(256), sh, st, (const float*)tpre, w, out, H, W);
+  } else {
+    const size_t sh = final_fwd_smem<bf16_t>();
+    (void)hipFuncSetAttribute((const void*)final_conv_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(final_conv_fwd_kernel<bf16_t>, grid, dim3(256), sh, st, (const bf16_t*)tpre, w, out, H, W);
+  }
   M2T_LAUNCH_CHECK();
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------
 // tail conv data gradient (+ GELU backward):
-//   g_act[p][ic] = sum_{oc,tap} w[oc][ic][tap] * Geff[oc][tap],   g_tpre = g_act * GELU'(tpre)
-// Geff[oc][tap] gathers gout at the output positions that read input pixel p through tap,
-// INCLUDING the reads that reached p through the reflect padding (rows/cols 1 and n-2 also
-// serve the padded ring positions -1 and n).   thread = (pixel, 16-channel group)
+//   g_act[p][ic] = sum_{(tap,oc)} Geff[p][(tap,oc)] * w[oc][ic][tap],   g_tpre = g_act * GELU'(tpre)
+// Geff gathers gout at the output positions that read input pixel p through `tap`, INCLUDING the
+// reads that reached p through the reflect padding (rows/cols 1 and n-2 also serve the padded
+// ring positions -1 and n).  GEMM: M = 256 tile pixels, K = 27 -> 32, N = 64.
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) final_conv_dgrad_kernel(const float* __restrict__ gout, const float* __restrict__ w,
-                                                               const T* __restrict__ tpre, T* __restrict__ gt, int B, int H,
-                                                               int W) {
-  __shared__ float ws[27][64];   // [oc*9 + tap][ic]
-  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
-    const int oc = i / 576, r = i % 576, ic = r / 9, tap = r % 9;   // torch [3][64][3][3]
-    ws[oc * 9 + tap][ic] = w[i];
+                                                               const T* __restrict__ tpre, T* __restrict__ gt, int H, int W) {
+  __shared__ float Gs[3][FC_HP];                                     // gout halo tile (0 outside the image)
+  __shared__ __attribute__((aligned(16))) T Ge[256][40];            // Geff [pixel][(tap,oc) padded to 32]
+  __shared__ __attribute__((aligned(16))) T Wt[64][40];             // [ic][(tap,oc)]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int x0 = blockIdx.x * FC_T, y0 = blockIdx.y * FC_T, b = blockIdx.z;
+  const long long hw = (long long)H * W;
+  for (int i = tid; i < 3 * FC_HP; i += 256) {
+    const int oc = i / FC_HP, p = i - oc * FC_HP;
+    const int py = p / (FC_T + 2), px = p - py * (FC_T + 2);
+    const int gy = y0 + py - 1, gx = x0 + px - 1;
+    Gs[oc][p] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gout[((long long)b * 3 + oc) * hw + (long long)gy * W + gx] : 0.f;
+  }
+  for (int i = tid; i < 64 * 32; i += 256) {
+    const int ic = i >> 5, n = i & 31;
+    float v = 0.f;
+    if (n < 27) v = w[((n % 3) * 64 + ic) * 9 + n / 3];
+    Wt[ic][n] = from_f<T>(v);
   }
   __syncthreads();
-  const long long total = (long long)B * H * W * 4;
-  const long long hw = (long long)H * W;
-  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
-       t += (long long)gridDim.x * blockDim.x) {
-    asm volatile("" ::: "memory");   // keep the 27x16 weight reads inside the loop (no 432-register hoist)
-    const int cgp = (int)(t & 3);
-    const long long pix = t >> 2;
-    const int xx = (int)(pix % W);
-    const long long q = pix / W;
-    const int yy = (int)(q % H);
-    const int b = (int)(q / H);
-    // padded-grid positions that map onto (yy, xx)
+  {
+    // one thread per tile pixel builds its 27 gathered taps
+    const int ty = tid >> 4, tx = tid & 15;
+    const int yy = y0 + ty, xx = x0 + tx;
     int pys[2], pxs[2], npy = 1, npx = 1;
     pys[0] = yy; pxs[0] = xx;
     if (yy == 1) pys[npy++] = -1;
-    if (yy == H - 2) { if (npy < 2) pys[npy++] = H; }
+    if (yy == H - 2 && npy < 2) pys[npy++] = H;
     if (xx == 1) pxs[npx++] = -1;
-    if (xx == W - 2) { if (npx < 2) pxs[npx++] = W; }
-    // (for H or W == 3 a pixel could serve both ring sides; sizes here are >= 32)
-    float acc[16];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    if (xx == W - 2 && npx < 2) pxs[npx++] = W;
 #pragma unroll 1
-    for (int oc = 0; oc < 3; ++oc) {       // one output channel at a time keeps the live set small
+    for (int oc = 0; oc < 3; ++oc) {          // one output channel at a time keeps the live set small
       float ge[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) ge[i] = 0.f;
@@ -450,53 +503,79 @@ __global__ void __launch_bounds__(256) final_conv_dgrad_kernel(const float* __re
             for (int kx = 0; kx < 3; ++kx) {
               const int ox = pxs[c] - kx + 1;
               if (ox < 0 || ox >= W) continue;
-              ge[ky * 3 + kx] += gout[((long long)b * 3 + oc) * hw + (long long)oy * W + ox];
+              ge[ky * 3 + kx] += Gs[oc][(oy - y0 + 1) * (FC_T + 2) + (ox - x0 + 1)];   // always inside the +-1 halo
             }
           }
         }
 #pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        const float gv = ge[i];
-        const float* wr = &ws[oc * 9 + i][cgp * 16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = fmaf(gv, wr[e], acc[e]);
-      }
+      for (int i = 0; i < 9; ++i) Ge[tid][i * 3 + oc] = from_f<T>(ge[i]);
     }
-    float p[16];
-    load16f(tpre + pix * 64 + cgp * 16, p);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] *= gelu_erf_grad(p[e]);
-    store16f(gt + pix * 64 + cgp * 16, acc);
+    for (int i = 27; i < 32; ++i) Ge[tid][i] = from_f<T>(0.f);
+  }
+  __syncthreads();
+  // wave wv: pixel tiles 4 wv .. 4 wv + 3 (= tile rows), all 4 channel tiles; A rows = ic (permuted so a
+  // lane ends with 16 consecutive channels), B cols = pixels
+#pragma unroll 1
+  for (int mtl = 0; mtl < 4; ++mtl) {
+    const int mt = 4 * wv + mtl;
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const Frag8<T> xf = load8(&Ge[16 * mt + lr][8 * g]);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int nl = 16 * (lr >> 2) + 4 * nt + (lr & 3);
+      const Frag8<T> wf = load8(&Wt[nl][8 * g]);
+      mma16(acc[nt], wf, xf);
+    }
+    const int pix_t = 16 * mt + lr;
+    const long long pix = ((long long)b * H + y0 + (pix_t >> 4)) * W + x0 + (pix_t & 15);
+    float v[16], pp[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[nt][r];
+    load16f(tpre + pix * 64 + 16 * g, pp);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] *= gelu_erf_grad(pp[e]);
+    store16f(gt + pix * 64 + 16 * g, v);
   }
 }
 int launch_final_conv_dgrad(int dt, const float* gout, const float* w, const void* tpre, void* gtpre, int B, int H, int W,
                             hipStream_t st) {
-  const long long total = (long long)B * H * W * 4;
-  const int g = (int)std::min<long long>(ceil_divll(total, 256), 8192);
-  if (dt == M2T_F32) hipLaunchKernelGGL(final_conv_dgrad_kernel<float>, dim3(g), dim3(256), 0, st, gout, w, (const float*)tpre, (float*)gtpre, B, H, W);
-  else hipLaunchKernelGGL(final_conv_dgrad_kernel<bf16_t>, dim3(g), dim3(256), 0, st, gout, w, (const bf16_t*)tpre, (bf16_t*)gtpre, B, H, W);
+  if (H % FC_T || W % FC_T) return m2t_set_error(-2, "final_conv: H,W must be multiples of 16");
+  dim3 grid(W / FC_T, H / FC_T, B);
+  if (dt == M2T_F32) hipLaunchKernelGGL(final_conv_dgrad_kernel<float>, grid, dim3(256), 0, st, gout, w, (const float*)tpre, (float*)gtpre, H, W);
+  else hipLaunchKernelGGL(final_conv_dgrad_kernel<bf16_t>, grid, dim3(256), 0, st, gout, w, (const bf16_t*)tpre, (bf16_t*)gtpre, H, W);
   M2T_LAUNCH_CHECK();
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------
-// tail conv weight gradient: dW[oc][ic][tap] = sum_p gout[oc][p] * act[refl(p + tap)][ic]
-// Workgroup sweeps 16x16 tiles; thread (ic = tid&63, wave = tid>>6 owns 4 tile rows) keeps
-// 27 accumulators and slides a 3x3 register window along each row (3 LDS reads per pixel).
+// tail conv weight gradient: dW[oc][ic][tap] = sum_{output pixels o} gout[oc][o] * act[refl(o + off(tap))][ic]
+// Per 16x16 tile and tap: a [16 (3 used) x 256] x [256 x 64] product whose contraction runs over the
+// tile's output pixels; the gradient operand is the row-major [oc][o] tile, the activation operand comes
+// from the row-major halo tile by transposing LDS reads at the tap's offset (8 consecutive pixels of a
+// tile row = 8 consecutive halo rows).  Wave w owns channel tile w for all 9 taps (9 accumulators);
+// a workgroup sweeps several tiles before writing its slab.
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) final_conv_wgrad_kernel(const float* __restrict__ gout, const T* __restrict__ tpre,
                                                                float* __restrict__ slabs, int B, int H, int W,
                                                                int tiles_per_block) {
-  __shared__ __attribute__((aligned(16))) T As[(FC_T + 2) * (FC_T + 2)][FC_LD];
-  __shared__ float Gs[3][FC_T * FC_T];
-  const int tid = threadIdx.x, ic = tid & 63, wv = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T(*As)[FC_LD] = reinterpret_cast<T(*)[FC_LD]>(smem);                                          // [352][72] act
+  T(*Gs)[FC_T * FC_T + 8] = reinterpret_cast<T(*)[FC_T * FC_T + 8]>(smem + sizeof(T) * FC_HPP * FC_LD);   // [16][264], rows 3.. zero
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
   const int tw = W / FC_T, th = H / FC_T;
   const long long ntiles = (long long)B * th * tw;
   const long long hw = (long long)H * W;
-  float acc[27];
+  f32x4 acc[9];
 #pragma unroll
-  for (int i = 0; i < 27; ++i) acc[i] = 0.f;
+  for (int i = 0; i < 9; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 13 * (FC_T * FC_T + 8); i += 256) Gs[3 + i / (FC_T * FC_T + 8)][i % (FC_T * FC_T + 8)] = from_f<T>(0.f);
   const long long t0 = (long long)blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
   for (long long t = t0; t < t1; ++t) {
     const int tx = (int)(t % tw);
@@ -508,58 +587,51 @@ __global__ void __launch_bounds__(256) final_conv_wgrad_kernel(const float* __re
     final_stage_act<T>(As, tpre + (long long)b * hw * 64, y0, x0, H, W, tid);
     for (int i = tid; i < 3 * FC_T * FC_T; i += 256) {
       const int oc = i >> 8, p = i & 255;
-      Gs[oc][p] = gout[((long long)b * 3 + oc) * hw + (long long)(y0 + (p >> 4)) * W + x0 + (p & 15)];
+      Gs[oc][p] = from_f<T>(gout[((long long)b * 3 + oc) * hw + (long long)(y0 + (p >> 4)) * W + x0 + (p & 15)]);
     }
     __syncthreads();
 #pragma unroll 1
-    for (int rr = 0; rr < 4; ++rr) {
-      const int py = 4 * wv + rr;
-      float win[3][3];
+    for (int ch = 0; ch < 8; ++ch) {
+      // contraction slot (g, j) <-> output pixel o = 32 ch + 8 g + j : tile row 2 ch + (g >> 1), col 8 (g & 1) + j
+      const Frag8<T> gf = load8(&Gs[lr][32 * ch + 8 * g]);
+      const int orow = 2 * ch + (g >> 1), ocol = 8 * (g & 1);
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        win[ky][1] = to_f(As[(py + ky) * (FC_T + 2) + 0][ic]);
-        win[ky][2] = to_f(As[(py + ky) * (FC_T + 2) + 1][ic]);
-      }
-#pragma unroll 4
-      for (int px = 0; px < FC_T; ++px) {
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          win[ky][0] = win[ky][1];
-          win[ky][1] = win[ky][2];
-          win[ky][2] = to_f(As[(py + ky) * (FC_T + 2) + px + 2][ic]);
-        }
-        const float g0 = Gs[0][py * FC_T + px], g1 = Gs[1][py * FC_T + px], g2 = Gs[2][py * FC_T + px];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            acc[0 * 9 + ky * 3 + kx] = fmaf(g0, win[ky][kx], acc[0 * 9 + ky * 3 + kx]);
-            acc[1 * 9 + ky * 3 + kx] = fmaf(g1, win[ky][kx], acc[1 * 9 + ky * 3 + kx]);
-            acc[2 * 9 + ky * 3 + kx] = fmaf(g2, win[ky][kx], acc[2 * 9 + ky * 3 + kx]);
-          }
+      for (int tap = 0; tap < 9; ++tap) {
+        const int hp = (orow + tap / 3) * (FC_T + 2) + ocol + tap % 3;       // halo row of the slot's first pixel
+        const Frag8<T> af = load8_tr(&As[hp][16 * wv], &As[hp + 4][16 * wv], FC_LD, lane);
+        mma16(acc[tap], gf, af);
       }
     }
   }
-  __syncthreads();
-  float(*red)[27][64] = reinterpret_cast<float(*)[27][64]>(&As[0][0]);   // 4*27*64*4 = 27.6 KB <= sizeof(As)
+  // slab [32 n = tap*3+oc][64 ic]; lane (ic = 16 wv + lr, g) holds rows oc = 4 g + r (only g == 0, r < 3 are real)
+  float* out = slabs + (long long)blockIdx.x * (32 * 64);
+  if (g == 0) {
 #pragma unroll
-  for (int i = 0; i < 27; ++i) red[wv][i][ic] = acc[i];
-  __syncthreads();
-  for (int i = tid; i < 27 * 64; i += 256) {
-    // torch layout [oc][ic][tap]: i = (oc*64 + ic)*9 + tap
-    const int oc = i / 576, r = i % 576, c = r / 9, tap = r % 9;
-    const int a = oc * 9 + tap;
-    slabs[(long long)blockIdx.x * (27 * 64) + i] = red[0][a][c] + red[1][a][c] + red[2][a][c] + red[3][a][c];
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int r = 0; r < 3; ++r) out[(tap * 3 + r) * 64 + 16 * wv + lr] = acc[tap][r];
   }
+  if (tid < 5 * 64) out[27 * 64 + tid] = 0.f;
+}
+template <typename T> static size_t final_wgrad_smem() {
+  return sizeof(T) * (FC_HPP * FC_LD + 16 * (FC_T * FC_T + 8));
 }
 int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* slabs, int* nslab, int B, int H, int W,
                             hipStream_t st) {
+  if (H % FC_T || W % FC_T) return m2t_set_error(-2, "final_conv: H,W must be multiples of 16");
   const long long ntiles = (long long)B * (H / FC_T) * (W / FC_T);
-  int nblk = (int)std::min<long long>(512, ntiles);
+  int nblk = (int)std::min<long long>(1024, ntiles);
   const int tpb = (int)ceil_divll(ntiles, nblk);
   nblk = (int)ceil_divll(ntiles, tpb);
-  if (dt == M2T_F32) hipLaunchKernelGGL(final_conv_wgrad_kernel<float>, dim3(nblk), dim3(256), 0, st, gout, (const float*)tpre, slabs, B, H, W, tpb);
-  else hipLaunchKernelGGL(final_conv_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, gout, (const bf16_t*)tpre, slabs, B, H, W, tpb);
+  if (dt == M2T_F32) {
+    const size_t sh = final_wgrad_smem<float>();
+    (void)hipFuncSetAttribute((const void*)final_conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(final_conv_wgrad_kernel<float>, dim3(nblk), dim3(256), sh, st, gout, (const float*)tpre, slabs, B, H, W, tpb);
+  } else {
+    const size_t sh = final_wgrad_smem<bf16_t>();
+    (void)hipFuncSetAttribute((const void*)final_conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(final_conv_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), sh, st, gout, (const bf16_t*)tpre, slabs, B, H, W, tpb);
+  }
   M2T_LAUNCH_CHECK();
   *nslab = nblk;
   return 0;

@@ -703,6 +703,10 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
       const int kk = (int)(e % p2); const int np = (int)(e / p2);
       const int sub = np / p0, c = np % p0;
       d = ((long long)c * p1 + sub) * p2 + kk;
+    } else if (perm == 3) {    // tail conv slab [32 (tap*3+oc, 27 used)][64 ic] -> torch [3][64][3][3]
+      const int ic = (int)(e & 63), nn = (int)(e >> 6);
+      if (nn >= 27) continue;
+      d = ((long long)(nn % 3) * 64 + ic) * 9 + nn / 3;
     }
     out[d] = acc;
   }

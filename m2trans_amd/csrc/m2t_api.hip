@@ -84,6 +84,21 @@ struct m2t_plan {
   std::map<std::string, long long> pk;       // packed weight offsets (elements of T)
   long long npacked = 0;
   bool have_seed = false, have_acts = false;
+  bool use_side = true;
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> events;
+  int ensure_side() {
+    if (side) return 0;
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return -1;
+    events.resize(192);
+    for (auto& e : events)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
+    return 0;
+  }
+  ~m2t_plan() {
+    for (auto e : events) if (e) (void)hipEventDestroy(e);
+    if (side) (void)hipStreamDestroy(side);
+  }
 
   void add_param(const std::string& n, long long cnt) { pnames.push_back(n); poff[n] = nparams; pnum[n] = cnt; nparams += cnt; }
   size_t add_ws(const std::string& n, size_t elems, size_t es) {
@@ -203,9 +218,11 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("gn", BP * 64, es);
   p->add_ws("ga", BP * 16, es);
   p->add_ws("gd", BP * 16, es);
-  p->add_ws("gqkv", BP * 48, es);
+  p->add_ws("gqkv0", BP * 48, es);
+  p->add_ws("gqkv1", BP * 48, es);
   p->add_ws("win", BP * 50, es);
-  p->add_ws("relw", (size_t)(BP / 64) * 10 * 16, 4);
+  p->add_ws("relw0", (size_t)(BP / 64) * 10 * 16, 4);
+  p->add_ws("relw1", (size_t)(BP / 64) * 10 * 16, 4);
   p->add_ws("rel_part", 32 * 10 * 256, 4);
   p->add_ws("slabs", (size_t)256 * 9 * 64 * 64, 4);
   p->add_ws("col_part", (size_t)256 * 768, 4);
@@ -362,16 +379,42 @@ extern "C" int m2t_set_output_grad(m2t_plan* p, const float* g_sr, float rgb_ran
   return 0;
 }
 
+// Two-stream backward.  The data-gradient chain (what the next kernel needs) runs on the
+// caller's stream; everything that only produces PARAMETER gradients (weight/bias gradients,
+// slab reductions, rel-pos reductions) runs on the plan's side stream, forked/joined with
+// events, because neither class of kernel fills 256 CUs on its own at these sizes.
+// Hazards are closed explicitly: gqkv/relw are double-buffered and re-used only after the
+// side stream's consumer of two branches ago has finished; a block's gy buffer is rewritten
+// only after the side stream's conv-wgrad of the following block has read it.
 extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, float* grads, void* workspace,
                             void* stream) {
   if (!p || !params || !x || !grads || !workspace) return m2t_set_error(M2T_ERR_ARG, "m2t_backward: null argument");
   if (!p->have_acts || !p->have_seed)
     return m2t_set_error(M2T_ERR_STATE, "m2t_backward: needs m2t_forward and a seed (m2t_l1_loss / m2t_set_output_grad)");
   hipStream_t st = (hipStream_t)stream;
+  if (p->ensure_side() != 0) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: cannot create the side stream / events");
+  hipStream_t sd = p->use_side ? p->side : st;
+  size_t evi = 0;
+  auto next_event = [&]() -> hipEvent_t { return p->events[(evi++) % p->events.size()]; };
+  auto fork = [&]() {            // side stream continues from this point of the main stream
+    if (sd == st) return;
+    hipEvent_t e = next_event();
+    (void)hipEventRecord(e, st);
+    (void)hipStreamWaitEvent(sd, e, 0);
+  };
+  auto side_marker = [&]() -> hipEvent_t {
+    if (sd == st) return nullptr;
+    hipEvent_t e = next_event();
+    (void)hipEventRecord(e, sd);
+    return e;
+  };
+  auto main_wait = [&](hipEvent_t e) { if (e) (void)hipStreamWaitEvent(st, e, 0); };
+
   const int dt = p->dt, B = p->B, H = p->H, W = p->W, s = p->scale;
   const long long BP = (long long)B * p->P;
-  float* slabs = (float*)WSP("slabs");
-  float* colp = (float*)WSP("col_part");
+  float* slabs = (float*)WSP("slabs");       // side stream only
+  float* colp = (float*)WSP("col_part");     // side stream only
+  float* relp = (float*)WSP("rel_part");     // side stream only
   const float* gpre = (const float*)WSP("gpre");
   int ns = 0;
   const int r0 = (s == 4) ? 2 : s;
@@ -379,18 +422,20 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   const std::string wl = (s == 4) ? "tail.6.weight" : "tail.3.weight";
   const void* last_pre = (s == 4) ? WSP("t2pre") : WSP("t1pre");
   void* g_last = (s == 4) ? WSP("g_t2pre") : WSP("g_t1pre");
-  { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, st); CK(launch_final_conv_wgrad(dt, gpre, last_pre, slabs, &ns, B, p->Hsp, p->Wsp, st)); }
-  CK(launch_reduce_slabs(slabs, grads + p->poff.at(wl), ns, 3 * 64 * 9, 0, 0, 0, 0, st));
+  fork();
+  { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, sd); CK(launch_final_conv_wgrad(dt, gpre, last_pre, slabs, &ns, B, p->Hsp, p->Wsp, sd)); }
+  CK(launch_reduce_slabs(slabs, grads + p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0, sd));
   { M2TProfScope ps(M2T_PROF_FINAL_DGRAD, st); CK(launch_final_conv_dgrad(dt, gpre, params + p->poff.at(wl), last_pre, g_last, B, p->Hsp, p->Wsp, st)); }
   if (s == 4) {
     // tail.3: u = gelu(t1pre) W3^T + b3, shuffled into t2pre
+    fork();
     m2t_wgrad_args wa{};
     wa.G = WSP("g_t2pre"); wa.gmode = M2T_A_UNSHUF; wa.X = WSP("t1pre"); wa.ldx = 64; wa.xmode = M2T_A_GELU;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP * 4; wa.N = 256; wa.K = 64; wa.H = 2 * H; wa.Wd = 2 * W; wa.r = 2; wa.C = 64;
-    { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, st); CK(launch_wgrad_tn(dt, wa, &ns, st)); }
-    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64, st));
+    { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
+    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64, sd));
     // bias gradient rode along in the wgrad kernel (shuffled column order -> torch order)
-    CK(launch_reduce_slabs(colp, grads + p->poff.at("tail.3.bias"), ns, 256, 2, 64, 4, 1, st));
+    CK(launch_reduce_slabs(colp, grads + p->poff.at("tail.3.bias"), ns, 256, 2, 64, 4, 1, sd));
     m2t_gemm_args ga{};
     ga.A = WSP("g_t2pre"); ga.W = packed_ptr(p, workspace, "t3T"); ga.Y = WSP("g_t1pre"); ga.ldy = 64;
     ga.aux = WSP("t1pre"); ga.ldaux = 64; ga.M = BP * 4; ga.N = 64; ga.K = 256;
@@ -400,12 +445,13 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   void* Y = WSP("X" + std::to_string(p->nb));
   {
     const int N0 = 64 * r0 * r0;
+    fork();
     m2t_wgrad_args wa{};
     wa.G = WSP("g_t1pre"); wa.gmode = M2T_A_UNSHUF; wa.X = Y; wa.ldx = 64; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = N0; wa.K = 64; wa.H = H; wa.Wd = W; wa.r = r0; wa.C = 64;
-    { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, st); CK(launch_wgrad_tn(dt, wa, &ns, st)); }
-    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.0.weight"), ns, (long long)N0 * 64, 2, 64, r0 * r0, 64, st));
-    CK(launch_reduce_slabs(colp, grads + p->poff.at("tail.0.bias"), ns, N0, 2, 64, r0 * r0, 1, st));
+    { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
+    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.0.weight"), ns, (long long)N0 * 64, 2, 64, r0 * r0, 64, sd));
+    CK(launch_reduce_slabs(colp, grads + p->poff.at("tail.0.bias"), ns, N0, 2, 64, r0 * r0, 1, sd));
     m2t_gemm_args ga{};
     ga.A = WSP("g_t1pre"); ga.W = packed_ptr(p, workspace, "t0T"); ga.Y = WSP("gT"); ga.ldy = 64;
     ga.M = BP; ga.N = 64; ga.K = N0; ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
@@ -414,6 +460,11 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   // ---- body, last block first.  gy = gradient of X[b+1] ----
   void* gy = WSP("gT");
   void* gnext[2] = {WSP("gA"), WSP("gB")};
+  void* gqkv_buf[2] = {WSP("gqkv0"), WSP("gqkv1")};
+  float* relw_buf[2] = {(float*)WSP("relw0"), (float*)WSP("relw1")};
+  hipEvent_t branch_done[2] = {nullptr, nullptr};
+  hipEvent_t conv_done_prev = nullptr;      // side finished reading gy of the previously processed block
+  int counter = 0;
   for (int b = p->nb - 1; b >= 0; --b) {
     const std::string k = "b" + std::to_string(b) + ".";
     const std::string pre = "body." + std::to_string(b) + ".";
@@ -423,10 +474,12 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     void* xc = WSP(k + "xc");
     void* gxc = WSP("gxc");
     void* gn = WSP("gn");
-    // feed_forward conv: weight / bias / data gradients
-    { M2TProfScope ps(M2T_PROF_CONV3_WGRAD, st); CK(launch_conv3x3_c64_wgrad(dt, xc, gy, slabs, &ns, B, H, W, st)); }
-    CK(launch_reduce_slabs(slabs, grads + p->poff.at(pre + "feed_forward.0.weight"), ns, 9 * 64 * 64, 1, 64, 64, 0, st));
-    CK(launch_colsum(dt, gy, 64, BP, 64, colp, 256, grads + p->poff.at(pre + "feed_forward.0.bias"), 0, st));
+    // feed_forward conv: weight / bias gradients on the side stream, data gradient on the main one
+    fork();
+    { M2TProfScope ps(M2T_PROF_CONV3_WGRAD, sd); CK(launch_conv3x3_c64_wgrad(dt, xc, gy, slabs, &ns, B, H, W, sd)); }
+    CK(launch_reduce_slabs(slabs, grads + p->poff.at(pre + "feed_forward.0.weight"), ns, 9 * 64 * 64, 1, 64, 64, 0, sd));
+    CK(launch_colsum(dt, gy, 64, BP, 64, colp, 256, grads + p->poff.at(pre + "feed_forward.0.bias"), 0, sd));
+    hipEvent_t conv_done = side_marker();
     { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st)); }
     for (int i = 3; i >= 0; --i) {
       const int C = BR_C[i], L = BR_L[i];
@@ -437,36 +490,52 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       const void* qkv = WSP(k + "qkv" + std::to_string(i + 1));
       const float* rh = params + p->poff.at(an + "rel_h");
       const float* rw = params + p->poff.at(an + "rel_w");
-      float* grh = grads + p->poff.at(an + "rel_h");
-      float* grw = grads + p->poff.at(an + "rel_w");
+      const int bi = (counter++) & 1;
+      void* gqkv = gqkv_buf[bi];
+      float* relw = relw_buf[bi];
+      main_wait(branch_done[bi]);            // side consumers of this gqkv / relw buffer (two branches ago) are done
       if (i == 0) {
-        CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 0, WSP("gqkv"), WSP("win"), (float*)WSP("relw"), (float*)WSP("rel_part"), grh, grw, B, h, w, C, st));
+        CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 0, gqkv, WSP("win"), relw, B, h, w, C, st));
       } else {
         CK(launch_branch_post_bwd(dt, L, gxc, i, WSP("ga"), B, H, W, st));
-        CK(launch_window_attn_bwd(dt, qkv, rh, rw, WSP("ga"), C, 0, WSP("gqkv"), WSP("win"), (float*)WSP("relw"), (float*)WSP("rel_part"), grh, grw, B, h, w, C, st));
+        CK(launch_window_attn_bwd(dt, qkv, rh, rw, WSP("ga"), C, 0, gqkv, WSP("win"), relw, B, h, w, C, st));
       }
+      fork();
       m2t_wgrad_args wa{};
-      wa.G = WSP("gqkv"); wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = d; wa.ldx = C; wa.xmode = M2T_A_PLAIN;
+      wa.G = gqkv; wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = d; wa.ldx = C; wa.xmode = M2T_A_PLAIN;
       wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = 1; wa.Wd = 1; wa.r = 1; wa.C = 64;
-      { M2TProfScope ps(M2T_PROF_WGRAD_QKV, st); CK(launch_wgrad_tn(dt, wa, &ns, st)); }
-      CK(launch_reduce_slabs(slabs, grads + p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0, st));
+      { M2TProfScope ps(M2T_PROF_WGRAD_QKV, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
+      CK(launch_reduce_slabs(slabs, grads + p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0, sd));
+      CK(launch_rel_reduce(relw, relp, grads + p->poff.at(an + "rel_h"), grads + p->poff.at(an + "rel_w"), (int)(M / 64), C, sd));
+      branch_done[bi] = side_marker();
       m2t_gemm_args ga{};
-      ga.A = WSP("gqkv"); ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
+      ga.A = gqkv; ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
       ga.Y = WSP("gd"); ga.ldy = C; ga.M = M; ga.N = C; ga.K = 3 * C; ga.H = 1; ga.Wd = 1; ga.r = 1; ga.C = 64;
       { M2TProfScope ps(M2T_PROF_GEMM_QKV_DGRAD, st); CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st)); }
       CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st));
     }
     void* gx = gnext[b & 1];
+    // gx's buffer was the gy of block b+1: its conv-wgrad / colsum on the side stream must be done
+    main_wait(conv_done_prev);
     CK(launch_instnorm_bwd(dt, gn, X, mean, rstd, gy, gx, (float*)WSP("norm_part"), (float*)WSP("norm_s"), B, (int)p->P, st));
+    conv_done_prev = conv_done;
     gy = gx;
   }
   // head: g(res) = g(X0) from the chain + g(Y) from `res + x`
   CK(launch_add(dt, gy, WSP("gT"), WSP("gxc"), BP * 64, st));
-  CK(launch_head_conv_wgrad(dt, x, WSP("gxc"), slabs, &ns, B, p->H0, p->W0, H, W, st));
-  CK(launch_reduce_slabs(slabs, grads + p->poff.at("head.weight"), ns, 64 * 27, 0, 0, 0, 0, st));
-  CK(launch_colsum(dt, WSP("gxc"), 64, BP, 64, colp, 256, grads + p->poff.at("head.bias"), 0, st));
+  fork();
+  CK(launch_head_conv_wgrad(dt, x, WSP("gxc"), slabs, &ns, B, p->H0, p->W0, H, W, sd));
+  CK(launch_reduce_slabs(slabs, grads + p->poff.at("head.weight"), ns, 64 * 27, 0, 0, 0, 0, sd));
+  CK(launch_colsum(dt, WSP("gxc"), 64, BP, 64, colp, 256, grads + p->poff.at("head.bias"), 0, sd));
+  main_wait(side_marker());          // join: every gradient is complete in main-stream order
   p->have_seed = false;
   return 0;
+}
+
+extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
+  if (!p || !key) return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: null");
+  if (std::string(key) == "side_stream") { p->use_side = (value != 0); return 0; }
+  return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");
 }
 
 extern "C" int m2t_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
@@ -513,6 +582,9 @@ extern "C" int m2t_window_attention_bwd(int dtype, const void* qkv, const float*
   const size_t nwin = (size_t)B * (h / 8) * (w / 8);
   const size_t woff = (nwin * 100 * 2 * C * es + 255) & ~(size_t)255;
   const size_t roff = woff + ((nwin * 10 * C * 4 + 255) & ~(size_t)255);
-  return launch_window_attn_bwd(dtype, qkv, rel_h, rel_w, gout, C, 0, gqkv, scratch, (float*)((char*)scratch + woff),
-                                (float*)((char*)scratch + roff), grel_h, grel_w, B, h, w, C, (hipStream_t)stream);
+  int rc = launch_window_attn_bwd(dtype, qkv, rel_h, rel_w, gout, C, 0, gqkv, scratch, (float*)((char*)scratch + woff),
+                                  B, h, w, C, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_rel_reduce((float*)((char*)scratch + woff), (float*)((char*)scratch + roff), grel_h, grel_w, (int)nwin, C,
+                           (hipStream_t)stream);
 }

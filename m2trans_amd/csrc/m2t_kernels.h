@@ -105,5 +105,6 @@ int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const fl
 // gout [B][h][w][ldg] (channels gc0..gc0+C) -> gqkv [B][h][w][3C]; per-window dK/dV scratch `win` [B*L][100][2C] (T);
 // rel-pos gradient slabs
 int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
-                           int gc0, void* gqkv, void* win, float* relw, float* rel_part, float* grel_h, float* grel_w,
-                           int B, int h, int w, int C, hipStream_t st);
+                           int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st);
+// relw [nwin][10][C] per-window partials -> grel_h / grel_w (torch layouts)
+int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st);
