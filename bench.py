@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--all-kernel-events", action="store_true", help="time every kernel category in the timed region (adds ~8%% overhead)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the whole backward on one stream")
+    ap.add_argument("--semantic-loss", action="store_true",
+                    help="BASELINE configs[2]: add the MedCLIP(Swin-T) image-text regulariser (random-init tower, hash text features)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=2)
     return ap.parse_args()
 
@@ -122,8 +124,23 @@ def main():
     margs = types.SimpleNamespace(n_feats=64, scale=args.scale, rgb_range=1.0, n_blocks=8, colors=3,
                                   compute_dtype=args.dtype)
     model = create_model(margs).to(device)
-    ts = TrainStep(model, lr=1e-4, lambda_l1=1.0, process_group=pg, world_size=world)
+    sem, captions = None, None
     B = args.batch
+    if args.semantic_loss:
+        from m2trans_amd.losses import SemanticLoss
+        sem = SemanticLoss(criterion="l1", N_patches=3, device=device, compute_dtype=args.dtype, max_batch=B)
+        enc = sem._enc = None
+        from m2trans_amd.losses import SwinEncoder
+        e = SwinEncoder(2 * B, _lib.F32 if args.dtype == "fp32" else _lib.BF16, device)
+        g = torch.Generator().manual_seed(33)
+        state = {n: (torch.randn(k, generator=g) * (0.02 if "weight" in n and "norm" not in n else 0.0)
+                     + (1.0 if n.endswith("norm.weight") or ("layernorm" in n and n.endswith("weight")) else 0.0))
+                 for n, (o, k) in e.slots.items()}
+        del e
+        sem.load_image_encoder(state)
+        captions = [f"synthetic ultrasound caption {i}" for i in range(B)]
+    ts = TrainStep(model, lr=1e-4, lambda_l1=1.0, process_group=pg, world_size=world,
+                   semantic_loss=sem, lambda_clip=0.01 if sem is not None else 0.0)
     batches = [synthetic_batch(B, args.lr_size, args.scale, rank, s, device) for s in range(2)]
     if args.no_side_stream:
         plan = model._plan_for(batches[0][0])
@@ -134,7 +151,7 @@ def main():
     for s in range(args.warmup):
         if rank == 0 and not args.no_kernel_events and s == args.warmup - 1:
             m2t_profile.enable()      # last warm-up step: time every category to find the dominant kernel
-        ts.step(*batches[s % 2])
+        ts.step(*batches[s % 2], captions)
     torch.cuda.synchronize()
     if rank == 0 and not args.no_kernel_events and args.warmup > 0:
         tt = m2t_profile.read_all()
@@ -149,7 +166,7 @@ def main():
         m2t_profile.enable(m2t_profile.ALL_MASK if args.all_kernel_events else (dominant_mask or m2t_profile.ALL_MASK))
     t0 = time.perf_counter()
     for s in range(args.steps):
-        ts.step(*batches[s % 2])
+        ts.step(*batches[s % 2], captions)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -181,7 +198,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic U[0,1) LR/HR patches resident in HBM, seed-33 reference init",
             "config": {"workload": f"x{args.scale} SR train step (fwd + L1 + bwd + Adam), {args.lr_size}x{args.lr_size} LR "
-                                   f"patches, batch {B}/GPU, L1 loss only (BASELINE configs[1])",
+                                   f"patches, batch {B}/GPU, " + ("L1 + MedCLIP(Swin-T) regulariser (BASELINE configs[2])" if args.semantic_loss else "L1 loss only (BASELINE configs[1])"),
                        "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
             "roofline": roofline,
         }

@@ -106,6 +106,31 @@ int m2t_window_attention_bwd(int dtype, const void* qkv, const float* rel_h, con
                              void* gqkv, float* grel_h, float* grel_w, void* scratch, int B, int h, int w, int C,
                              void* stream);
 
+/* ---- SemanticLoss (losses.py:18-81): MedCLIP image tower = Swin-T 224 forward + the loss value ----
+ * Forward only: the reference evaluates it under torch.no_grad() (losses.py:63), so it contributes a
+ * constant to the logged loss and no gradient.  Weights: ONE flat float32 buffer in the order reported
+ * by m2t_swin_param_name() (HF swin-tiny checkpoint names of transformers 4.24 + "projection_head.weight"
+ * [512,768], the MedCLIP vision projection). */
+typedef struct m2t_swin m2t_swin;
+int m2t_swin_create(m2t_swin** out, int max_images, int dtype);
+void m2t_swin_destroy(m2t_swin* p);
+/* "workspace_bytes", "num_params", "num_param_tensors", "param:<name>", "numel:<name>" */
+long long m2t_swin_query(const m2t_swin* p, const char* key);
+const char* m2t_swin_param_name(const m2t_swin* p, int index);
+/* once per weight set: converts / fuses the frozen weights into the workspace */
+int m2t_swin_load_weights(m2t_swin* p, const float* weights, void* workspace, void* stream);
+/* medmodel.encode_image on n 224x224 crops (createNRandompatches, losses.py:29-40):
+ * src [n_src,3,Hs,Ws] float32 NCHW on the device, crops_host int[n][3] = (source index, row0, col0)
+ * -> emb [n,512] float32, unit L2 norm. */
+int m2t_swin_encode(m2t_swin* p, const float* src, int n_src, int Hs, int Ws, const int* crops_host, int n,
+                    float* emb, void* workspace, void* stream);
+/* losses.py:71-79 for a batch: emb [2B,512] (SR embeddings then HR embeddings), text [B,512] (any norm)
+ * -> per_sample[B] = |sr.t - hr.t| / n_patches, total[1] = their sum. */
+int m2t_semantic_loss(const float* emb, const float* text, int B, int n_patches, float* per_sample, float* total,
+                      void* stream);
+/* F.interpolate(mode='bicubic', align_corners=True) (losses.py:53-54): src [NC,Hin,Win] -> dst [NC,Hout,Wout]. */
+int m2t_bicubic_resize(const float* src, float* dst, int NC, int Hin, int Win, int Hout, int Wout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,14 @@ SIGNATURES = {
     "m2t_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f, _vp]),
     "m2t_profile_enable": (_i, [C.c_ulonglong]),
     "m2t_profile_read": (_i, [_i, C.POINTER(_d), C.POINTER(_ll)]),
+    "m2t_swin_create": (_i, [C.POINTER(_vp), _i, _i]),
+    "m2t_swin_destroy": (None, [_vp]),
+    "m2t_swin_query": (_ll, [_vp, C.c_char_p]),
+    "m2t_swin_param_name": (C.c_char_p, [_vp, _i]),
+    "m2t_swin_load_weights": (_i, [_vp, _vp, _vp, _vp]),
+    "m2t_swin_encode": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i), _i, _vp, _vp, _vp]),
+    "m2t_semantic_loss": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "m2t_bicubic_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "m2t_dwt": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "m2t_iwt": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "m2t_pixel_shuffle": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

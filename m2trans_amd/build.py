@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libm2t.so")
-SOURCES = ["k_pointwise.hip", "k_gemm.hip", "k_conv.hip", "k_attn.hip", "m2t_api.hip"]
+SOURCES = ["k_pointwise.hip", "k_gemm.hip", "k_conv.hip", "k_attn.hip", "k_swin.hip", "m2t_api.hip", "m2t_swin.hip"]
 HEADERS = ["m2t_common.h", "m2t_kernels.h", "m2t_gemm_load.h", os.path.join("..", "..", "include", "m2t.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-ffp-contract=off"]
@@ -57,7 +57,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose and r.stderr.strip():
             print(r.stderr)
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):

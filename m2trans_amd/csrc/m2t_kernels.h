@@ -59,7 +59,7 @@ int launch_layout(int dt, const float* nchw, void* nhwc, float* nchw_out, int B,
 // ---- k_gemm.hip -------------------------------------------------------------------------
 // Y[M][N] = A[M][K] * W[N][K]^T  with A-side and epilogue variants
 enum m2t_gemm_a { M2T_A_PLAIN = 0, M2T_A_GELU = 1, M2T_A_UNSHUF = 2 };
-enum m2t_gemm_epi { M2T_E_PLAIN = 0, M2T_E_BIAS = 1, M2T_E_BIAS_SHUF = 2, M2T_E_GELU_GRAD = 3 };
+enum m2t_gemm_epi { M2T_E_PLAIN = 0, M2T_E_BIAS = 1, M2T_E_BIAS_SHUF = 2, M2T_E_GELU_GRAD = 3, M2T_E_BIAS_GELU = 4, M2T_E_BIAS_RESID = 5 };
 struct m2t_gemm_args {
   const void* A; int lda;       // A rows (or, UNSHUF: the [B][H*r][W*r][C] tensor)
   const void* W;                // [N][K] element type T
@@ -108,3 +108,14 @@ int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const fl
                            int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st);
 // relw [nwin][10][C] per-window partials -> grel_h / grel_w (torch layouts)
 int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st);
+
+// ---- k_swin.hip (MedCLIP image tower = Swin-T forward, losses.py:68-69) --------------------
+int launch_swin_patchify(int dt, const float* src, int Hs, int Ws, const int* crops, int n, void* out, hipStream_t st);
+int launch_layernorm(int dt, const void* x, const float* gamma, const float* beta, void* y, long long M, int C, hipStream_t st);
+int launch_swin_attn(int dt, const void* qkv, const float* bias_table, void* out, int nimg, int H, int W, int C, int heads,
+                     int shift, hipStream_t st);
+int launch_swin_merge_gather(int dt, const void* x, void* y, int nimg, int H, int W, int C, hipStream_t st);
+int launch_swin_head(int dt, const void* x, const float* proj, float* emb, int nimg, hipStream_t st);
+int launch_semantic_loss(const float* emb, const float* text, int B, int n_patches, float* per_sample, float* total, hipStream_t st);
+int launch_bicubic_resize(const float* src, float* dst, int NC, int Hin, int Win, int Hout, int Wout, hipStream_t st);
+int launch_convert(int dt, const float* src, void* dst, long long n, hipStream_t st);

@@ -35,12 +35,16 @@ def cosine_lr(epoch: int, lr0: float = 1e-4, eta_min: float = 1e-6, t_max: float
 class TrainStep:
     def __init__(self, model: M2Trans, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  lambda_l1: float = 1.0, process_group=None, world_size: Optional[int] = None,
-                 grad_bucket_dtype: torch.dtype = torch.float32):
+                 grad_bucket_dtype: torch.dtype = torch.float32, semantic_loss=None, lambda_clip: float = 0.0):
         self.model = model
         self.lr = float(lr)
         self.betas = (float(betas[0]), float(betas[1]))
         self.eps = float(eps)
         self.lambda_l1 = float(lambda_l1)
+        # the MedCLIP regulariser (train.py:78,203-205): a no-grad constant added to the logged loss
+        self.semantic_loss = semantic_loss
+        self.lambda_clip = float(lambda_clip)
+        self.clip_loss = None
         self.pg = process_group
         if world_size is None:
             world_size = torch.distributed.get_world_size(process_group) if (
@@ -53,16 +57,17 @@ class TrainStep:
         self.grads = model.attach_flat_grads()
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.l1_loss = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.loss = self.l1_loss
         self.bucket = GradBucket(self.grads, process_group, grad_bucket_dtype) if self.world_size > 1 else None
 
     def set_lr(self, lr: float):
         self.lr = float(lr)
 
     # -- pieces (also used by tests) -------------------------------------------------------
-    def forward_backward(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
-        """forward + L1 + backward into model.flat_grads; returns the device loss tensor
-        (this rank's share of the global mean)."""
+    def forward_backward(self, lr_img: torch.Tensor, hr_img: torch.Tensor, captions=None) -> torch.Tensor:
+        """forward + L1 (+ the constant SemanticLoss term) + backward into model.flat_grads; returns the
+        device loss tensor (this rank's share of the global mean)."""
         m = self.model
         lib = _lib.load()
         plan = m._plan_for(lr_img)
@@ -72,16 +77,24 @@ class TrainStep:
         if tuple(hr_img.shape) != (B, 3, lr_img.shape[2] * m.scale, lr_img.shape[3] * m.scale):
             raise _lib.M2TError("hr shape must be [B,3,H*scale,W*scale]")
         divisor = global_divisor(hr_img.numel(), self.world_size)      # global mean (equal shards)
+        use_clip = self.semantic_loss is not None and self.lambda_clip > 0 and captions is not None
+        sr = torch.empty_like(hr_img) if use_clip else None
         plan.gen += 1
         with torch.cuda.device(lr_img.device):
             st = _lib.stream_ptr()
             ws = _lib.ptr(plan.workspace)
-            _lib.check(lib.m2t_forward(plan.handle, _lib.ptr(m.flat_params), _lib.ptr(lr_img), None,
+            _lib.check(lib.m2t_forward(plan.handle, _lib.ptr(m.flat_params), _lib.ptr(lr_img), _lib.ptr(sr),
                                        float(m.rgb_range), 1, ws, st), "m2t_forward")
             _lib.check(lib.m2t_l1_loss(plan.handle, _lib.ptr(hr_img), self.lambda_l1, divisor, float(m.rgb_range),
-                                       _lib.ptr(self.loss), ws, st), "m2t_l1_loss")
+                                       _lib.ptr(self.l1_loss), ws, st), "m2t_l1_loss")
             _lib.check(lib.m2t_backward(plan.handle, _lib.ptr(m.flat_params), _lib.ptr(lr_img), _lib.ptr(self.grads),
                                         ws, st), "m2t_backward")
+        if use_clip:
+            # clip_loss += loss_clip(sr[i], hr[i], caption_i) * lambda_clip  (train.py:203-205); no gradient
+            self.clip_loss = self.semantic_loss.batch(sr, hr_img, captions) * self.lambda_clip
+            self.loss = self.l1_loss + self.clip_loss
+        else:
+            self.loss = self.l1_loss
         return self.loss
 
     def all_reduce_grads(self):
@@ -98,8 +111,8 @@ class TrainStep:
                        "m2t_adam_step")
 
     # -- the step ----------------------------------------------------------------------------
-    def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor) -> torch.Tensor:
-        loss = self.forward_backward(lr_img, hr_img)
+    def step(self, lr_img: torch.Tensor, hr_img: torch.Tensor, captions=None) -> torch.Tensor:
+        loss = self.forward_backward(lr_img, hr_img, captions)
         self.all_reduce_grads()
         self.optimizer_step()
         return loss
