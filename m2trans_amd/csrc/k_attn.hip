@@ -13,6 +13,7 @@
 //   * large C is processed in 64-channel chunks so the same code serves C = 16, 64, 256 in
 //     fp32 and bf16 inside 160 KB of LDS.
 #include "m2t_kernels.h"
+#include "m2t_haar.h"
 
 #define WA_NK 100
 #define WA_KT 7          // key tiles that can hold real keys (112)
@@ -43,28 +44,45 @@ __device__ __forceinline__ WinGeom make_geom(int h, int w) {
   return g;
 }
 
+// All stagers issue EVERY global load of the tile first (fully unrolled, registers) and only then
+// touch LDS: one exposed memory latency per tile instead of one per 256-thread sweep.
+//
 // stage the K^ chunk row-major: 128 key rows x CW channels; real keys get k + rel-pos
 // (zero-padded phantom keys = rel-pos alone), rows >= 100 and channels >= CC are zero
 template <typename T, int C, int CC, int CW>
 __device__ __forceinline__ void stage_khat(T (*Ks)[CW + 8], const T* __restrict__ qkv, const float* __restrict__ rel_h,
                                            const float* __restrict__ rel_w, const WinGeom& gm, int c0, int tid) {
   constexpr int VEC = CW / 8;
-  for (int idx = tid; idx < WA_KR * VEC; idx += 256) {
+  constexpr int ITEMS = WA_KR * VEC / 256;
+  Frag8<T> kf[ITEMS];
+  f32x4 r0[ITEMS], r1[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * 256;
     const int cv = idx % VEC, key = idx / VEC;
     const int c = cv * 8;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    kf[it] = frag_zero<T>();
+    r0[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    r1[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (key < WA_NK && c < CC) {
       long long pix;
-      if (gm.key_pixel(key, pix)) load8f(qkv + pix * (3 * C) + C + c0 + c, v);
+      if (gm.key_pixel(key, pix)) kf[it] = load8(qkv + pix * (3 * C) + C + c0 + c);
       const int kr = key / 10, kc = key - kr * 10;
       const int cc = c0 + c;
+      // parameter tensors start on 64-byte boundaries of the flat buffer and cc is a multiple of 8
       const float* rp = (cc < C / 2) ? (rel_h + kr * (C / 2) + cc) : (rel_w + kc * (C / 2) + (cc - C / 2));
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += rp[e];
+      r0[it] = *reinterpret_cast<const f32x4*>(rp);
+      r1[it] = *reinterpret_cast<const f32x4*>(rp + 4);
     }
-    store8f(&Ks[key][c], v);
+  }
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * 256;
+    const int cv = idx % VEC, key = idx / VEC;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = kf[it].get(e) + r0[it][e]; v[4 + e] = kf[it].get(4 + e) + r1[it][e]; }
+    store8f(&Ks[key][cv * 8], v);
   }
 }
 // stage a row-major chunk of 128 key rows x CW channels from channel offset `coff` of qkv (V), zero outside
@@ -72,13 +90,21 @@ template <typename T, int C, int CC, int CW>
 __device__ __forceinline__ void stage_keys_rows(T (*Vs)[CW + 8], const T* __restrict__ qkv, int coff, const WinGeom& gm,
                                                 int c0, int tid) {
   constexpr int VEC = CW / 8;
-  for (int idx = tid; idx < WA_KR * VEC; idx += 256) {
+  constexpr int ITEMS = WA_KR * VEC / 256;
+  Frag8<T> f[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * 256;
     const int cv = idx % VEC, key = idx / VEC;
     const int c = cv * 8;
-    Frag8<T> f = frag_zero<T>();
+    f[it] = frag_zero<T>();
     long long pix;
-    if (key < WA_NK && c < CC && gm.key_pixel(key, pix)) f = load8(qkv + pix * (3 * C) + coff + c0 + c);
-    store8(&Vs[key][c], f);
+    if (key < WA_NK && c < CC && gm.key_pixel(key, pix)) f[it] = load8(qkv + pix * (3 * C) + coff + c0 + c);
+  }
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * 256;
+    store8(&Vs[idx / VEC][(idx % VEC) * 8], f[it]);
   }
 }
 // stage a row-major chunk of the 64 query rows x CW channels: dst[q][c] = src[query pixel][coff + c0 + c]
@@ -86,21 +112,33 @@ template <typename T, int CC, int CW>
 __device__ __forceinline__ void stage_query_rows(T (*dst)[CW + 8], const T* __restrict__ src, int ld, int coff,
                                                  const WinGeom& gm, int c0, int tid) {
   constexpr int VEC = CW / 8;
-  for (int idx = tid; idx < 64 * VEC; idx += 256) {
+  constexpr int ITEMS = (64 * VEC + 255) / 256;
+  Frag8<T> f[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * 256;
     const int cv = idx % VEC, q = idx / VEC;
-    Frag8<T> f = frag_zero<T>();
-    if (cv * 8 < CC) f = load8(src + gm.query_pixel(q) * ld + coff + c0 + cv * 8);
-    store8(&dst[q][cv * 8], f);
+    f[it] = frag_zero<T>();
+    if (idx < 64 * VEC && cv * 8 < CC) f[it] = load8(src + gm.query_pixel(q) * ld + coff + c0 + cv * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * 256;
+    if (idx < 64 * VEC) store8(&dst[idx / VEC][(idx % VEC) * 8], f[it]);
   }
 }
 
 // =======================================================================================
 // forward
 // =======================================================================================
-template <typename T, int C>
+// L = 0: out[q pixel][oc0 + c] = O (+ res).  L = 1, 2 (C = 16 * 4^L): the branch epilogue is fused in --
+// xc[full-res pixels][oc0 + 0..15] = IWT^L(O) + xin  (models/M2Trans_network.py:145,153,161): a lane holds, for its
+// query, every band of 4 consecutive base channels, so the inverse Haar butterflies are register-local.
+template <typename T, int C, int L>
 __global__ void __launch_bounds__(256) window_attn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rel_h,
                                                               const float* __restrict__ rel_w, T* __restrict__ out, int ldo,
                                                               int oc0, const T* __restrict__ res, int ldr, int h, int w) {
+  static_assert(L == 0 || C == (16 << (2 * L)), "fused IWT needs C = 16 * 4^L");
   constexpr int CC = (C < 64) ? C : 64;       // channels per chunk
   constexpr int CW = (CC < 32) ? 32 : CC;     // staged width (MFMA k-chunk is 32)
   constexpr int NCH = C / CC;
@@ -171,13 +209,11 @@ __global__ void __launch_bounds__(256) window_attn_fwd_kernel(const T* __restric
     }
 
   // ---- O^T = V^T P^T, one channel chunk at a time; V^T fragments by transposing LDS reads ----
-#pragma unroll 1
-  for (int ch = 0; ch < NCH; ++ch) {
+  auto pv_chunk = [&](int ch, f32x4 (&o)[NT]) {
     const int c0 = ch * CC;
     __syncthreads();
     stage_keys_rows<T, C, CC, CW>(Ks, qkv, 2 * C, gm, c0, tid);
     __syncthreads();
-    f32x4 o[NT];
 #pragma unroll
     for (int mt = 0; mt < NT; ++mt) o[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -187,35 +223,71 @@ __global__ void __launch_bounds__(256) window_attn_fwd_kernel(const T* __restric
         const Frag8<T> vf = load8_tr(&Ks[32 * c4 + 4 * g][16 * mt], &Ks[32 * c4 + 16 + 4 * g][16 * mt], LD, lane);
         mma16(o[mt], vf, pf[c4]);
       }
-    // lane (q, g) holds channels c0 + 16 mt + 4 g + r
+  };
+  if constexpr (L == 0) {
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      f32x4 o[NT];
+      pv_chunk(ch, o);
+      // lane (q, g) holds channels c0 + 16 mt + 4 g + r
 #pragma unroll
-    for (int mt = 0; mt < NT; ++mt) {
-      float v[4] = {o[mt][0], o[mt][1], o[mt][2], o[mt][3]};
-      const int cc = c0 + 16 * mt + 4 * g;
-      if (res) {
-        float p[4];
-        load4(res + qpix * ldr + cc, p);
+      for (int mt = 0; mt < NT; ++mt) {
+        float v[4] = {o[mt][0], o[mt][1], o[mt][2], o[mt][3]};
+        const int cc = ch * CC + 16 * mt + 4 * g;
+        if (res) {
+          float p[4];
+          load4(res + qpix * ldr + cc, p);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += p[e];
+          for (int e = 0; e < 4; ++e) v[e] += p[e];
+        }
+        store4(out + qpix * ldo + oc0 + cc, v);
       }
-      store4(out + qpix * ldo + oc0 + cc, v);
     }
+  } else {
+    constexpr int S = Haar<L>::S, NB = Haar<L>::N;
+    f32x4 oall[NCH][NT];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) pv_chunk(ch, oall[ch]);
+    // channel = (ch * 4 + mt) * 16 + 4 g + r  =  band * 16 + base channel (band-major nesting of repeated DWTs)
+    float vv[4][S][S];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float bands[NB];
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int mt = 0; mt < NT; ++mt) bands[ch * NT + mt] = oall[ch][mt][r];
+      Haar<L>::inv(bands, vv[r]);
+    }
+    const int H = h * S, W = w * S;
+    const int by = 8 * gm.wy + (q >> 3), bx = 8 * gm.wx + (q & 7);
+#pragma unroll
+    for (int y = 0; y < S; ++y)
+#pragma unroll
+      for (int x = 0; x < S; ++x) {
+        const long long pix = ((long long)gm.b * H + S * by + y) * W + S * bx + x;
+        float p[4];
+        load4(res + pix * ldr + 4 * g, p);
+        float v[4] = {vv[0][y][x] + p[0], vv[1][y][x] + p[1], vv[2][y][x] + p[2], vv[3][y][x] + p[3]};
+        store4(out + pix * ldo + oc0 + 4 * g, v);
+      }
   }
 }
 
 int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0,
-                           const void* res, int ldr, int B, int h, int w, int C, hipStream_t st) {
+                           const void* res, int ldr, int B, int h, int w, int C, hipStream_t st, int post_levels) {
   if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn: h,w must be multiples of 8");
+  if (post_levels != 0 && !(res && ((post_levels == 1 && C == 64) || (post_levels == 2 && C == 256))))
+    return m2t_set_error(-2, "window_attn: fused IWT epilogue needs (levels, C) = (1, 64) or (2, 256) and the residual");
   const int nwin = B * (h / 8) * (w / 8);
   M2TProfScope ps(C == 16 ? M2T_PROF_ATTN_FWD_16 : (C == 64 ? M2T_PROF_ATTN_FWD_64 : M2T_PROF_ATTN_FWD_256), st);
-#define GO(T_, C_) hipLaunchKernelGGL((window_attn_fwd_kernel<T_, C_>), dim3(nwin), dim3(256), 0, st, (const T_*)qkv, rel_h, rel_w, (T_*)out, ldo, oc0, (const T_*)res, ldr, h, w)
-  if (dt == M2T_F32) {
-    if (C == 16) GO(float, 16); else if (C == 64) GO(float, 64); else if (C == 256) GO(float, 256);
-    else return m2t_set_error(-2, "window_attn: C must be 16, 64 or 256");
-  } else {
-    if (C == 16) GO(bf16_t, 16); else if (C == 64) GO(bf16_t, 64); else if (C == 256) GO(bf16_t, 256);
-    else return m2t_set_error(-2, "window_attn: C must be 16, 64 or 256");
-  }
+#define GO(T_, C_, L_) hipLaunchKernelGGL((window_attn_fwd_kernel<T_, C_, L_>), dim3(nwin), dim3(256), 0, st, (const T_*)qkv, rel_h, rel_w, (T_*)out, ldo, oc0, (const T_*)res, ldr, h, w)
+#define GOT(T_)                                                                                   \
+  if (post_levels == 1) GO(T_, 64, 1); else if (post_levels == 2) GO(T_, 256, 2);                   \
+  else if (C == 16) GO(T_, 16, 0); else if (C == 64) GO(T_, 64, 0); else if (C == 256) GO(T_, 256, 0); \
+  else return m2t_set_error(-2, "window_attn: C must be 16, 64 or 256");
+  if (dt == M2T_F32) { GOT(float) } else { GOT(bf16_t) }
+#undef GOT
 #undef GO
   M2T_LAUNCH_CHECK();
   return 0;
@@ -230,7 +302,70 @@ int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const fl
 // The relative-position gradient of the window (dK^ summed over key columns / rows, phantom
 // keys included) is reduced from the fp32 accumulators and written to relw [B*L][10][C].
 // =======================================================================================
-template <typename T, int C>
+// one band of a 2x2 Haar butterfly (same association order as haar2_fwd)
+__device__ __forceinline__ float haar2_fwd_band(float a, float b, float c, float d, int band) {
+  switch (band) {
+    case 0: return 0.5f * (((a + b) + c) + d);
+    case 1: return 0.5f * (((-a - b) + c) + d);
+    case 2: return 0.5f * (((-a + b) - c) + d);
+    default: return 0.5f * (((a - b) - c) + d);
+  }
+}
+// stage the 64 query rows x CW channels of the OUTPUT gradient chunk `ch` (row-major [q][c]).
+// L = 0: plain rows of go.  L = 1, 2: go is the full-res g_xc tensor (ld, channel offset coff); the
+// branch's gradient is DWT^L of its 16-channel slice (IWT^T = DWT), computed on load: thread (q, 4-channel
+// group) reads its (2^L)^2 pixel block and writes the bands that fall into this 64-channel chunk.
+template <typename T, int L, int CC, int CW>
+__device__ __forceinline__ void stage_go_rows(T (*dst)[CW + 8], const T* __restrict__ go, int ld, int coff, const WinGeom& gm,
+                                              int ch, int tid) {
+  if constexpr (L == 0) {
+    stage_query_rows<T, CC, CW>(dst, go, ld, coff, gm, ch * CC, tid);
+  } else {
+    constexpr int S = Haar<L>::S;
+    const int q = tid >> 2, cg = tid & 3;
+    const int H = gm.h * S, W = gm.w * S;
+    const int by = 8 * gm.wy + (q >> 3), bx = 8 * gm.wx + (q & 7);
+    float v[4][S][S];
+#pragma unroll
+    for (int y = 0; y < S; ++y)
+#pragma unroll
+      for (int x = 0; x < S; ++x) {
+        float t4[4];
+        load4(go + (((long long)gm.b * H + S * by + y) * W + S * bx + x) * ld + coff + 4 * cg, t4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i][y][x] = t4[i];
+      }
+    if constexpr (L == 1) {
+      float o[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Haar<1>::fwd(v[i], o[i]);
+#pragma unroll
+      for (int b1 = 0; b1 < 4; ++b1) {
+        float t4[4] = {o[0][b1], o[1][b1], o[2][b1], o[3][b1]};
+        store4(&dst[q][b1 * 16 + 4 * cg], t4);
+      }
+    } else {
+      // chunk ch = second-level band; first level on the four 2x2 quadrants, then ONE band of the second level
+#pragma unroll
+      for (int b1 = 0; b1 < 4; ++b1) {
+        float t4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float tq[2][2];
+#pragma unroll
+          for (int I = 0; I < 2; ++I)
+#pragma unroll
+            for (int J = 0; J < 2; ++J)
+              tq[I][J] = haar2_fwd_band(v[i][2 * I][2 * J], v[i][2 * I + 1][2 * J], v[i][2 * I][2 * J + 1], v[i][2 * I + 1][2 * J + 1], b1);
+          t4[i] = haar2_fwd_band(tq[0][0], tq[1][0], tq[0][1], tq[1][1], ch);
+        }
+        store4(&dst[q][b1 * 16 + 4 * cg], t4);
+      }
+    }
+  }
+}
+
+template <typename T, int C, int L>
 __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ rel_h,
                                                               const float* __restrict__ rel_w, const T* __restrict__ go,
                                                               int ldg, int gc0, T* __restrict__ gqkv, T* __restrict__ win,
@@ -244,12 +379,13 @@ __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restric
   // region A: Ks [128][LD] | Vs [128][LD] (phase 1)  /  Ks | DOs [64][LD] | Qs [64][LD] (phase 2)
   //           / KA fp32 [112][CC+1] (rel-pos reduction, aliases Ks after the chunk's products)
   // region B: PT [112][72], DST [112][72]   ([key][query])
+  static_assert(L == 0 || C == (16 << (2 * L)), "fused DWT needs C = 16 * 4^L");
   constexpr size_t szK = sizeof(T) * WA_KR * LD;
-  constexpr size_t szA = 2 * szK;
+  constexpr size_t szA = 2 * szK + sizeof(T) * 64 * LD;
   T(*Ks)[LD] = reinterpret_cast<T(*)[LD]>(smem);
-  T(*Vs)[LD] = reinterpret_cast<T(*)[LD]>(smem + szK);
-  T(*DOs)[LD] = reinterpret_cast<T(*)[LD]>(smem + szK);
-  T(*Qs)[LD] = reinterpret_cast<T(*)[LD]>(smem + szK + sizeof(T) * 64 * LD);
+  T(*Vs)[LD] = reinterpret_cast<T(*)[LD]>(smem + szK);                       // phase 1
+  T(*Qs)[LD] = reinterpret_cast<T(*)[LD]>(smem + szK);                       // phase 2 (aliases Vs)
+  T(*DOs)[LD] = reinterpret_cast<T(*)[LD]>(smem + 2 * szK);                  // output-gradient rows, both phases
   float(*KA)[CC + 1] = reinterpret_cast<float(*)[CC + 1]>(smem);
   T(*PT)[WA_QP] = reinterpret_cast<T(*)[WA_QP]>(smem + szA);
   T(*DST)[WA_QP] = reinterpret_cast<T(*)[WA_QP]>(smem + szA + sizeof(T) * (WA_KT * 16) * WA_QP);
@@ -270,14 +406,13 @@ __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restric
     __syncthreads();
     stage_khat<T, C, CC, CW>(Ks, qkv, rel_h, rel_w, gm, c0, tid);
     stage_keys_rows<T, C, CC, CW>(Vs, qkv, 2 * C, gm, c0, tid);
+    stage_go_rows<T, L, CC, CW>(DOs, go, ldg, gc0, gm, ch, tid);
     __syncthreads();
 #pragma unroll
     for (int kc = 0; kc < CW / 32; ++kc) {
-      Frag8<T> qf = frag_zero<T>(), gf = frag_zero<T>();
-      if (kc * 32 + 8 * g < CC) {
-        qf = load8(qkv + qpix * (3 * C) + c0 + kc * 32 + 8 * g);
-        gf = load8(go + qpix * ldg + gc0 + c0 + kc * 32 + 8 * g);
-      }
+      Frag8<T> qf = frag_zero<T>();
+      if (kc * 32 + 8 * g < CC) qf = load8(qkv + qpix * (3 * C) + c0 + kc * 32 + 8 * g);
+      const Frag8<T> gf = load8(&DOs[q][kc * 32 + 8 * g]);
 #pragma unroll
       for (int t = 0; t < WA_KT; ++t) {
         const Frag8<T> kf = load8(&Ks[16 * t + lr][kc * 32 + 8 * g]);
@@ -351,7 +486,7 @@ __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restric
     const int c0 = ch * CC;
     __syncthreads();   // phase-1 / previous chunk's LDS reads (incl. KA) are done; PT/DST are written
     stage_khat<T, C, CC, CW>(Ks, qkv, rel_h, rel_w, gm, c0, tid);
-    stage_query_rows<T, CC, CW>(DOs, go, ldg, gc0, gm, c0, tid);
+    stage_go_rows<T, L, CC, CW>(DOs, go, ldg, gc0, gm, ch, tid);
     stage_query_rows<T, CC, CW>(Qs, qkv, 3 * C, 0, gm, c0, tid);
     __syncthreads();
     // dq for this wave's 16 queries: A = K^ read transposed (rows = channels, contraction = keys)
@@ -506,21 +641,24 @@ __global__ void __launch_bounds__(256) rel_reduce2_kernel(const float* __restric
 template <typename T, int C> static size_t attn_bwd_smem() {
   constexpr int CC = (C < 64) ? C : 64;
   constexpr int CW = (CC < 32) ? 32 : CC;
-  return 2 * sizeof(T) * WA_KR * (CW + 8) + 2 * sizeof(T) * (WA_KT * 16) * WA_QP;
+  return 2 * sizeof(T) * WA_KR * (CW + 8) + sizeof(T) * 64 * (CW + 8) + 2 * sizeof(T) * (WA_KT * 16) * WA_QP;
 }
 
 template <typename T>
 static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const float* rel_w, const T* gout, int ldg, int gc0,
-                                    T* gqkv, T* win, float* relw, int B, int h, int w, int C, hipStream_t st) {
+                                    T* gqkv, T* win, float* relw, int B, int h, int w, int C, hipStream_t st, int dwt_levels) {
   const int nwin = B * (h / 8) * (w / 8);
-#define GO(C_)                                                                                                     \
+  if (dwt_levels != 0 && !((dwt_levels == 1 && C == 64) || (dwt_levels == 2 && C == 256)))
+    return m2t_set_error(-2, "window_attn_bwd: fused DWT needs (levels, C) = (1, 64) or (2, 256)");
+#define GO(C_, L_)                                                                                                 \
   {                                                                                                                \
     const size_t sh = attn_bwd_smem<T, C_>();                                                                      \
-    (void)hipFuncSetAttribute((const void*)window_attn_bwd_kernel<T, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-    hipLaunchKernelGGL((window_attn_bwd_kernel<T, C_>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, h, w); \
+    (void)hipFuncSetAttribute((const void*)window_attn_bwd_kernel<T, C_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    hipLaunchKernelGGL((window_attn_bwd_kernel<T, C_, L_>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, h, w); \
   }
   m2t_prof_begin(C == 16 ? M2T_PROF_ATTN_BWD_16 : (C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256), st);
-  if (C == 16) GO(16) else if (C == 64) GO(64) else if (C == 256) GO(256)
+  if (dwt_levels == 1) GO(64, 1) else if (dwt_levels == 2) GO(256, 2)
+  else if (C == 16) GO(16, 0) else if (C == 64) GO(64, 0) else if (C == 256) GO(256, 0)
   else return m2t_set_error(-2, "window_attn_bwd: C must be 16, 64 or 256");
 #undef GO
   m2t_prof_end(C == 16 ? M2T_PROF_ATTN_BWD_16 : (C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256), st);
@@ -544,9 +682,10 @@ int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* 
   return 0;
 }
 int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
-                           int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st) {
+                           int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st,
+                           int dwt_levels) {
   if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn_bwd: h,w must be multiples of 8");
   if (dt == M2T_F32)
-    return launch_window_attn_bwd_t<float>((const float*)qkv, rel_h, rel_w, (const float*)gout, ldg, gc0, (float*)gqkv, (float*)win, relw, B, h, w, C, st);
-  return launch_window_attn_bwd_t<bf16_t>((const bf16_t*)qkv, rel_h, rel_w, (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, B, h, w, C, st);
+    return launch_window_attn_bwd_t<float>((const float*)qkv, rel_h, rel_w, (const float*)gout, ldg, gc0, (float*)gqkv, (float*)win, relw, B, h, w, C, st, dwt_levels);
+  return launch_window_attn_bwd_t<bf16_t>((const bf16_t*)qkv, rel_h, rel_w, (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, B, h, w, C, st, dwt_levels);
 }

@@ -144,14 +144,24 @@ __global__ void __launch_bounds__(256) conv3x3_c64_kernel(const T* __restrict__ 
   const int x0 = blockIdx.x * C3_TW, y0 = blockIdx.y * C3_TH, b = blockIdx.z;
   const T* xb = x + (long long)b * H * W * 64;
 
-  // stage the halo tile (zero outside the image)
-  for (int idx = tid; idx < (C3_TH + 2) * (C3_TW + 2) * 8; idx += 256) {
-    const int cv = idx & 7, p = idx >> 3;
-    const int py = p / (C3_TW + 2), px = p - py * (C3_TW + 2);
-    const int gy = y0 + py - 1, gx = x0 + px - 1;
-    Frag8<T> f = frag_zero<T>();
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) f = load8(xb + ((long long)gy * W + gx) * 64 + cv * 8);
-    store8(&Xs[p][cv * 8], f);
+  // stage the halo tile (zero outside the image): every load first, then the LDS stores
+  {
+    constexpr int TOT = (C3_TH + 2) * (C3_TW + 2) * 8, ITEMS = (TOT + 255) / 256;
+    Frag8<T> f[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * 256;
+      const int cv = idx & 7, p = idx >> 3;
+      const int py = p / (C3_TW + 2), px = p - py * (C3_TW + 2);
+      const int gy = y0 + py - 1, gx = x0 + px - 1;
+      f[it] = frag_zero<T>();
+      if (idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W) f[it] = load8(xb + ((long long)gy * W + gx) * 64 + cv * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < TOT) store8(&Xs[idx >> 3][(idx & 7) * 8], f[it]);
+    }
   }
   f32x4 acc[2][4];
 #pragma unroll
@@ -159,16 +169,29 @@ __global__ void __launch_bounds__(256) conv3x3_c64_kernel(const T* __restrict__ 
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // weight slice of the next tap is fetched into registers while the current tap is multiplied
+  Frag8<T> wreg[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = tid + it * 256;
+    wreg[it] = load8(wp + ((long long)(idx >> 3)) * 64 + (idx & 7) * 8);
+  }
   for (int tap = 0; tap < 9; ++tap) {
     const int ky = tap / 3, kx = tap - ky * 3;
     __syncthreads();   // previous tap's reads of Ws done (and, tap 0, Xs staged)
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int idx = tid + it * 256;
-      const int row = idx >> 3, cv = idx & 7;
-      store8(&Ws[row][cv * 8], load8(wp + ((long long)tap * 64 + row) * 64 + cv * 8));
+      store8(&Ws[idx >> 3][(idx & 7) * 8], wreg[it]);
     }
     __syncthreads();
+    if (tap < 8) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * 256;
+        wreg[it] = load8(wp + ((long long)(tap + 1) * 64 + (idx >> 3)) * 64 + (idx & 7) * 8);
+      }
+    }
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
       Frag8<T> xf[2];
@@ -260,27 +283,49 @@ __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restr
     const int b = (int)(q / th);
     const int x0 = tx * 16, y0 = ty * TH;
     __syncthreads();
-    // gy tile -> GT[oc][m], m = row*16 + col
-    for (int idx = tid; idx < MT * 8; idx += 256) {
-      const int m = idx % MT, cv = idx / MT;
-      const int row = m >> 4, col = m & 15;
-      const Frag8<T> f = load8(gy + (((long long)b * H + y0 + row) * W + x0 + col) * 64 + cv * 8);
+    // gy tile -> GT[oc][m], m = row*16 + col ; x halo -> three shifted transposed copies.
+    // All global loads first (registers), then the transposing LDS stores.
+    {
+      constexpr int NG = MT * 8 / 256;
+      constexpr int TOTX = (TH + 2) * 18 * 8, NX = (TOTX + 255) / 256;
+      Frag8<T> fg[NG], fx[NX];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) GT[cv * 8 + e][m] = f.v_elem(e);
-    }
-    // x halo -> three shifted transposed copies
-    for (int idx = tid; idx < (TH + 2) * 18 * 8; idx += 256) {
-      const int p = idx % ((TH + 2) * 18), cv = idx / ((TH + 2) * 18);
-      const int row = p / 18, xs = p - row * 18 - 1;        // xs in [-1, 16]
-      const int gyy = y0 + row - 1, gxx = x0 + xs;
-      Frag8<T> f = frag_zero<T>();
-      if (gyy >= 0 && gyy < H && gxx >= 0 && gxx < W) f = load8(x + (((long long)b * H + gyy) * W + gxx) * 64 + cv * 8);
+      for (int it = 0; it < NG; ++it) {
+        const int idx = tid + it * 256;
+        const int m = idx % MT, cv = idx / MT;
+        fg[it] = load8(gy + (((long long)b * H + y0 + (m >> 4)) * W + x0 + (m & 15)) * 64 + cv * 8);
+      }
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int col = xs - (dx - 1);                      // copy dx holds x[.., col + dx - 1]
-        if (col >= 0 && col < 16) {
+      for (int it = 0; it < NX; ++it) {
+        const int idx = tid + it * 256;
+        const int p = idx % ((TH + 2) * 18), cv = idx / ((TH + 2) * 18);
+        const int row = p / 18, xs = p - row * 18 - 1;        // xs in [-1, 16]
+        const int gyy = y0 + row - 1, gxx = x0 + xs;
+        fx[it] = frag_zero<T>();
+        if (idx < TOTX && gyy >= 0 && gyy < H && gxx >= 0 && gxx < W)
+          fx[it] = load8(x + (((long long)b * H + gyy) * W + gxx) * 64 + cv * 8);
+      }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) XT[dx][cv * 8 + e][row * 16 + col] = f.v_elem(e);
+      for (int it = 0; it < NG; ++it) {
+        const int idx = tid + it * 256;
+        const int m = idx % MT, cv = idx / MT;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) GT[cv * 8 + e][m] = fg[it].v_elem(e);
+      }
+#pragma unroll
+      for (int it = 0; it < NX; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < TOTX) {
+          const int p = idx % ((TH + 2) * 18), cv = idx / ((TH + 2) * 18);
+          const int row = p / 18, xs = p - row * 18 - 1;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int col = xs - (dx - 1);                      // copy dx holds x[.., col + dx - 1]
+            if (col >= 0 && col < 16) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) XT[dx][cv * 8 + e][row * 16 + col] = fx[it].v_elem(e);
+            }
+          }
         }
       }
     }
@@ -350,17 +395,28 @@ int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs
 // halo tile of GELU(tpre) (reflect addressing), rows >= 324 zero
 template <typename T>
 __device__ __forceinline__ void final_stage_act(T (*As)[FC_LD], const T* __restrict__ tb, int y0, int x0, int H, int W, int tid) {
-  for (int idx = tid; idx < FC_HPP * 8; idx += 256) {
+  constexpr int ITEMS = FC_HPP * 8 / 256;   // 11
+  Frag8<T> f[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * 256;
     const int cv = idx & 7, p = idx >> 3;
-    Frag8<T> f = frag_zero<T>();
+    f[it] = frag_zero<T>();
     if (p < FC_HP) {
       const int py = p / (FC_T + 2), px = p - py * (FC_T + 2);
       const int gy = reflect_idx(y0 + py - 1, H), gx = reflect_idx(x0 + px - 1, W);
-      f = load8(tb + ((long long)gy * W + gx) * 64 + cv * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f.set(e, gelu_erf(f.get(e)));
+      f[it] = load8(tb + ((long long)gy * W + gx) * 64 + cv * 8);
     }
-    store8(&As[p][cv * 8], f);
+  }
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int idx = tid + it * 256;
+    const int cv = idx & 7, p = idx >> 3;
+    if (p < FC_HP) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[it].set(e, gelu_erf(f[it].get(e)));
+    }
+    store8(&As[p][cv * 8], f[it]);
   }
 }
 

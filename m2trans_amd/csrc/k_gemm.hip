@@ -37,26 +37,36 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __r
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
-    // ---- stage A (128 x 32) and W (64 x 32) ----
+  // register-staged pipeline: the next k-chunk's global loads are in flight while the current one is multiplied
+  Frag8<T> ra[2], rw;
+  auto fetch = [&](int k0) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int idx = tid + it * 256;
       const int row = idx >> 2, kv = idx & 3;
       const long long m = m0 + row;
       const int k = k0 + kv * 8;
-      Frag8<T> f = frag_zero<T>();
-      if (m < M && k < K) f = gemm_load_a<T, AMODE>(A, lda, m, k, sg);
-      store8(&As[row][kv * 8], f);
+      ra[it] = frag_zero<T>();
+      if (m < M && k < K) ra[it] = gemm_load_a<T, AMODE>(A, lda, m, k, sg);
     }
     {
       const int row = tid >> 2, kv = tid & 3;
       const int n = n0 + row, k = k0 + kv * 8;
-      Frag8<T> f = frag_zero<T>();
-      if (n < N && k < K) f = load8(W + (long long)n * K + k);
-      store8(&Ws[row][kv * 8], f);
+      rw = frag_zero<T>();
+      if (n < N && k < K) rw = load8(W + (long long)n * K + k);
     }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
+    if (k0 > 0) __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256;
+      store8(&As[idx >> 2][(idx & 3) * 8], ra[it]);
+    }
+    store8(&Ws[tid >> 2][(tid & 3) * 8], rw);
     __syncthreads();
+    if (k0 + GEMM_BK < K) fetch(k0 + GEMM_BK);
     // ---- 2 x 4 tile products per wave ----
     Frag8<T> xf[2];
 #pragma unroll
@@ -68,7 +78,6 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __r
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wf, xf[mt]);
     }
-    __syncthreads();
   }
 
   // ---- epilogue: lane (m = lr, g) holds n_local = 16 g + 4 nt + r ----

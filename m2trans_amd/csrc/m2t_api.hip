@@ -302,8 +302,8 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
         // x1 = attn1(x1) + x1 written straight into the concat buffer (:139,163)
         CK(launch_window_attn_fwd(dt, qkv, rh, rw, xc, 64, 0, d, 16, B, h, w, C, st));
       } else {
-        CK(launch_window_attn_fwd(dt, qkv, rh, rw, WSP("a"), C, 0, nullptr, 0, B, h, w, C, st));
-        CK(launch_branch_post(dt, L, WSP("a"), WSP("xin"), xc, i, B, H, W, st));
+        // x_k = IWT^L(attn_k(.)) + x_k_in written straight into the concat buffer (:145,153,161,163)
+        CK(launch_window_attn_fwd(dt, qkv, rh, rw, xc, 64, 16 * i, WSP("xin"), 16, B, h, w, C, st, L));
       }
     }
     // x = feed_forward(xc) + x (:164); the last block also folds in `res + x` (:70)
@@ -497,8 +497,8 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       if (i == 0) {
         CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 0, gqkv, WSP("win"), relw, B, h, w, C, st));
       } else {
-        CK(launch_branch_post_bwd(dt, L, gxc, i, WSP("ga"), B, H, W, st));
-        CK(launch_window_attn_bwd(dt, qkv, rh, rw, WSP("ga"), C, 0, gqkv, WSP("win"), relw, B, h, w, C, st));
+        // gradient of IWT^L is DWT^L: applied while the kernel loads g_xc[chunk i]
+        CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 16 * i, gqkv, WSP("win"), relw, B, h, w, C, st, L));
       }
       fork();
       m2t_wgrad_args wa{};

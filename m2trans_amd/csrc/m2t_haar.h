@@ -1,0 +1,73 @@
+// m2t_haar.h -- L-level Haar DWT / IWT on registers (models/M2Trans_network.py:198-237), shared by the
+// pointwise kernels and by the attention kernels that fuse the transforms into their loads / stores.
+#pragma once
+#include "m2t_common.h"
+
+// =======================================================================================
+// Haar butterflies on registers (association order = the reference's, so fp32 is bit-exact)
+// =======================================================================================
+__device__ __forceinline__ void haar2_fwd(float a, float b, float c, float d, float (&o)[4]) {
+  // a=(even r,even c) b=(odd r,even c) c=(even r,odd c) d=(odd r,odd c)  (:203-207)
+  o[0] = 0.5f * (((a + b) + c) + d);
+  o[1] = 0.5f * (((-a - b) + c) + d);
+  o[2] = 0.5f * (((-a + b) - c) + d);
+  o[3] = 0.5f * (((a - b) - c) + d);
+}
+__device__ __forceinline__ void haar2_inv(float ll, float hl, float lh, float hh, float& a, float& b,
+                                          float& c, float& d) {
+  a = 0.5f * (((ll - hl) - lh) + hh);   // even r, even c   (:225)
+  b = 0.5f * (((ll - hl) + lh) - hh);   // odd r,  even c   (:227)
+  c = 0.5f * (((ll + hl) - lh) - hh);   // even r, odd c    (:229)
+  d = 0.5f * (((ll + hl) + lh) + hh);   // odd r,  odd c    (:231)
+}
+
+// L-level transform of one channel of a (2^L x 2^L) pixel block.
+// in: v[y][x];  out: o[band index], band index = band_L * 4^(L-1) + ... + band_1 (band-major
+// nesting exactly as repeated torch.cat((LL,HL,LH,HH),1) produces).
+template <int L> struct Haar;
+template <> struct Haar<0> {
+  static constexpr int S = 1, N = 1;
+  __device__ static __forceinline__ void fwd(const float (&v)[1][1], float (&o)[1]) { o[0] = v[0][0]; }
+  __device__ static __forceinline__ void inv(const float (&o)[1], float (&v)[1][1]) { v[0][0] = o[0]; }
+};
+template <> struct Haar<1> {
+  static constexpr int S = 2, N = 4;
+  __device__ static __forceinline__ void fwd(const float (&v)[2][2], float (&o)[4]) {
+    haar2_fwd(v[0][0], v[1][0], v[0][1], v[1][1], o);
+  }
+  __device__ static __forceinline__ void inv(const float (&o)[4], float (&v)[2][2]) {
+    haar2_inv(o[0], o[1], o[2], o[3], v[0][0], v[1][0], v[0][1], v[1][1]);
+  }
+};
+template <> struct Haar<2> {
+  static constexpr int S = 4, N = 16;
+  __device__ static __forceinline__ void fwd(const float (&v)[4][4], float (&o)[16]) {
+    float t[2][2][4];
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+        haar2_fwd(v[2 * I][2 * J], v[2 * I + 1][2 * J], v[2 * I][2 * J + 1], v[2 * I + 1][2 * J + 1], t[I][J]);
+#pragma unroll
+    for (int b1 = 0; b1 < 4; ++b1) {
+      float r[4];
+      haar2_fwd(t[0][0][b1], t[1][0][b1], t[0][1][b1], t[1][1][b1], r);
+#pragma unroll
+      for (int b2 = 0; b2 < 4; ++b2) o[b2 * 4 + b1] = r[b2];
+    }
+  }
+  __device__ static __forceinline__ void inv(const float (&o)[16], float (&v)[4][4]) {
+    float t[2][2][4];
+#pragma unroll
+    for (int b1 = 0; b1 < 4; ++b1)
+      haar2_inv(o[0 * 4 + b1], o[1 * 4 + b1], o[2 * 4 + b1], o[3 * 4 + b1], t[0][0][b1], t[1][0][b1],
+                t[0][1][b1], t[1][1][b1]);
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+        haar2_inv(t[I][J][0], t[I][J][1], t[I][J][2], t[I][J][3], v[2 * I][2 * J], v[2 * I + 1][2 * J],
+                  v[2 * I][2 * J + 1], v[2 * I + 1][2 * J + 1]);
+  }
+};
+

@@ -100,12 +100,15 @@ int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* 
 
 // ---- k_attn.hip -------------------------------------------------------------------------
 // qkv [B][h][w][3C] (q | k | v), rel_h/rel_w fp32 [10][C/2];  out rows at ldo (+ optional residual rows at ldr)
+// post_levels = 1, 2: out/res are the FULL-RES xc (ld ldo, channel offset oc0) / xin (ld ldr) tensors and the
+// epilogue writes xc = IWT^levels(attention) + xin
 int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0,
-                           const void* res, int ldr, int B, int h, int w, int C, hipStream_t st);
+                           const void* res, int ldr, int B, int h, int w, int C, hipStream_t st, int post_levels = 0);
 // gout [B][h][w][ldg] (channels gc0..gc0+C) -> gqkv [B][h][w][3C]; per-window dK/dV scratch `win` [B*L][100][2C] (T);
 // rel-pos gradient slabs
 int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
-                           int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st);
+                           int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st,
+                           int dwt_levels = 0);   // 1, 2: gout is the FULL-RES g_xc tensor; DWT^levels applied on load
 // relw [nwin][10][C] per-window partials -> grel_h / grel_w (torch layouts)
 int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st);
 
