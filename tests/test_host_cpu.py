@@ -199,3 +199,35 @@ def test_shard_size_rejects_uneven_batches():
     assert shard_size(256, 8) == 32
     with pytest.raises(ValueError):
         shard_size(10, 4)
+
+
+def test_checkpoint_round_trip_reference_format():
+    """train.py:341-349 / :92-108 wire format: module.-prefixed model keys, torch Adam state indexed in
+    model.parameters() order (frozen MeanShift tensors occupy indices 0..3 and carry no state)."""
+    from m2trans_amd.M2Trans_network import create_model
+    from m2trans_amd.checkpoint import export_checkpoint, import_checkpoint
+
+    class FakeStep:                      # the flat-buffer part of TrainStep, on the CPU
+        def __init__(self, m):
+            self.exp_avg = torch.randn_like(m.flat_params)
+            self.exp_avg_sq = torch.rand_like(m.flat_params)
+            self.step_count, self.lr, self.betas, self.eps = 7, 5e-5, (0.9, 0.999), 1e-8
+        def set_lr(self, lr):
+            self.lr = lr
+    m = create_model(_args(4, 1))
+    fs = FakeStep(m)
+    ck = export_checkpoint(m, fs, epoch=3)
+    assert all(k.startswith("module.") for k in ck["model_state_dict"])
+    # a stock torch Adam over ALL parameters (like train.py:81) accepts the optimizer state
+    ref_like = create_model(_args(4, 1))
+    opt = torch.optim.Adam(ref_like.parameters(), lr=1e-4)
+    opt.load_state_dict(ck["optimizer_state_dict"])
+    i_head = [n for n, _ in ref_like.named_parameters()].index("head.weight")
+    o, k, shp = m._slots[0]
+    assert torch.equal(opt.state_dict()["state"][i_head]["exp_avg"], fs.exp_avg[o:o + k].view(shp))
+    m2 = create_model(_args(4, 1))
+    fs2 = FakeStep(m2)
+    assert import_checkpoint(ck, m2, fs2) == 4
+    assert torch.equal(m2.flat_params, m.flat_params)
+    assert torch.equal(fs2.exp_avg, fs.exp_avg) and torch.equal(fs2.exp_avg_sq, fs.exp_avg_sq)
+    assert fs2.step_count == 7 and fs2.lr == 5e-5
