@@ -671,6 +671,15 @@ static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const floa
   }
   return 0;
 }
+int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int* nsplit_out, hipStream_t st) {
+  int nsplit = std::min(nwin, 32);
+  const int wps = ceil_div(nwin, nsplit);
+  nsplit = ceil_div(nwin, wps);
+  hipLaunchKernelGGL(rel_reduce1_kernel, dim3(ceil_div(10 * C, 256), nsplit), dim3(256), 0, st, relw, rel_part, nwin, 10 * C, wps);
+  M2T_LAUNCH_CHECK();
+  *nsplit_out = nsplit;
+  return 0;
+}
 int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st) {
   int nsplit = std::min(nwin, 32);
   const int wps = ceil_div(nwin, nsplit);

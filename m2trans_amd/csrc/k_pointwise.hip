@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(256) colsum2_kernel(const float* __restrict__ 
   }
 }
 int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* part, int max_part_blocks, float* out,
-                  int accumulate, hipStream_t st, int unshuf, int gH, int gW, int gr, int gC) {
+                  int accumulate, hipStream_t st, int unshuf, int gH, int gW, int gr, int gC, int* nblk_out) {
   if (N % 8 || N / 8 > 256) return m2t_set_error(-2, "colsum: bad N");
   ShufGeom sg{gH, gW, gr, gC};
   int nblk = (int)std::min<long long>(max_part_blocks, ceil_divll(M, 64));
@@ -611,6 +611,7 @@ int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* par
     else hipLaunchKernelGGL((colsum1_kernel<bf16_t, M2T_A_PLAIN>), dim3(nblk), dim3(256), 0, st, (const bf16_t*)a, lda, part, M, N, rpb, sg);
   }
   M2T_LAUNCH_CHECK();
+  if (nblk_out) { *nblk_out = nblk; return 0; }      // partials only: the caller reduces them later (batched)
   hipLaunchKernelGGL(colsum2_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, st, part, out, nblk, N, accumulate);
   M2T_LAUNCH_CHECK();
   return 0;
@@ -644,6 +645,54 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restri
     out[d] = acc;
   }
 }
+// Batched form: ONE launch reduces many slab sets (every weight / bias / rel-pos gradient of a group of
+// blocks), driven by a descriptor table.  grid (x = element chunks, y = descriptor).
+__device__ __forceinline__ long long red_dest(long long e, int perm, int p0, int p1, int p2, bool& skip) {
+  skip = false;
+  if (perm == 1) {           // conv3x3 packed [tap][O][I] -> torch [O][I][3][3]; p0 = O, p1 = I
+    const int i = (int)(e % p1); const int o = (int)((e / p1) % p0); const int tap = (int)(e / ((long long)p0 * p1));
+    return ((long long)o * p1 + i) * 9 + tap;
+  } else if (perm == 2) {    // shuffled rows n' = sub*C + c -> torch row c*rr + sub; p0 = C, p1 = rr, p2 = K
+    const int kk = (int)(e % p2); const int np = (int)(e / p2);
+    const int sub = np / p0, c = np % p0;
+    return ((long long)c * p1 + sub) * p2 + kk;
+  } else if (perm == 3) {    // tail conv slab [32 (tap*3+oc, 27 used)][64 ic] -> torch [3][64][3][3]
+    const int ic = (int)(e & 63), nn = (int)(e >> 6);
+    if (nn >= 27) { skip = true; return 0; }
+    return ((long long)(nn % 3) * 64 + ic) * 9 + nn / 3;
+  } else if (perm == 4) {    // rel-pos [10][C] -> rel_h [10][C/2] followed by rel_w [10][C/2]; p0 = C
+    const int c = (int)(e % p0), i = (int)(e / p0);
+    return (c < p0 / 2) ? ((long long)i * (p0 / 2) + c) : ((long long)10 * (p0 / 2) + (long long)i * (p0 / 2) + (c - p0 / 2));
+  }
+  return e;
+}
+__global__ void __launch_bounds__(256) multi_reduce_kernel(const float* __restrict__ arena, float* __restrict__ grads,
+                                                           const m2t_red_desc* __restrict__ descs) {
+  const m2t_red_desc d = descs[blockIdx.y];
+  const float* slab = arena + d.src_off;
+  float* out = grads + d.dst_off;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < d.n; e += (long long)gridDim.x * blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < d.ns; s += 4) {
+      a0 += slab[(long long)s * d.n + e];
+      a1 += slab[(long long)(s + 1) * d.n + e];
+      a2 += slab[(long long)(s + 2) * d.n + e];
+      a3 += slab[(long long)(s + 3) * d.n + e];
+    }
+    for (; s < d.ns; ++s) a0 += slab[(long long)s * d.n + e];
+    bool skip;
+    const long long dst = red_dest(e, d.perm, d.p0, d.p1, d.p2, skip);
+    if (!skip) out[dst] = (a0 + a1) + (a2 + a3);
+  }
+}
+int launch_multi_reduce(const float* arena, float* grads, const m2t_red_desc* descs, int ndesc, hipStream_t st) {
+  if (ndesc <= 0) return 0;
+  hipLaunchKernelGGL(multi_reduce_kernel, dim3(48, ndesc), dim3(256), 0, st, arena, grads, descs);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_reduce_slabs(const float* slab, float* out, int ns, long long n, int perm, int p0, int p1, int p2,
                         hipStream_t st) {
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, st, slab, out, ns, n, perm, p0, p1, p2);

@@ -85,6 +85,11 @@ struct m2t_plan {
   long long npacked = 0;
   bool have_seed = false, have_acts = false;
   bool use_side = true;
+  // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
+  // region; the descriptor table is identical every step, so it is uploaded once
+  std::vector<m2t_red_desc> red_descs;
+  bool red_uploaded = false;
+  size_t arena_floats = 0;
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> events;
   int ensure_side() {
@@ -224,7 +229,16 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("relw0", (size_t)(BP / 64) * 10 * 16, 4);
   p->add_ws("relw1", (size_t)(BP / 64) * 10 * 16, 4);
   p->add_ws("rel_part", 32 * 10 * 256, 4);
-  p->add_ws("slabs", (size_t)256 * 9 * 64 * 64, 4);
+  {
+    // arena: every slab set of one backward pass (see m2t_backward); sized from the launchers' slab rules
+    size_t per_block = (size_t)256 * 9 * 64 * 64 + (size_t)256 * 64;                 // conv wgrad + ff bias partials
+    per_block += (size_t)256 * 768 + (size_t)256 * 12288 + 2 * (size_t)16 * 196608;  // qkv wgrads (upper bounds)
+    per_block += 4 * (size_t)32 * 2560;                                               // rel-pos partials
+    size_t tail = 2 * (size_t)256 * (16384 + 36864) + (size_t)1024 * 2048 + 4 * (size_t)256 * 768 + (size_t)256 * 1728 * 2;
+    p->arena_floats = per_block * n_blocks + tail + (1u << 20);
+    p->add_ws("arena", p->arena_floats, 4);
+    p->add_ws("red_descs", 512 * sizeof(m2t_red_desc), 1);
+  }
   p->add_ws("col_part", (size_t)256 * 768, 4);
   p->ws_bytes = (p->ws_bytes + 255) & ~(size_t)255;
   *out = p;
@@ -412,9 +426,35 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
 
   const int dt = p->dt, B = p->B, H = p->H, W = p->W, s = p->scale;
   const long long BP = (long long)B * p->P;
-  float* slabs = (float*)WSP("slabs");       // side stream only
-  float* colp = (float*)WSP("col_part");     // side stream only
-  float* relp = (float*)WSP("rel_part");     // side stream only
+  // ---- slab arena + deferred reductions (all on the side stream) ----
+  float* arena = (float*)WSP("arena");
+  const m2t_red_desc* descs_dev = (const m2t_red_desc*)WSP("red_descs");
+  size_t arena_top = 0;
+  std::vector<m2t_red_desc> descs;
+  size_t flushed = 0;
+  bool overflow = false;
+  auto arena_alloc = [&](size_t nfloats) -> float* {
+    arena_top = (arena_top + 63) & ~(size_t)63;
+    float* ptr = arena + arena_top;
+    arena_top += nfloats;
+    if (arena_top > p->arena_floats) overflow = true;
+    return ptr;
+  };
+  auto defer = [&](const float* slab, long long dst_off, int ns, long long n, int perm, int p0, int p1, int p2) {
+    m2t_red_desc d;
+    d.src_off = (long long)(slab - arena); d.dst_off = dst_off; d.n = n; d.ns = ns; d.perm = perm; d.p0 = p0; d.p1 = p1; d.p2 = p2; d.pad_ = 0;
+    descs.push_back(d);
+  };
+  auto flush = [&]() -> int {        // one launch reduces everything deferred since the last flush
+    if (overflow) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: slab arena too small");
+    if (descs.size() > 512) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: too many deferred reductions");
+    if (!p->red_uploaded) return 0;  // first call: table not on the device yet, reduced at the end
+    const int cnt = (int)(descs.size() - flushed);
+    int rc = launch_multi_reduce(arena, grads, descs_dev + flushed, cnt, sd);
+    flushed = descs.size();
+    return rc;
+  };
+  float* relp = nullptr;
   const float* gpre = (const float*)WSP("gpre");
   int ns = 0;
   const int r0 = (s == 4) ? 2 : s;
@@ -423,19 +463,23 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   const void* last_pre = (s == 4) ? WSP("t2pre") : WSP("t1pre");
   void* g_last = (s == 4) ? WSP("g_t2pre") : WSP("g_t1pre");
   fork();
-  { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, sd); CK(launch_final_conv_wgrad(dt, gpre, last_pre, slabs, &ns, B, p->Hsp, p->Wsp, sd)); }
-  CK(launch_reduce_slabs(slabs, grads + p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0, sd));
+  {
+    float* slabs = arena_alloc((size_t)1024 * 32 * 64);
+    { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, sd); CK(launch_final_conv_wgrad(dt, gpre, last_pre, slabs, &ns, B, p->Hsp, p->Wsp, sd)); }
+    defer(slabs, p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0);
+  }
   { M2TProfScope ps(M2T_PROF_FINAL_DGRAD, st); CK(launch_final_conv_dgrad(dt, gpre, params + p->poff.at(wl), last_pre, g_last, B, p->Hsp, p->Wsp, st)); }
   if (s == 4) {
     // tail.3: u = gelu(t1pre) W3^T + b3, shuffled into t2pre
     fork();
+    float* slabs = arena_alloc((size_t)M2T_MAX_SLABS * 256 * 64);
+    float* colp = arena_alloc((size_t)M2T_MAX_SLABS * 256);
     m2t_wgrad_args wa{};
     wa.G = WSP("g_t2pre"); wa.gmode = M2T_A_UNSHUF; wa.X = WSP("t1pre"); wa.ldx = 64; wa.xmode = M2T_A_GELU;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP * 4; wa.N = 256; wa.K = 64; wa.H = 2 * H; wa.Wd = 2 * W; wa.r = 2; wa.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
-    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64, sd));
-    // bias gradient rode along in the wgrad kernel (shuffled column order -> torch order)
-    CK(launch_reduce_slabs(colp, grads + p->poff.at("tail.3.bias"), ns, 256, 2, 64, 4, 1, sd));
+    defer(slabs, p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64);
+    defer(colp, p->poff.at("tail.3.bias"), ns, 256, 2, 64, 4, 1);   // bias gradient rode along in the wgrad kernel
     m2t_gemm_args ga{};
     ga.A = WSP("g_t2pre"); ga.W = packed_ptr(p, workspace, "t3T"); ga.Y = WSP("g_t1pre"); ga.ldy = 64;
     ga.aux = WSP("t1pre"); ga.ldaux = 64; ga.M = BP * 4; ga.N = 64; ga.K = 256;
@@ -446,17 +490,20 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   {
     const int N0 = 64 * r0 * r0;
     fork();
+    float* slabs = arena_alloc((size_t)M2T_MAX_SLABS * N0 * 64);
+    float* colp = arena_alloc((size_t)M2T_MAX_SLABS * N0);
     m2t_wgrad_args wa{};
     wa.G = WSP("g_t1pre"); wa.gmode = M2T_A_UNSHUF; wa.X = Y; wa.ldx = 64; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = N0; wa.K = 64; wa.H = H; wa.Wd = W; wa.r = r0; wa.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
-    CK(launch_reduce_slabs(slabs, grads + p->poff.at("tail.0.weight"), ns, (long long)N0 * 64, 2, 64, r0 * r0, 64, sd));
-    CK(launch_reduce_slabs(colp, grads + p->poff.at("tail.0.bias"), ns, N0, 2, 64, r0 * r0, 1, sd));
+    defer(slabs, p->poff.at("tail.0.weight"), ns, (long long)N0 * 64, 2, 64, r0 * r0, 64);
+    defer(colp, p->poff.at("tail.0.bias"), ns, N0, 2, 64, r0 * r0, 1);
     m2t_gemm_args ga{};
     ga.A = WSP("g_t1pre"); ga.W = packed_ptr(p, workspace, "t0T"); ga.Y = WSP("gT"); ga.ldy = 64;
     ga.M = BP; ga.N = 64; ga.K = N0; ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_PLAIN, ga, st)); }
   }
+  CK(flush());
   // ---- body, last block first.  gy = gradient of X[b+1] ----
   void* gy = WSP("gT");
   void* gnext[2] = {WSP("gA"), WSP("gB")};
@@ -476,9 +523,15 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     void* gn = WSP("gn");
     // feed_forward conv: weight / bias gradients on the side stream, data gradient on the main one
     fork();
-    { M2TProfScope ps(M2T_PROF_CONV3_WGRAD, sd); CK(launch_conv3x3_c64_wgrad(dt, xc, gy, slabs, &ns, B, H, W, sd)); }
-    CK(launch_reduce_slabs(slabs, grads + p->poff.at(pre + "feed_forward.0.weight"), ns, 9 * 64 * 64, 1, 64, 64, 0, sd));
-    CK(launch_colsum(dt, gy, 64, BP, 64, colp, 256, grads + p->poff.at(pre + "feed_forward.0.bias"), 0, sd));
+    {
+      float* slabs = arena_alloc((size_t)256 * 9 * 64 * 64);
+      float* colp = arena_alloc((size_t)256 * 64);
+      { M2TProfScope ps(M2T_PROF_CONV3_WGRAD, sd); CK(launch_conv3x3_c64_wgrad(dt, xc, gy, slabs, &ns, B, H, W, sd)); }
+      defer(slabs, p->poff.at(pre + "feed_forward.0.weight"), ns, 9 * 64 * 64, 1, 64, 64, 0);
+      int nb2 = 0;
+      CK(launch_colsum(dt, gy, 64, BP, 64, colp, 256, nullptr, 0, sd, 0, 0, 0, 1, 64, &nb2));
+      defer(colp, p->poff.at(pre + "feed_forward.0.bias"), nb2, 64, 0, 0, 0, 0);
+    }
     hipEvent_t conv_done = side_marker();
     { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st)); }
     for (int i = 3; i >= 0; --i) {
@@ -494,19 +547,21 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       void* gqkv = gqkv_buf[bi];
       float* relw = relw_buf[bi];
       main_wait(branch_done[bi]);            // side consumers of this gqkv / relw buffer (two branches ago) are done
-      if (i == 0) {
-        CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 0, gqkv, WSP("win"), relw, B, h, w, C, st));
-      } else {
-        // gradient of IWT^L is DWT^L: applied while the kernel loads g_xc[chunk i]
-        CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 16 * i, gqkv, WSP("win"), relw, B, h, w, C, st, L));
-      }
+      // gradient of IWT^L is DWT^L: applied while the kernel loads g_xc[chunk i]
+      CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 16 * i, gqkv, WSP("win"), relw, B, h, w, C, st, L));
       fork();
-      m2t_wgrad_args wa{};
-      wa.G = gqkv; wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = d; wa.ldx = C; wa.xmode = M2T_A_PLAIN;
-      wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = 1; wa.Wd = 1; wa.r = 1; wa.C = 64;
-      { M2TProfScope ps(M2T_PROF_WGRAD_QKV, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
-      CK(launch_reduce_slabs(slabs, grads + p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0, sd));
-      CK(launch_rel_reduce(relw, relp, grads + p->poff.at(an + "rel_h"), grads + p->poff.at(an + "rel_w"), (int)(M / 64), C, sd));
+      {
+        float* slabs = arena_alloc((size_t)std::min<long long>(M2T_MAX_SLABS, std::max<long long>(1, 512 / (ceil_div(3 * C, 64) * ceil_div(C, 64)))) * 3 * C * C);
+        m2t_wgrad_args wa{};
+        wa.G = gqkv; wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = d; wa.ldx = C; wa.xmode = M2T_A_PLAIN;
+        wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = 1; wa.Wd = 1; wa.r = 1; wa.C = 64;
+        { M2TProfScope ps(M2T_PROF_WGRAD_QKV, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
+        defer(slabs, p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0);
+        relp = arena_alloc((size_t)32 * 10 * C);
+        int nsp = 0;
+        CK(launch_rel_reduce1(relw, relp, (int)(M / 64), C, &nsp, sd));
+        defer(relp, p->poff.at(an + "rel_h"), nsp, 10LL * C, 4, C, 0, 0);     // rel_h then rel_w are adjacent parameters
+      }
       branch_done[bi] = side_marker();
       m2t_gemm_args ga{};
       ga.A = gqkv; ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
@@ -520,13 +575,33 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     CK(launch_instnorm_bwd(dt, gn, X, mean, rstd, gy, gx, (float*)WSP("norm_part"), (float*)WSP("norm_s"), B, (int)p->P, st));
     conv_done_prev = conv_done;
     gy = gx;
+    if ((b & 1) == 0) CK(flush());
   }
   // head: g(res) = g(X0) from the chain + g(Y) from `res + x`
   CK(launch_add(dt, gy, WSP("gT"), WSP("gxc"), BP * 64, st));
   fork();
-  CK(launch_head_conv_wgrad(dt, x, WSP("gxc"), slabs, &ns, B, p->H0, p->W0, H, W, sd));
-  CK(launch_reduce_slabs(slabs, grads + p->poff.at("head.weight"), ns, 64 * 27, 0, 0, 0, 0, sd));
-  CK(launch_colsum(dt, WSP("gxc"), 64, BP, 64, colp, 256, grads + p->poff.at("head.bias"), 0, sd));
+  {
+    float* slabs = arena_alloc((size_t)256 * 64 * 27);
+    float* colp = arena_alloc((size_t)256 * 64);
+    CK(launch_head_conv_wgrad(dt, x, WSP("gxc"), slabs, &ns, B, p->H0, p->W0, H, W, sd));
+    defer(slabs, p->poff.at("head.weight"), ns, 64 * 27, 0, 0, 0, 0);
+    int nb2 = 0;
+    CK(launch_colsum(dt, WSP("gxc"), 64, BP, 64, colp, 256, nullptr, 0, sd, 0, 0, 0, 1, 64, &nb2));
+    defer(colp, p->poff.at("head.bias"), nb2, 64, 0, 0, 0, 0);
+  }
+  if (!p->red_uploaded) {
+    // first backward of this plan: publish the (step-invariant) descriptor table, then reduce everything
+    if (overflow) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: slab arena too small");
+    if (descs.size() > 512) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: too many deferred reductions");
+    p->red_descs = descs;
+    hipError_t e = hipMemcpyAsync(WSP("red_descs"), p->red_descs.data(), descs.size() * sizeof(m2t_red_desc), hipMemcpyHostToDevice, sd);
+    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+    p->red_uploaded = true;
+    flushed = 0;
+  } else if (p->red_descs.size() != descs.size()) {
+    return m2t_set_error(M2T_ERR_STATE, "m2t_backward: reduction table changed between steps");
+  }
+  CK(flush());
   main_wait(side_marker());          // join: every gradient is complete in main-stream order
   p->have_seed = false;
   return 0;

@@ -11,6 +11,10 @@ enum m2t_pack_kind {
   M2T_PACK_COPY = 0, M2T_PACK_TRANSPOSE = 1, M2T_PACK_CONV3 = 2, M2T_PACK_CONV3_T = 3,
   M2T_PACK_SHUF_ROWS = 4, M2T_PACK_SHUF_ROWS_T = 5
 };
+struct m2t_red_desc {      // one deferred slab reduction: grads[dst_off + perm(e)] = sum_s arena[src_off + s*n + e]
+  long long src_off, dst_off, n;
+  int ns, perm, p0, p1, p2, pad_;
+};
 struct m2t_pack_desc {
   long long src_off, dst_off, n;
   int kind, d0, d1, d2;
@@ -47,7 +51,9 @@ int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean
                         void* gx, float* part, float* s, int B, int P, hipStream_t st);
 int launch_add(int dt, const void* a, const void* b, void* o, long long n, hipStream_t st);
 int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* part, int max_part_blocks, float* out,
-                  int accumulate, hipStream_t st, int unshuf = 0, int gH = 0, int gW = 0, int gr = 1, int gC = 64);
+                  int accumulate, hipStream_t st, int unshuf = 0, int gH = 0, int gW = 0, int gr = 1, int gC = 64,
+                  int* nblk_out = nullptr);   // nblk_out != null: write the partials only and report their count
+int launch_multi_reduce(const float* arena, float* grads, const m2t_red_desc* descs, int ndesc, hipStream_t st);
 int launch_reduce_slabs(const float* slab, float* out, int ns, long long n, int perm, int p0, int p1, int p2, hipStream_t st);
 int launch_clamp_l1(const float* pre, const float* hr, float* sr, float* gpre, float* part, float* loss, int B, int Hp,
                     int Wp, int Hs, int Ws, float R, float loss_scale, float gscale, hipStream_t st);
@@ -111,6 +117,7 @@ int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const fl
                            int dwt_levels = 0);   // 1, 2: gout is the FULL-RES g_xc tensor; DWT^levels applied on load
 // relw [nwin][10][C] per-window partials -> grel_h / grel_w (torch layouts)
 int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st);
+int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int* nsplit_out, hipStream_t st);
 
 // ---- k_swin.hip (MedCLIP image tower = Swin-T forward, losses.py:68-69) --------------------
 int launch_swin_patchify(int dt, const float* src, int Hs, int Ws, const int* crops, int n, void* out, hipStream_t st);
