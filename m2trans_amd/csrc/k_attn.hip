@@ -646,7 +646,7 @@ template <typename T, int C> static size_t attn_bwd_smem() {
 
 template <typename T>
 static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const float* rel_w, const T* gout, int ldg, int gc0,
-                                    T* gqkv, T* win, float* relw, int B, int h, int w, int C, hipStream_t st, int dwt_levels) {
+                                    T* gqkv, T* win, float* relw, int B, int h, int w, int C, hipStream_t st, int dwt_levels, bool gather) {
   const int nwin = B * (h / 8) * (w / 8);
   if (dwt_levels != 0 && !((dwt_levels == 1 && C == 64) || (dwt_levels == 2 && C == 256)))
     return m2t_set_error(-2, "window_attn_bwd: fused DWT needs (levels, C) = (1, 64) or (2, 256)");
@@ -663,7 +663,7 @@ static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const floa
 #undef GO
   m2t_prof_end(C == 16 ? M2T_PROF_ATTN_BWD_16 : (C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256), st);
   M2T_LAUNCH_CHECK();
-  {
+  if (gather) {
     const long long total = (long long)B * h * w * (2 * C / 8);
     const int g = (int)std::min<long long>(ceil_divll(total, 256), 4096);
     hipLaunchKernelGGL(halo_gather_kernel<T>, dim3(g), dim3(256), 0, st, win, gqkv, B, h, w, C);
@@ -692,9 +692,9 @@ int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* 
 }
 int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
                            int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st,
-                           int dwt_levels) {
+                           int dwt_levels, bool gather) {
   if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn_bwd: h,w must be multiples of 8");
   if (dt == M2T_F32)
-    return launch_window_attn_bwd_t<float>((const float*)qkv, rel_h, rel_w, (const float*)gout, ldg, gc0, (float*)gqkv, (float*)win, relw, B, h, w, C, st, dwt_levels);
-  return launch_window_attn_bwd_t<bf16_t>((const bf16_t*)qkv, rel_h, rel_w, (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, B, h, w, C, st, dwt_levels);
+    return launch_window_attn_bwd_t<float>((const float*)qkv, rel_h, rel_w, (const float*)gout, ldg, gc0, (float*)gqkv, (float*)win, relw, B, h, w, C, st, dwt_levels, gather);
+  return launch_window_attn_bwd_t<bf16_t>((const bf16_t*)qkv, rel_h, rel_w, (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, B, h, w, C, st, dwt_levels, gather);
 }

@@ -135,7 +135,7 @@ template <typename T>
 static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStream_t st) {
   if (a.K % 8 || a.N % 16) return m2t_set_error(-2, "gemm_nt: K must be a multiple of 8 and N of 16");
   dim3 grid((unsigned)ceil_divll(a.M, GEMM_BM), (unsigned)ceil_div(a.N, GEMM_BN));
-  ShufGeom sg{a.H, a.Wd, a.r, a.C};
+  ShufGeom sg{a.H, a.Wd, a.r, a.C, a.halo_win};
 #define GO(AM, EM)                                                                                              \
   hipLaunchKernelGGL((gemm_nt_kernel<T, AM, EM>), grid, dim3(256), 0, st, (const T*)a.A, a.lda, (const T*)a.W, \
                      (T*)a.Y, a.ldy, a.bias, (const T*)a.aux, a.ldaux, a.M, a.N, a.K, sg)
@@ -145,6 +145,7 @@ static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStr
   else if (amode == M2T_A_GELU && emode == M2T_E_BIAS_SHUF) GO(M2T_A_GELU, M2T_E_BIAS_SHUF);
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_GELU) GO(M2T_A_PLAIN, M2T_E_BIAS_GELU);
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_RESID) GO(M2T_A_PLAIN, M2T_E_BIAS_RESID);
+  else if (amode == M2T_A_HALO && emode == M2T_E_PLAIN) GO(M2T_A_HALO, M2T_E_PLAIN);
   else if (amode == M2T_A_UNSHUF && emode == M2T_E_PLAIN) GO(M2T_A_UNSHUF, M2T_E_PLAIN);
   else if (amode == M2T_A_UNSHUF && emode == M2T_E_GELU_GRAD) GO(M2T_A_UNSHUF, M2T_E_GELU_GRAD);
   else return m2t_set_error(-2, "gemm_nt: unsupported (A mode, epilogue) combination");
@@ -155,6 +156,137 @@ static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStr
 int launch_gemm_nt(int dt, int amode, int emode, const m2t_gemm_args& a, hipStream_t st) {
   if (dt == M2T_F32) return launch_gemm_nt_t<float>(amode, emode, a, st);
   return launch_gemm_nt_t<bf16_t>(amode, emode, a, st);
+}
+
+// =======================================================================================
+// tail_expand: the two upsampler 1x1 convs (models/M2Trans_network.py:42-47,52-54) as one specialised
+// kernel:  t[(b, r h + i, r w + j)][c] = bias[c r^2 + i r + j] + sum_k act(x[(b,h,w)][k]) W[(i r + j) 64 + c][k]
+// K = 64, N = 64 r^2 (packed rows already in sub-pixel-major order).  A persistent workgroup keeps the WHOLE
+// weight matrix in LDS and sweeps 128-row tiles: the activation tile is staged once (GELU applied once, not
+// once per 64-column block), the next tile's global loads fly while the current one is multiplied, and each
+// 64-column group is exactly one sub-pixel, so a lane stores 16 consecutive channels of one output pixel.
+// =======================================================================================
+template <typename T, bool GELU_IN, int NSUB>
+__global__ void __launch_bounds__(256)
+tail_expand_kernel(const T* __restrict__ X, const T* __restrict__ Wp, const float* __restrict__ bias, T* __restrict__ Y,
+                   long long M, int H, int Wd, int r, int tiles_per_block) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T(*Ws)[72] = reinterpret_cast<T(*)[72]>(smem);                                   // [64 NSUB][72]
+  T(*As)[72] = reinterpret_cast<T(*)[72]>(smem + sizeof(T) * 64 * NSUB * 72);      // [128][72]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  for (int idx = tid; idx < 64 * NSUB * 8; idx += 256) store8(&Ws[idx >> 3][(idx & 7) * 8], load8(Wp + (long long)(idx >> 3) * 64 + (idx & 7) * 8));
+  const long long ntiles = (M + 127) / 128;
+  const long long t0 = (long long)blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
+  Frag8<T> ra[4];
+  auto fetch = [&](long long t) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 256;
+      const long long m = t * 128 + (idx >> 3);
+      ra[it] = frag_zero<T>();
+      if (m < M) ra[it] = load8(X + m * 64 + (idx & 7) * 8);
+    }
+  };
+  if (t0 < t1) fetch(t0);
+  const int rr = r * r;
+  for (long long t = t0; t < t1; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 256;
+      Frag8<T> f = ra[it];
+      if (GELU_IN) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f.set(e, gelu_erf(f.get(e)));
+      }
+      store8(&As[idx >> 3][(idx & 7) * 8], f);
+    }
+    __syncthreads();
+    if (t + 1 < t1) fetch(t + 1);
+    Frag8<T> xf[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) xf[mt][kc] = load8(&As[32 * wv + 16 * mt + lr][32 * kc + 8 * g]);
+    // destination pixels of this lane's two rows
+    long long pixbase[2];
+    bool ok[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const long long m = t * 128 + 32 * wv + 16 * mt + lr;
+      ok[mt] = m < M;
+      const int w = (int)(m % Wd);
+      const long long q = m / Wd;
+      const int h = (int)(q % H);
+      const long long b = q / H;
+      pixbase[mt] = (b * H * r + (long long)h * r) * ((long long)Wd * r) + (long long)w * r;
+    }
+#pragma unroll 1
+    for (int sub = 0; sub < NSUB; ++sub) {
+      f32x4 acc[2][4];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int nl = 64 * sub + 16 * (lr >> 2) + 4 * nt + (lr & 3);
+          const Frag8<T> wf = load8(&Ws[nl][32 * kc + 8 * g]);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wf, xf[mt][kc]);
+        }
+      const int i = sub / r, j = sub - i * r;
+      float bv[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bv[e] = bias[(16 * g + e) * rr + sub];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        if (!ok[mt]) continue;
+        float v[16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) v[4 * nt + q4] = acc[mt][nt][q4] + bv[4 * nt + q4];
+        const long long pix = pixbase[mt] + (long long)i * Wd * r + j;
+        store16f(Y + pix * 64 + 16 * g, v);
+      }
+    }
+  }
+}
+template <typename T>
+static int launch_tail_expand_t(const T* X, const T* Wp, const float* bias, T* Y, long long M, int H, int Wd, int r, bool gelu_in,
+                                hipStream_t st) {
+  const long long ntiles = (M + 127) / 128;
+  int nblk = (int)std::min<long long>(ntiles, 1024);
+  const int tpb = (int)ceil_divll(ntiles, nblk);
+  nblk = (int)ceil_divll(ntiles, tpb);
+#define GO(G_, NS_)                                                                                                    \
+  {                                                                                                                    \
+    const size_t sh = sizeof(T) * (64 * NS_ + 128) * 72;                                                               \
+    (void)hipFuncSetAttribute((const void*)tail_expand_kernel<T, G_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    hipLaunchKernelGGL((tail_expand_kernel<T, G_, NS_>), dim3(nblk), dim3(256), sh, st, X, Wp, bias, Y, M, H, Wd, r, tpb); \
+  }
+  if (r == 2) { if (gelu_in) GO(true, 4) else GO(false, 4) }
+  else if (r == 3) { if (gelu_in) GO(true, 9) else GO(false, 9) }
+  else return m2t_set_error(-2, "tail_expand: r must be 2 or 3");
+#undef GO
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+int launch_tail_expand(int dt, const void* X, const void* Wp, const float* bias, void* Y, long long M, int H, int Wd, int r,
+                       bool gelu_in, hipStream_t st) {
+  if (dt == M2T_F32 && r == 3) {
+    // fp32 x3: the 576 x 64 fp32 weight matrix does not fit LDS beside the tile -> generic tiled GEMM
+    m2t_gemm_args ga{};
+    ga.A = X; ga.lda = 64; ga.W = Wp; ga.Y = Y; ga.ldy = 64; ga.bias = bias; ga.M = M; ga.N = 64 * r * r; ga.K = 64;
+    ga.H = H; ga.Wd = Wd; ga.r = r; ga.C = 64;
+    return launch_gemm_nt(dt, gelu_in ? M2T_A_GELU : M2T_A_PLAIN, M2T_E_BIAS_SHUF, ga, st);
+  }
+  if (dt == M2T_F32) return launch_tail_expand_t<float>((const float*)X, (const float*)Wp, bias, (float*)Y, M, H, Wd, r, gelu_in, st);
+  return launch_tail_expand_t<bf16_t>((const bf16_t*)X, (const bf16_t*)Wp, bias, (bf16_t*)Y, M, H, Wd, r, gelu_in, st);
 }
 
 // =======================================================================================
@@ -262,12 +394,13 @@ static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_
   int nslab = (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want, ceil_divll(a.M, WG_BM)));
   long long rps = ceil_divll(ceil_divll(a.M, nslab), WG_BM) * WG_BM;
   nslab = (int)ceil_divll(a.M, rps);
-  ShufGeom sg{a.H, a.Wd, a.r, a.C};
+  ShufGeom sg{a.H, a.Wd, a.r, a.C, a.halo_win};
   dim3 grid(tn, tk, nslab);
 #define GO(GM, XM)                                                                                               \
   hipLaunchKernelGGL((wgrad_tn_kernel<T, GM, XM>), grid, dim3(256), 0, st, (const T*)a.G, a.ldg, (const T*)a.X, \
                      a.ldx, a.slabs, a.bias_slabs, a.M, a.N, a.K, rps, sg)
   if (a.gmode == M2T_A_PLAIN && a.xmode == M2T_A_PLAIN) GO(M2T_A_PLAIN, M2T_A_PLAIN);
+  else if (a.gmode == M2T_A_HALO && a.xmode == M2T_A_PLAIN) GO(M2T_A_HALO, M2T_A_PLAIN);
   else if (a.gmode == M2T_A_UNSHUF && a.xmode == M2T_A_PLAIN) GO(M2T_A_UNSHUF, M2T_A_PLAIN);
   else if (a.gmode == M2T_A_UNSHUF && a.xmode == M2T_A_GELU) GO(M2T_A_UNSHUF, M2T_A_GELU);
   else return m2t_set_error(-2, "wgrad_tn: unsupported operand modes");

@@ -225,7 +225,8 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("gd", BP * 16, es);
   p->add_ws("gqkv0", BP * 48, es);
   p->add_ws("gqkv1", BP * 48, es);
-  p->add_ws("win", BP * 50, es);
+  p->add_ws("win0", BP * 50, es);
+  p->add_ws("win1", BP * 50, es);
   p->add_ws("relw0", (size_t)(BP / 64) * 10 * 16, 4);
   p->add_ws("relw1", (size_t)(BP / 64) * 10 * 16, 4);
   p->add_ws("rel_part", 32 * 10 * 256, 4);
@@ -327,20 +328,13 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
   }
   void* Y = WSP("X" + std::to_string(p->nb));
   const int r0 = (s == 4) ? 2 : s;
-  {
-    m2t_gemm_args ga{};
-    ga.A = Y; ga.lda = 64; ga.W = packed_ptr(p, workspace, "t0"); ga.Y = WSP("t1pre"); ga.ldy = 64;
-    ga.bias = params + p->poff.at("tail.0.bias"); ga.M = BP; ga.N = 64 * r0 * r0; ga.K = 64;
-    ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
-    { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_BIAS_SHUF, ga, st)); }
-  }
+  { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st);
+    CK(launch_tail_expand(dt, Y, packed_ptr(p, workspace, "t0"), params + p->poff.at("tail.0.bias"), WSP("t1pre"), BP, H, W, r0, false, st)); }
   const void* last_pre = WSP("t1pre");
   if (s == 4) {
-    m2t_gemm_args ga{};
-    ga.A = WSP("t1pre"); ga.lda = 64; ga.W = packed_ptr(p, workspace, "t3"); ga.Y = WSP("t2pre"); ga.ldy = 64;
-    ga.bias = params + p->poff.at("tail.3.bias"); ga.M = BP * 4; ga.N = 256; ga.K = 64;
-    ga.H = 2 * H; ga.Wd = 2 * W; ga.r = 2; ga.C = 64;
-    { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_GELU, M2T_E_BIAS_SHUF, ga, st)); }
+    { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st);
+      CK(launch_tail_expand(dt, WSP("t1pre"), packed_ptr(p, workspace, "t3"), params + p->poff.at("tail.3.bias"), WSP("t2pre"), BP * 4,
+                            2 * H, 2 * W, 2, true, st)); }
     last_pre = WSP("t2pre");
   }
   const float* wlast = params + p->poff.at(s == 4 ? "tail.6.weight" : "tail.3.weight");
@@ -509,6 +503,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   void* gnext[2] = {WSP("gA"), WSP("gB")};
   void* gqkv_buf[2] = {WSP("gqkv0"), WSP("gqkv1")};
   float* relw_buf[2] = {(float*)WSP("relw0"), (float*)WSP("relw1")};
+  void* win_buf[2] = {WSP("win0"), WSP("win1")};
   hipEvent_t branch_done[2] = {nullptr, nullptr};
   hipEvent_t conv_done_prev = nullptr;      // side finished reading gy of the previously processed block
   int counter = 0;
@@ -545,16 +540,19 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       const float* rw = params + p->poff.at(an + "rel_w");
       const int bi = (counter++) & 1;
       void* gqkv = gqkv_buf[bi];
+      void* win = win_buf[bi];
       float* relw = relw_buf[bi];
       main_wait(branch_done[bi]);            // side consumers of this gqkv / relw buffer (two branches ago) are done
       // gradient of IWT^L is DWT^L: applied while the kernel loads g_xc[chunk i]
-      CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 16 * i, gqkv, WSP("win"), relw, B, h, w, C, st, L));
+      // (gathering dK|dV inside the GEMM / wgrad loaders (M2T_A_HALO) was measured SLOWER: the gather is then
+      //  repeated once per n-tile / k-tile block; the stand-alone halo_gather pass runs once)
+      CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 16 * i, gqkv, win, relw, B, h, w, C, st, L, true));
       fork();
       {
         float* slabs = arena_alloc((size_t)std::min<long long>(M2T_MAX_SLABS, std::max<long long>(1, 512 / (ceil_div(3 * C, 64) * ceil_div(C, 64)))) * 3 * C * C);
         m2t_wgrad_args wa{};
         wa.G = gqkv; wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = d; wa.ldx = C; wa.xmode = M2T_A_PLAIN;
-        wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = 1; wa.Wd = 1; wa.r = 1; wa.C = 64;
+        wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = h; wa.Wd = w; wa.r = 1; wa.C = C; wa.halo_win = win;
         { M2TProfScope ps(M2T_PROF_WGRAD_QKV, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
         defer(slabs, p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0);
         relp = arena_alloc((size_t)32 * 10 * C);
@@ -565,7 +563,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       branch_done[bi] = side_marker();
       m2t_gemm_args ga{};
       ga.A = gqkv; ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
-      ga.Y = WSP("gd"); ga.ldy = C; ga.M = M; ga.N = C; ga.K = 3 * C; ga.H = 1; ga.Wd = 1; ga.r = 1; ga.C = 64;
+      ga.Y = WSP("gd"); ga.ldy = C; ga.M = M; ga.N = C; ga.K = 3 * C; ga.H = h; ga.Wd = w; ga.r = 1; ga.C = C; ga.halo_win = win;
       { M2TProfScope ps(M2T_PROF_GEMM_QKV_DGRAD, st); CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st)); }
       CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st));
     }
@@ -658,7 +656,7 @@ extern "C" int m2t_window_attention_bwd(int dtype, const void* qkv, const float*
   const size_t woff = (nwin * 100 * 2 * C * es + 255) & ~(size_t)255;
   const size_t roff = woff + ((nwin * 10 * C * 4 + 255) & ~(size_t)255);
   int rc = launch_window_attn_bwd(dtype, qkv, rel_h, rel_w, gout, C, 0, gqkv, scratch, (float*)((char*)scratch + woff),
-                                  B, h, w, C, (hipStream_t)stream);
+                                  B, h, w, C, (hipStream_t)stream, 0, true);
   if (rc) return rc;
   return launch_rel_reduce((float*)((char*)scratch + woff), (float*)((char*)scratch + roff), grel_h, grel_w, (int)nwin, C,
                            (hipStream_t)stream);

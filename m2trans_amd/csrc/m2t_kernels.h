@@ -64,7 +64,7 @@ int launch_layout(int dt, const float* nchw, void* nhwc, float* nchw_out, int B,
 
 // ---- k_gemm.hip -------------------------------------------------------------------------
 // Y[M][N] = A[M][K] * W[N][K]^T  with A-side and epilogue variants
-enum m2t_gemm_a { M2T_A_PLAIN = 0, M2T_A_GELU = 1, M2T_A_UNSHUF = 2 };
+enum m2t_gemm_a { M2T_A_PLAIN = 0, M2T_A_GELU = 1, M2T_A_UNSHUF = 2, M2T_A_HALO = 3 };
 enum m2t_gemm_epi { M2T_E_PLAIN = 0, M2T_E_BIAS = 1, M2T_E_BIAS_SHUF = 2, M2T_E_GELU_GRAD = 3, M2T_E_BIAS_GELU = 4, M2T_E_BIAS_RESID = 5 };
 struct m2t_gemm_args {
   const void* A; int lda;       // A rows (or, UNSHUF: the [B][H*r][W*r][C] tensor)
@@ -74,8 +74,12 @@ struct m2t_gemm_args {
   const void* aux; int ldaux;   // E_GELU_GRAD: pre-activation tensor, same shape as Y
   long long M; int N, K;
   int H, Wd, r, C;              // shuffle geometry: rows m = (b, h, w) over [B][H][Wd]; C channels after shuffle
+  const void* halo_win = nullptr;   // M2T_A_HALO: per-window dK|dV scratch (H, Wd = branch grid, C = branch channels)
 };
 int launch_gemm_nt(int dt, int amode, int emode, const m2t_gemm_args& a, hipStream_t st);
+// upsampler 1x1 conv + bias + pixel-shuffle scatter, K = 64, N = 64 r^2; X rows over [B][H][Wd], optional GELU on load
+int launch_tail_expand(int dt, const void* X, const void* Wp, const float* bias, void* Y, long long M, int H, int Wd, int r,
+                       bool gelu_in, hipStream_t st);
 // dW[N][K] (fp32 slabs) = sum_m G[m][N]^T X[m][K];  G/X side variants as above
 struct m2t_wgrad_args {
   const void* G; int ldg; int gmode;   // M2T_A_PLAIN or M2T_A_UNSHUF
@@ -84,6 +88,7 @@ struct m2t_wgrad_args {
   float* bias_slabs;                   // optional [nslab][N]: column sums of G (bias gradient)
   long long M; int N, K;
   int H, Wd, r, C;
+  const void* halo_win = nullptr;
 };
 int launch_wgrad_tn(int dt, const m2t_wgrad_args& a, int* nslab_out, hipStream_t st);
 
@@ -114,7 +119,8 @@ int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const fl
 // rel-pos gradient slabs
 int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
                            int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st,
-                           int dwt_levels = 0);   // 1, 2: gout is the FULL-RES g_xc tensor; DWT^levels applied on load
+                           int dwt_levels = 0,    // 1, 2: gout is the FULL-RES g_xc tensor; DWT^levels applied on load
+                           bool gather = true);   // false: leave dK|dV in `win` (consumers gather with M2T_A_HALO)
 // relw [nwin][10][C] per-window partials -> grel_h / grel_w (torch layouts)
 int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st);
 int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int* nsplit_out, hipStream_t st);
