@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--all-kernel-events", action="store_true", help="time every kernel category in the timed region (adds ~8%% overhead)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the whole backward on one stream")
+    ap.add_argument("--debug-skip-side", action="store_true", help="TIMING EXPERIMENT: skip all parameter-gradient kernels (wrong results)")
     ap.add_argument("--semantic-loss", action="store_true",
                     help="BASELINE configs[2]: add the MedCLIP(Swin-T) image-text regulariser (random-init tower, hash text features)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=2)
@@ -142,6 +143,9 @@ def main():
     ts = TrainStep(model, lr=1e-4, lambda_l1=1.0, process_group=pg, world_size=world,
                    semantic_loss=sem, lambda_clip=0.01 if sem is not None else 0.0)
     batches = [synthetic_batch(B, args.lr_size, args.scale, rank, s, device) for s in range(2)]
+    if args.debug_skip_side:
+        plan = model._plan_for(batches[0][0])
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"debug_skip_side", 1), "m2t_set_option")
     if args.no_side_stream:
         plan = model._plan_for(batches[0][0])
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"side_stream", 0), "m2t_set_option")

@@ -85,6 +85,9 @@ struct m2t_plan {
   long long npacked = 0;
   bool have_seed = false, have_acts = false;
   bool use_side = true;
+  bool use_fused_tail = false;     // measured: ties the three-kernel sequence (42 us per branch either way)
+  bool debug_skip_side = false;    // timing experiments only: skip every parameter-gradient kernel (results are WRONG)      // halo gather + qkv dgrad GEMM + prep_bwd as one kernel (k_branch.hip)
+  bool use_fused_branch = false;   // fused forward branch kernel (k_branch.hip): correct, currently ties the unfused chain
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
   // region; the descriptor table is identical every step, so it is uploaded once
   std::vector<m2t_red_desc> red_descs;
@@ -233,7 +236,7 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   {
     // arena: every slab set of one backward pass (see m2t_backward); sized from the launchers' slab rules
     size_t per_block = (size_t)256 * 9 * 64 * 64 + (size_t)256 * 64;                 // conv wgrad + ff bias partials
-    per_block += (size_t)256 * 768 + (size_t)256 * 12288 + 2 * (size_t)16 * 196608;  // qkv wgrads (upper bounds)
+    per_block += (size_t)1024 * 768 + (size_t)512 * 12288 + 2 * (size_t)32 * 196608; // qkv wgrads (upper bounds)
     per_block += 4 * (size_t)32 * 2560;                                               // rel-pos partials
     size_t tail = 2 * (size_t)256 * (16384 + 36864) + (size_t)1024 * 2048 + 4 * (size_t)256 * 768 + (size_t)256 * 1728 * 2;
     p->arena_floats = per_block * n_blocks + tail + (1u << 20);
@@ -306,19 +309,25 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
       const std::string an = pre + "attn" + std::to_string(i + 1) + ".";
       void* d = WSP(k + "d" + std::to_string(i + 1));
       void* qkv = WSP(k + "qkv" + std::to_string(i + 1));
-      CK(launch_branch_prep(dt, L, X, mean, rstd, xc, i, WSP("xin"), d, B, H, W, st));
-      m2t_gemm_args ga{};
-      ga.A = d; ga.lda = C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1));
-      ga.Y = qkv; ga.ldy = 3 * C; ga.M = M; ga.N = 3 * C; ga.K = C;
-      { M2TProfScope ps(M2T_PROF_GEMM_QKV, st); CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st)); }
       const float* rh = params + p->poff.at(an + "rel_h");
       const float* rw = params + p->poff.at(an + "rel_w");
-      if (i == 0) {
-        // x1 = attn1(x1) + x1 written straight into the concat buffer (:139,163)
-        CK(launch_window_attn_fwd(dt, qkv, rh, rw, xc, 64, 0, d, 16, B, h, w, C, st));
-      } else {
-        // x_k = IWT^L(attn_k(.)) + x_k_in written straight into the concat buffer (:145,153,161,163)
-        CK(launch_window_attn_fwd(dt, qkv, rh, rw, xc, 64, 16 * i, WSP("xin"), 16, B, h, w, C, st, L));
+      // fused branch kernel (prep + projection + attention + IWT/residual in one launch per window)
+      int rc = p->use_fused_branch ? launch_branch_fwd(dt, L, X, mean, rstd, xc, i, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1)),
+                                                       rh, rw, WSP("xin"), d, qkv, B, h, w, st) : M2T_UNSUPPORTED;
+      if (rc != 0 && rc != M2T_UNSUPPORTED) return rc;
+      if (rc == M2T_UNSUPPORTED) {
+        CK(launch_branch_prep(dt, L, X, mean, rstd, xc, i, WSP("xin"), d, B, H, W, st));
+        m2t_gemm_args ga{};
+        ga.A = d; ga.lda = C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1));
+        ga.Y = qkv; ga.ldy = 3 * C; ga.M = M; ga.N = 3 * C; ga.K = C;
+        { M2TProfScope ps(M2T_PROF_GEMM_QKV, st); CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st)); }
+        if (i == 0) {
+          // x1 = attn1(x1) + x1 written straight into the concat buffer (:139,163)
+          CK(launch_window_attn_fwd(dt, qkv, rh, rw, xc, 64, 0, d, 16, B, h, w, C, st));
+        } else {
+          // x_k = IWT^L(attn_k(.)) + x_k_in written straight into the concat buffer (:145,153,161,163)
+          CK(launch_window_attn_fwd(dt, qkv, rh, rw, xc, 64, 16 * i, WSP("xin"), 16, B, h, w, C, st, L));
+        }
       }
     }
     // x = feed_forward(xc) + x (:164); the last block also folds in `res + x` (:70)
@@ -456,8 +465,9 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   const std::string wl = (s == 4) ? "tail.6.weight" : "tail.3.weight";
   const void* last_pre = (s == 4) ? WSP("t2pre") : WSP("t1pre");
   void* g_last = (s == 4) ? WSP("g_t2pre") : WSP("g_t1pre");
+  const bool skip = p->debug_skip_side;
   fork();
-  {
+  if (!skip) {
     float* slabs = arena_alloc((size_t)1024 * 32 * 64);
     { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, sd); CK(launch_final_conv_wgrad(dt, gpre, last_pre, slabs, &ns, B, p->Hsp, p->Wsp, sd)); }
     defer(slabs, p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0);
@@ -466,14 +476,16 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   if (s == 4) {
     // tail.3: u = gelu(t1pre) W3^T + b3, shuffled into t2pre
     fork();
-    float* slabs = arena_alloc((size_t)M2T_MAX_SLABS * 256 * 64);
-    float* colp = arena_alloc((size_t)M2T_MAX_SLABS * 256);
+    float* slabs = arena_alloc((size_t)wgrad_slab_count(BP * 4, 256, 64) * 256 * 64);
+    float* colp = arena_alloc((size_t)wgrad_slab_count(BP * 4, 256, 64) * 256);
     m2t_wgrad_args wa{};
+    if (!skip) {
     wa.G = WSP("g_t2pre"); wa.gmode = M2T_A_UNSHUF; wa.X = WSP("t1pre"); wa.ldx = 64; wa.xmode = M2T_A_GELU;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP * 4; wa.N = 256; wa.K = 64; wa.H = 2 * H; wa.Wd = 2 * W; wa.r = 2; wa.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
     defer(slabs, p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64);
     defer(colp, p->poff.at("tail.3.bias"), ns, 256, 2, 64, 4, 1);   // bias gradient rode along in the wgrad kernel
+    }
     m2t_gemm_args ga{};
     ga.A = WSP("g_t2pre"); ga.W = packed_ptr(p, workspace, "t3T"); ga.Y = WSP("g_t1pre"); ga.ldy = 64;
     ga.aux = WSP("t1pre"); ga.ldaux = 64; ga.M = BP * 4; ga.N = 64; ga.K = 256;
@@ -484,14 +496,16 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   {
     const int N0 = 64 * r0 * r0;
     fork();
-    float* slabs = arena_alloc((size_t)M2T_MAX_SLABS * N0 * 64);
-    float* colp = arena_alloc((size_t)M2T_MAX_SLABS * N0);
+    float* slabs = arena_alloc((size_t)wgrad_slab_count(BP, N0, 64) * N0 * 64);
+    float* colp = arena_alloc((size_t)wgrad_slab_count(BP, N0, 64) * N0);
     m2t_wgrad_args wa{};
     wa.G = WSP("g_t1pre"); wa.gmode = M2T_A_UNSHUF; wa.X = Y; wa.ldx = 64; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = N0; wa.K = 64; wa.H = H; wa.Wd = W; wa.r = r0; wa.C = 64;
+    if (!skip) {
     { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
     defer(slabs, p->poff.at("tail.0.weight"), ns, (long long)N0 * 64, 2, 64, r0 * r0, 64);
     defer(colp, p->poff.at("tail.0.bias"), ns, N0, 2, 64, r0 * r0, 1);
+    }
     m2t_gemm_args ga{};
     ga.A = WSP("g_t1pre"); ga.W = packed_ptr(p, workspace, "t0T"); ga.Y = WSP("gT"); ga.ldy = 64;
     ga.M = BP; ga.N = 64; ga.K = N0; ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
@@ -518,7 +532,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     void* gn = WSP("gn");
     // feed_forward conv: weight / bias gradients on the side stream, data gradient on the main one
     fork();
-    {
+    if (!skip) {
       float* slabs = arena_alloc((size_t)256 * 9 * 64 * 64);
       float* colp = arena_alloc((size_t)256 * 64);
       { M2TProfScope ps(M2T_PROF_CONV3_WGRAD, sd); CK(launch_conv3x3_c64_wgrad(dt, xc, gy, slabs, &ns, B, H, W, sd)); }
@@ -544,12 +558,16 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       float* relw = relw_buf[bi];
       main_wait(branch_done[bi]);            // side consumers of this gqkv / relw buffer (two branches ago) are done
       // gradient of IWT^L is DWT^L: applied while the kernel loads g_xc[chunk i]
-      // (gathering dK|dV inside the GEMM / wgrad loaders (M2T_A_HALO) was measured SLOWER: the gather is then
-      //  repeated once per n-tile / k-tile block; the stand-alone halo_gather pass runs once)
-      CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 16 * i, gqkv, win, relw, B, h, w, C, st, L, true));
+      // dK|dV stay window-major in `win`; the fused tail kernel gathers them once per row, writes them back
+      // into gqkv for the weight-gradient GEMM, multiplies by Wqkv and applies IWT / branch mixing.
+      // (gathering inside the TILED GEMM / wgrad loaders, M2T_A_HALO, was measured slower: the gather is then
+      //  repeated once per column-block.)
+      CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 16 * i, gqkv, win, relw, B, h, w, C, st, L, !p->use_fused_tail));
+      if (p->use_fused_tail)
+        CK(launch_branch_bwd_tail(dt, L, gqkv, win, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T"), gxc, gn, i, B, h, w, st));
       fork();
-      {
-        float* slabs = arena_alloc((size_t)std::min<long long>(M2T_MAX_SLABS, std::max<long long>(1, 512 / (ceil_div(3 * C, 64) * ceil_div(C, 64)))) * 3 * C * C);
+      if (!skip) {
+        float* slabs = arena_alloc((size_t)wgrad_slab_count(M, 3 * C, C) * 3 * C * C);
         m2t_wgrad_args wa{};
         wa.G = gqkv; wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = d; wa.ldx = C; wa.xmode = M2T_A_PLAIN;
         wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = h; wa.Wd = w; wa.r = 1; wa.C = C; wa.halo_win = win;
@@ -561,11 +579,13 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         defer(relp, p->poff.at(an + "rel_h"), nsp, 10LL * C, 4, C, 0, 0);     // rel_h then rel_w are adjacent parameters
       }
       branch_done[bi] = side_marker();
-      m2t_gemm_args ga{};
-      ga.A = gqkv; ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
-      ga.Y = WSP("gd"); ga.ldy = C; ga.M = M; ga.N = C; ga.K = 3 * C; ga.H = h; ga.Wd = w; ga.r = 1; ga.C = C; ga.halo_win = win;
-      { M2TProfScope ps(M2T_PROF_GEMM_QKV_DGRAD, st); CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st)); }
-      CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st));
+      if (!p->use_fused_tail) {
+        m2t_gemm_args ga{};
+        ga.A = gqkv; ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
+        ga.Y = WSP("gd"); ga.ldy = C; ga.M = M; ga.N = C; ga.K = 3 * C; ga.H = h; ga.Wd = w; ga.r = 1; ga.C = C; ga.halo_win = win;
+        { M2TProfScope ps(M2T_PROF_GEMM_QKV_DGRAD, st); CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st)); }
+        CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st));
+      }
     }
     void* gx = gnext[b & 1];
     // gx's buffer was the gy of block b+1: its conv-wgrad / colsum on the side stream must be done
@@ -578,7 +598,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   // head: g(res) = g(X0) from the chain + g(Y) from `res + x`
   CK(launch_add(dt, gy, WSP("gT"), WSP("gxc"), BP * 64, st));
   fork();
-  {
+  if (!skip) {
     float* slabs = arena_alloc((size_t)256 * 64 * 27);
     float* colp = arena_alloc((size_t)256 * 64);
     CK(launch_head_conv_wgrad(dt, x, WSP("gxc"), slabs, &ns, B, p->H0, p->W0, H, W, sd));
@@ -608,6 +628,9 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
 extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (!p || !key) return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: null");
   if (std::string(key) == "side_stream") { p->use_side = (value != 0); return 0; }
+  if (std::string(key) == "fused_branch") { p->use_fused_branch = (value != 0); return 0; }
+  if (std::string(key) == "fused_tail") { p->use_fused_tail = (value != 0); return 0; }
+  if (std::string(key) == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
   return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");
 }
 

@@ -5,7 +5,7 @@
 
 #define M2T_NORM_SPLIT 32     // pixel splits per image in the InstanceNorm reductions
 #define M2T_LOSS_BLOCKS 1024  // partial sums of the L1 loss
-#define M2T_MAX_SLABS 256     // split-M slabs of a weight-gradient GEMM
+#define M2T_MAX_SLABS 1024    // split-M slabs of a weight-gradient GEMM
 
 enum m2t_pack_kind {
   M2T_PACK_COPY = 0, M2T_PACK_TRANSPOSE = 1, M2T_PACK_CONV3 = 2, M2T_PACK_CONV3_T = 3,
@@ -91,6 +91,7 @@ struct m2t_wgrad_args {
   const void* halo_win = nullptr;
 };
 int launch_wgrad_tn(int dt, const m2t_wgrad_args& a, int* nslab_out, hipStream_t st);
+int wgrad_slab_count(long long M, int N, int K);   // upper bound of the slabs launch_wgrad_tn will write
 
 // ---- k_conv.hip -------------------------------------------------------------------------
 int launch_head_conv_fwd(int dt, const float* x, const float* w, const float* b, void* out, int B, int H0, int W0,
@@ -108,6 +109,19 @@ int launch_final_conv_dgrad(int dt, const float* gout, const float* w, const voi
                             hipStream_t st);
 int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* slabs, int* nslab, int B, int H, int W,
                             hipStream_t st);
+
+// ---- k_branch.hip -----------------------------------------------------------------------
+// one CFTM branch of the forward pass (prep + qkv projection + window attention + IWT/residual) per window;
+// returns M2T_UNSUPPORTED (and launches nothing) for the one unsupported combination (fp32, L = 2)
+#define M2T_UNSUPPORTED (-1000)
+int launch_branch_fwd(int dt, int L, const void* X, const float* mean, const float* rstd, void* xc, int k, const void* Wqkv,
+                      const float* rel_h, const float* rel_w, void* xin, void* dout, void* qkv, int B, int h, int w,
+                      hipStream_t st);
+
+// backward tail of one branch: halo gather of dK|dV (written back into gqkv) + qkv data-gradient GEMM + IWT/mix
+// (branch_prep_bwd) in one kernel.  gqkv [B][h][w][3C] (q part valid), win [B*L][100][2C], WT [C][3C]
+int launch_branch_bwd_tail(int dt, int L, void* gqkv, const void* win, const void* WT, void* gxc, void* gn, int k, int B, int h,
+                           int w, hipStream_t st);
 
 // ---- k_attn.hip -------------------------------------------------------------------------
 // qkv [B][h][w][3C] (q | k | v), rel_h/rel_w fp32 [10][C/2];  out rows at ldo (+ optional residual rows at ldr)

@@ -1,0 +1,34 @@
+// m2t_window.h -- geometry of the 8x8-query / 10x10-key halo windows (models/M2Trans_network.py:310-317),
+// shared by the attention kernels and the fused branch kernel.
+#pragma once
+#include "m2t_common.h"
+
+#define WA_NK 100
+#define WA_KT 7          // key tiles that can hold real keys (112)
+#define WA_KR 128        // key rows staged (4 contraction chunks of 32)
+#define WA_QP 72         // 64 queries + 8 pad
+
+struct WinGeom {
+  int h, w, nw, nh;
+  int b, wy, wx;
+  __device__ __forceinline__ bool key_pixel(int key, long long& pix) const {
+    const int kr = key / 10, kc = key - kr * 10;
+    const int y = 8 * wy + kr - 1, x = 8 * wx + kc - 1;
+    pix = ((long long)b * h + y) * w + x;
+    return (y >= 0 && y < h && x >= 0 && x < w);
+  }
+  __device__ __forceinline__ long long query_pixel(int q) const {
+    return ((long long)b * h + 8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
+  }
+};
+__device__ __forceinline__ WinGeom make_geom(int h, int w) {
+  WinGeom g;
+  g.h = h; g.w = w; g.nw = w / 8; g.nh = h / 8;
+  const int wi = blockIdx.x;
+  g.wx = wi % g.nw;
+  const int q = wi / g.nw;
+  g.wy = q % g.nh;
+  g.b = q / g.nh;
+  return g;
+}
+
