@@ -619,7 +619,7 @@ template <typename T, int C> static size_t attn_bwd_smem() {
 
 template <typename T>
 static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const float* rel_w, const T* gout, int ldg, int gc0,
-                                    T* gqkv, T* win, float* relw, int B, int h, int w, int C, hipStream_t st, int dwt_levels, bool gather) {
+                                    T* gqkv, T* win, float* relw, int B, int h, int w, int C, hipStream_t st, int dwt_levels, bool gather, bool resident) {
   const int nwin = B * (h / 8) * (w / 8);
   if (dwt_levels != 0 && !((dwt_levels == 1 && C == 64) || (dwt_levels == 2 && C == 256)))
     return m2t_set_error(-2, "window_attn_bwd: fused DWT needs (levels, C) = (1, 64) or (2, 256)");
@@ -630,7 +630,13 @@ static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const floa
     hipLaunchKernelGGL((window_attn_bwd_kernel<T, C_, L_>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, h, w); \
   }
   m2t_prof_begin(C == 16 ? M2T_PROF_ATTN_BWD_16 : (C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256), st);
-  if (dwt_levels == 1) GO(64, 1) else if (dwt_levels == 2) GO(256, 2)
+  int res_rc = M2T_UNSUPPORTED;
+  if (resident && sizeof(T) == 2) {
+    res_rc = launch_window_attn_bwd_resident(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, B, h, w, C, dwt_levels, st);
+    if (res_rc != 0 && res_rc != M2T_UNSUPPORTED) return res_rc;
+  }
+  if (res_rc == 0) {}
+  else if (dwt_levels == 1) GO(64, 1) else if (dwt_levels == 2) GO(256, 2)
   else if (C == 16) GO(16, 0) else if (C == 64) GO(64, 0) else if (C == 256) GO(256, 0)
   else return m2t_set_error(-2, "window_attn_bwd: C must be 16, 64 or 256");
 #undef GO
@@ -665,9 +671,9 @@ int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* 
 }
 int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
                            int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st,
-                           int dwt_levels, bool gather) {
+                           int dwt_levels, bool gather, bool resident) {
   if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn_bwd: h,w must be multiples of 8");
   if (dt == M2T_F32)
-    return launch_window_attn_bwd_t<float>((const float*)qkv, rel_h, rel_w, (const float*)gout, ldg, gc0, (float*)gqkv, (float*)win, relw, B, h, w, C, st, dwt_levels, gather);
-  return launch_window_attn_bwd_t<bf16_t>((const bf16_t*)qkv, rel_h, rel_w, (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, B, h, w, C, st, dwt_levels, gather);
+    return launch_window_attn_bwd_t<float>((const float*)qkv, rel_h, rel_w, (const float*)gout, ldg, gc0, (float*)gqkv, (float*)win, relw, B, h, w, C, st, dwt_levels, gather, resident);
+  return launch_window_attn_bwd_t<bf16_t>((const bf16_t*)qkv, rel_h, rel_w, (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, B, h, w, C, st, dwt_levels, gather, resident);
 }

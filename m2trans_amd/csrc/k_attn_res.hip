@@ -1,0 +1,444 @@
+// k_attn_res.hip -- "resident" backward of the 8x8 / 10x10 halo window attention (bf16, C = 64 / 256).
+//
+// Same mathematics as window_attn_bwd_kernel (k_attn.hip; models/M2Trans_network.py:310-332 under autograd)
+// but the whole window -- K^ (keys + rel-pos), V, dO and q for ALL channels -- is loaded from HBM once and
+// stays in LDS for both phases, so a window pays one exposed memory latency instead of eight
+// (C = 256: 4 channel chunks x 2 phases in the chunked kernel, and only one 4-wave workgroup per CU):
+//   phase 0  every global load of the window is issued, then written to LDS (dO through DWT^L when the
+//            branch's gradient is the DWT of a full-resolution slice);
+//   phase 1  S^T = K^ Q^T and dP^T = V dO^T; with 8 waves the keys are split in two halves per query
+//            tile and the softmax statistics are merged through LDS (online max/sum merge);
+//   phase 2  the channel tiles are split over the waves: each wave produces dV, dK^ and dq for its 16/32
+//            channels with the P / dS operands ([query][key]) shared through LDS; q (phase-1 registers) and
+//            P overlay V; the outputs leave through LDS as whole 16-byte-per-lane rows.
+// The relative-position gradient (dK^ summed over key columns / rows, phantom keys included) is one more
+// key tile of the dK^ product: sum_j dK^[10 i + j][c] = sum_q q[q][c] * (sum_j dS[q][10 i + j]), so the
+// row / column sums of dS are appended to dS as columns 128.. / 144.. and fall out of the same MFMA chain.
+// LDS (C = 256): K^ 53 328 + V 53 328 + dO 33 792 + dS 21 504 + stats 1 536 = 163 488 B of 163 840.
+// Measured (B=16, 32x32, C=256, MI355X): 20 us per launch against 54 us for the chunked kernel; a third of
+// it is phase 0 at the HBM fair share of a CU (all 256 workgroups load in lockstep).
+#include "m2t_kernels.h"
+#include "m2t_haar.h"
+#include "m2t_window.h"
+
+namespace {
+
+template <int C> struct ResCfg {
+  static constexpr int LD = C + 8;
+  static constexpr int KROWS = 101;                       // 100 keys + one zero row (all pad keys alias it)
+  static constexpr int PLD = 128 + 8;                     // P   [query][key 0..127]            (keys >= 100 are 0)
+  static constexpr int DLD = 160 + 8;                     // dS  [query][key 0..127 | 10 row sums @128 | 10 column sums @144]
+  static constexpr size_t szK = sizeof(bf16_t) * KROWS * LD;
+  static constexpr size_t szQ = sizeof(bf16_t) * 64 * LD;
+  static constexpr size_t szP = sizeof(bf16_t) * 64 * PLD;
+  static constexpr size_t szD = sizeof(bf16_t) * 64 * DLD;
+  static constexpr bool P_IN_V = (szQ + szP <= szK);
+  static constexpr size_t offV = szK;
+  static constexpr size_t offDO = 2 * szK;
+  static constexpr size_t offP = P_IN_V ? offV + szQ : offDO + szQ;
+  static constexpr size_t offD = P_IN_V ? offDO + szQ : offP + szP;
+  static constexpr size_t offRED = offD + szD;
+  static constexpr size_t total = offRED + sizeof(float) * 3 * 2 * 64;
+};
+
+// transposed 8-element operand: elements 0..3 = rows row_lo_base + 0..3, 4..7 = rows row_hi_base + 0..3 at
+// column col0 + (lane & 15); rows >= zero_row alias the zero row.  (see load8_tr in m2t_common.h)
+__device__ __forceinline__ Frag8<bf16_t> tr8(const bf16_t* base, int ld, int row_lo_base, int row_hi_base, int col0,
+                                             int lane, int zero_row) {
+  const int i = lane & 15, qq = i >> 2, pp = i & 3;
+  typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+  const int rlo = min(row_lo_base + qq, zero_row), rhi = min(row_hi_base + qq, zero_row);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(base + rlo * ld + col0 + 4 * pp));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(base + rhi * ld + col0 + 4 * pp));
+  Frag8<bf16_t> f;
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+
+// dO rows for the whole window: DOs[q][c], c over all C channels.
+// L = 0: plain rows of go (ld, channel offset coff).  L = 1, 2: go is the full-resolution g_xc tensor and the
+// branch gradient is DWT^L of its 16-channel slice: thread (q, 4-channel group) reads its (2^L)^2 pixel block
+// once and writes every band (band-major channel order, as torch.cat((LL,HL,LH,HH),1) nests).
+template <int C, int L, int NTHR>
+__device__ __forceinline__ void stage_go_all(bf16_t (*dst)[C + 8], const bf16_t* __restrict__ go, int ld, int coff,
+                                             const WinGeom& gm, int tid) {
+  if constexpr (L == 0) {
+    constexpr int VEC = C / 8;
+    constexpr int ITEMS = (64 * VEC + NTHR - 1) / NTHR;
+    Frag8<bf16_t> f[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * NTHR;
+      f[it] = frag_zero<bf16_t>();
+      if (idx < 64 * VEC) f[it] = load8(go + gm.query_pixel(idx / VEC) * ld + coff + (idx % VEC) * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * NTHR;
+      if (idx < 64 * VEC) store8(&dst[idx / VEC][(idx % VEC) * 8], f[it]);
+    }
+  } else {
+    static_assert(C == (16 << (2 * L)), "fused DWT needs C = 16 * 4^L");
+    constexpr int S = Haar<L>::S, N = Haar<L>::N;
+    if (tid < 256) {
+      const int q = tid >> 2, cg = tid & 3;
+      const int H = gm.h * S, W = gm.w * S;
+      const int by = 8 * gm.wy + (q >> 3), bx = 8 * gm.wx + (q & 7);
+      float v[4][S][S];
+#pragma unroll
+      for (int y = 0; y < S; ++y)
+#pragma unroll
+        for (int x = 0; x < S; ++x) {
+          float t4[4];
+          load4(go + (((long long)gm.b * H + S * by + y) * W + S * bx + x) * ld + coff + 4 * cg, t4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i][y][x] = t4[i];
+        }
+      float o[4][N];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Haar<L>::fwd(v[i], o[i]);
+#pragma unroll
+      for (int b = 0; b < N; ++b) {
+        float t4[4] = {o[0][b], o[1][b], o[2][b], o[3][b]};
+        store4(&dst[q][b * 16 + 4 * cg], t4);
+      }
+    }
+  }
+}
+
+template <int C, int L, int NW>
+__global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                                      const float* __restrict__ rel_w, const bf16_t* __restrict__ go,
+                                                                      int ldg, int gc0, bf16_t* __restrict__ gqkv,
+                                                                      bf16_t* __restrict__ win, float* __restrict__ relw, int h, int w) {
+  using T = bf16_t;
+  using Cfg = ResCfg<C>;
+  constexpr int LD = Cfg::LD, PLD = Cfg::PLD, DLD = Cfg::DLD, NTHR = NW * 64, VEC = C / 8, NT = C / 16, KH = NW / 4, TPW = NT / NW, NKC = C / 32;
+  constexpr int ZR = 100;                                  // the zero row of Kh / Vs
+  constexpr int NTL = (KH == 2) ? 4 : WA_KT;               // key tiles per wave in phase 1
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(NT % NW == 0 && TPW >= 1, "channel tiles must split evenly over the waves");
+  static_assert(Cfg::total <= 163840, "LDS budget");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T(*Kh)[LD] = reinterpret_cast<T(*)[LD]>(smem);
+  T(*Vs)[LD] = reinterpret_cast<T(*)[LD]>(smem + Cfg::offV);          // phase 1
+  T(*Qs)[LD] = reinterpret_cast<T(*)[LD]>(smem + Cfg::offV);          // phase 2 (aliases Vs)
+  T(*DOs)[LD] = reinterpret_cast<T(*)[LD]>(smem + Cfg::offDO);
+  T(*Pq)[PLD] = reinterpret_cast<T(*)[PLD]>(smem + Cfg::offP);        // [query][key]; inside the V region when it fits
+  T(*Dq)[DLD] = reinterpret_cast<T(*)[DLD]>(smem + Cfg::offD);
+  float(*red)[2][64] = reinterpret_cast<float(*)[2][64]>(smem + Cfg::offRED);   // [max | sum | delta][key half][query]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const WinGeom gm = make_geom(h, w);
+  const int qt = wv & 3, kh = wv >> 2;
+  const int q = 16 * qt + lr;
+  const long long qpix = gm.query_pixel(q);
+
+  // ---- phase 0: every global load of the window, then LDS ----
+  constexpr int KIT = (WA_NK * VEC + NTHR - 1) / NTHR;
+  {
+    Frag8<T> kf[KIT], vf[KIT];
+    f32x4 r0[KIT], r1[KIT];
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int idx = tid + it * NTHR;
+      const int cv = idx % VEC, key = idx / VEC;
+      kf[it] = frag_zero<T>();
+      vf[it] = frag_zero<T>();
+      r0[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      r1[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (key < WA_NK) {
+        long long pix;
+        if (gm.key_pixel(key, pix)) {
+          kf[it] = load8(qkv + pix * (3 * C) + C + cv * 8);
+          vf[it] = load8(qkv + pix * (3 * C) + 2 * C + cv * 8);
+        }
+        const int kr = key / 10, kc = key - kr * 10;
+        const int cc = cv * 8;
+        const float* rp = (cc < C / 2) ? (rel_h + kr * (C / 2) + cc) : (rel_w + kc * (C / 2) + (cc - C / 2));
+        r0[it] = *reinterpret_cast<const f32x4*>(rp);
+        r1[it] = *reinterpret_cast<const f32x4*>(rp + 4);
+      }
+    }
+    stage_go_all<C, L, NTHR>(DOs, go, ldg, gc0, gm, tid);
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int idx = tid + it * NTHR;
+      const int cv = idx % VEC, key = idx / VEC;
+      if (key < WA_NK) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = kf[it].get(e) + r0[it][e]; v[4 + e] = kf[it].get(4 + e) + r1[it][e]; }
+        store8f(&Kh[key][cv * 8], v);
+        store8(&Vs[key][cv * 8], vf[it]);
+      }
+    }
+    if (tid < VEC) {
+      store8(&Kh[ZR][tid * 8], frag_zero<T>());
+      store8(&Vs[ZR][tid * 8], frag_zero<T>());
+    }
+  }
+  Frag8<T> qreg[NKC];
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) qreg[kc] = load8(qkv + qpix * (3 * C) + kc * 32 + 8 * g);
+  __syncthreads();
+
+  // ---- phase 1: S^T = K^ Q^T and dP^T = V dO^T for (query tile qt, key tiles t0 .. t0 + NTL - 1) ----
+  const int t0 = kh * 4;
+  f32x4 s[NTL], dp[NTL];
+#pragma unroll
+  for (int tl = 0; tl < NTL; ++tl) { s[tl] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[tl] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) {
+    const Frag8<T> gf = load8(&DOs[q][kc * 32 + 8 * g]);
+#pragma unroll
+    for (int tl = 0; tl < NTL; ++tl) {
+      // (key tile 7 of the second half does not exist: its rows alias the zero row and its keys are masked)
+      const int row = min(16 * (t0 + tl) + lr, ZR);
+      const Frag8<T> kf = load8(&Kh[row][kc * 32 + 8 * g]);
+      mma16(s[tl], kf, qreg[kc]);
+      const Frag8<T> vf = load8(&Vs[row][kc * 32 + 8 * g]);
+      mma16(dp[tl], vf, gf);
+    }
+  }
+  // ---- softmax over the 100 keys and dS ----
+  const float scale = rsqrtf((float)C);
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int tl = 0; tl < NTL; ++tl)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * (t0 + tl) + 4 * g + r;
+      s[tl][r] = (key < WA_NK) ? s[tl][r] * scale : -3.0e38f;
+      mx = fmaxf(mx, s[tl][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int tl = 0; tl < NTL; ++tl)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * (t0 + tl) + 4 * g + r;
+      const float e = (key < WA_NK) ? __expf(s[tl][r] - mx) : 0.f;
+      s[tl][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  float inv;
+  if constexpr (KH == 2) {
+    if (g == 0) { red[0][kh][q] = mx; red[1][kh][q] = sum; }
+    __syncthreads();                    // also: every wave is done with the Kh / Vs reads of phase 1
+    const float m0 = red[0][0][q], m1 = red[0][1][q];
+    const float mm = fmaxf(m0, m1);
+    const float f0 = __expf(m0 - mm), f1 = __expf(m1 - mm);
+    const float tot = red[1][0][q] * f0 + red[1][1][q] * f1;
+    inv = (kh ? f1 : f0) / tot;
+  } else {
+    __syncthreads();
+    inv = 1.0f / sum;
+  }
+  float delta = 0.f;
+#pragma unroll
+  for (int tl = 0; tl < NTL; ++tl)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s[tl][r] *= inv;                  // P
+      delta += s[tl][r] * dp[tl][r];
+    }
+  delta += __shfl_xor(delta, 16);
+  delta += __shfl_xor(delta, 32);
+  if constexpr (KH == 2) {
+    if (g == 0) red[2][kh][q] = delta;
+    __syncthreads();
+    delta = red[2][0][q] + red[2][1][q];
+  }
+  // P and dS as [query][key]: a lane's four keys of a tile are contiguous (masked keys give exact zeros)
+#pragma unroll
+  for (int tl = 0; tl < NTL; ++tl) {
+    float pv[4], dv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pv[r] = s[tl][r]; dv[r] = s[tl][r] * (dp[tl][r] - delta) * scale; }
+    store4(&Pq[q][16 * (t0 + tl) + 4 * g], pv);
+    store4(&Dq[q][16 * (t0 + tl) + 4 * g], dv);
+  }
+  if constexpr (KH == 1) {              // keys 112..127 (contraction padding of dq)
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    store4(&Dq[q][112 + 4 * g], z);
+  }
+  if (kh == 0) {
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) store8(&Qs[q][kc * 32 + 8 * g], qreg[kc]);
+  }
+  __syncthreads();
+  // row / column sums of dS (over key columns j -> @128 + i, over key rows -> @144 + i)
+  for (int idx = tid; idx < 32 * 64; idx += NTHR) {
+    const int i = idx & 31, qq = idx >> 5;
+    float a = 0.f;
+    if (i < 10) {
+#pragma unroll
+      for (int j = 0; j < 10; ++j) a += to_f(Dq[qq][i * 10 + j]);
+    } else if (i >= 16 && i < 26) {
+#pragma unroll
+      for (int j = 0; j < 10; ++j) a += to_f(Dq[qq][j * 10 + (i - 16)]);
+    }
+    Dq[qq][128 + i] = from_f<T>(a);
+  }
+  __syncthreads();
+
+  // ---- phase 2: wave wv owns channel tiles wv*TPW .. wv*TPW + TPW - 1 ----
+  // The 16x16 output tiles (4 channels x 1 row per lane) go through LDS and leave as whole rows, 16 bytes per
+  // lane: dV -> the V region (q, P are dead once dV and dK^ are computed), dK^ -> the K^ region and dq -> the dO
+  // region (K^ is dead once dq is computed).
+  T(*VOUT)[LD] = Vs;
+  T(*KOUT)[LD] = Kh;
+  T(*QOUT)[LD] = DOs;
+  const long long wbase = (long long)blockIdx.x * WA_NK * (2 * C);
+  const int mt0 = wv * TPW;
+  // dV^T [c][key] = sum_q dO[q][c] P[q][key] ; dK^^T [c][key] = sum_q q[q][c] dS[q][key]; tile 7 of dK^ = the
+  // rel-pos sums of this tile's channel half
+  f32x4 av[TPW][WA_KT], ak[TPW][WA_KT + 1];
+#pragma unroll
+  for (int m = 0; m < TPW; ++m) {
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) av[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t <= WA_KT; ++t) ak[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) {
+    Frag8<T> a[TPW];
+#pragma unroll
+    for (int m = 0; m < TPW; ++m) a[m] = tr8(&DOs[0][0], LD, 32 * kc + 8 * g, 32 * kc + 8 * g + 4, 16 * (mt0 + m), lane, 64);
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const Frag8<T> b = tr8(&Pq[0][0], PLD, 32 * kc + 8 * g, 32 * kc + 8 * g + 4, 16 * t, lane, 64);
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) mma16(av[m][t], a[m], b);
+    }
+  }
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) {
+    Frag8<T> a[TPW];
+#pragma unroll
+    for (int m = 0; m < TPW; ++m) a[m] = tr8(&Qs[0][0], LD, 32 * kc + 8 * g, 32 * kc + 8 * g + 4, 16 * (mt0 + m), lane, 64);
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const Frag8<T> b = tr8(&Dq[0][0], DLD, 32 * kc + 8 * g, 32 * kc + 8 * g + 4, 16 * t, lane, 64);
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) mma16(ak[m][t], a[m], b);
+    }
+#pragma unroll
+    for (int m = 0; m < TPW; ++m) {
+      const int col0 = (16 * (mt0 + m) < C / 2) ? 128 : 144;
+      const Frag8<T> b = tr8(&Dq[0][0], DLD, 32 * kc + 8 * g, 32 * kc + 8 * g + 4, col0, lane, 64);
+      mma16(ak[m][WA_KT], a[m], b);
+    }
+  }
+  if (lr < 10) {
+#pragma unroll
+    for (int m = 0; m < TPW; ++m) {
+      float v[4] = {ak[m][WA_KT][0], ak[m][WA_KT][1], ak[m][WA_KT][2], ak[m][WA_KT][3]};
+      store4(relw + ((long long)blockIdx.x * 10 + lr) * C + 16 * (mt0 + m) + 4 * g, v);
+    }
+  }
+  __syncthreads();                      // every wave is done with dO, q and P
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) {
+    const int key = 16 * t + lr;
+    if (key < WA_NK) {
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) {
+        float u[4] = {av[m][t][0], av[m][t][1], av[m][t][2], av[m][t][3]};
+        store4(&VOUT[key][16 * (mt0 + m) + 4 * g], u);
+      }
+    }
+  }
+  // dq^T [c][q] = sum_keys K^[key][c] dS[q][key]
+  f32x4 o[TPW][4];
+#pragma unroll
+  for (int m = 0; m < TPW; ++m)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    Frag8<T> a[TPW];
+#pragma unroll
+    for (int m = 0; m < TPW; ++m) a[m] = tr8(&Kh[0][0], LD, 32 * c4 + 8 * g, 32 * c4 + 8 * g + 4, 16 * (mt0 + m), lane, ZR);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const Frag8<T> b = load8(&Dq[16 * t + lr][32 * c4 + 8 * g]);
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) mma16(o[m][t], a[m], b);
+    }
+  }
+  __syncthreads();                      // every wave is done with K^; the dV rows are complete
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) {
+    const int key = 16 * t + lr;
+    if (key < WA_NK) {
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) {
+        float v[4] = {ak[m][t][0], ak[m][t][1], ak[m][t][2], ak[m][t][3]};
+        store4(&KOUT[key][16 * (mt0 + m) + 4 * g], v);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int m = 0; m < TPW; ++m) {
+      float v[4] = {o[m][t][0], o[m][t][1], o[m][t][2], o[m][t][3]};
+      store4(&QOUT[16 * t + lr][16 * (mt0 + m) + 4 * g], v);
+    }
+  for (int idx = tid; idx < WA_NK * VEC; idx += NTHR) {
+    const int key = idx / VEC, cv = idx % VEC;
+    store8(win + wbase + (long long)key * (2 * C) + C + cv * 8, load8(&VOUT[key][cv * 8]));
+  }
+  __syncthreads();
+  for (int idx = tid; idx < WA_NK * VEC; idx += NTHR) {
+    const int key = idx / VEC, cv = idx % VEC;
+    store8(win + wbase + (long long)key * (2 * C) + cv * 8, load8(&KOUT[key][cv * 8]));
+  }
+  for (int idx = tid; idx < 64 * VEC; idx += NTHR) {
+    const int row = idx / VEC, cv = idx % VEC;
+    store8(gqkv + gm.query_pixel(row) * (3 * C) + cv * 8, load8(&QOUT[row][cv * 8]));
+  }
+}
+
+template <int C, int L, int NW>
+int go_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, const bf16_t* gout, int ldg, int gc0, bf16_t* gqkv,
+           bf16_t* win, float* relw, int nwin, int h, int w, hipStream_t st) {
+  const size_t sh = ResCfg<C>::total;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)window_attn_bwd_res_kernel<C, L, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((window_attn_bwd_res_kernel<C, L, NW>), dim3(nwin), dim3(NW * 64), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0,
+                     gqkv, win, relw, h, w);
+  return 0;
+}
+
+}  // namespace
+
+// bf16, C in {64, 256}, dwt_levels in {0, L(C)}; returns M2T_UNSUPPORTED otherwise (the caller then uses the chunked kernel)
+int launch_window_attn_bwd_resident(const void* qkv_, const float* rel_h, const float* rel_w, const void* gout_, int ldg, int gc0,
+                                    void* gqkv_, void* win_, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st) {
+  const bf16_t* qkv = (const bf16_t*)qkv_;
+  const bf16_t* gout = (const bf16_t*)gout_;
+  bf16_t* gqkv = (bf16_t*)gqkv_;
+  bf16_t* win = (bf16_t*)win_;
+  const int nwin = B * (h / 8) * (w / 8);
+  int rc = M2T_UNSUPPORTED;
+  if (C == 256 && dwt_levels == 2) rc = go_res<256, 2, 8>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st);
+  else if (C == 256 && dwt_levels == 0) rc = go_res<256, 0, 8>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st);
+  else if (C == 64 && dwt_levels == 1) rc = go_res<64, 1, 4>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st);
+  else if (C == 64 && dwt_levels == 0) rc = go_res<64, 0, 4>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st);
+  if (rc != 0) return rc;
+  M2T_LAUNCH_CHECK();
+  return 0;
+}

@@ -387,7 +387,7 @@ wgrad_tn_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ X, int l
 
 int wgrad_slab_count(long long M, int N, int K) {
   const int tn = ceil_div(N, 64), tk = ceil_div(K, 64);
-  const long long want = std::max<long long>(1, 1024 / (tn * tk));
+  const long long want = std::max<long long>(1, 512 / (tn * tk));
   return (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want, ceil_divll(M, WG_BM)));
 }
 
@@ -395,7 +395,7 @@ template <typename T>
 static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_t st) {
   if (a.K % 8 || a.N % 8) return m2t_set_error(-2, "wgrad_tn: N,K must be multiples of 8");
   const int tn = ceil_div(a.N, 64), tk = ceil_div(a.K, 64);
-  // enough slabs for ~4 workgroups per CU (the blocks are latency-bound); rows per slab a multiple of the 128-row step
+  // enough slabs for ~2 workgroups per CU (more slabs only inflate the deferred reduction); rows per slab a multiple of the 128-row step
   int nslab = wgrad_slab_count(a.M, a.N, a.K);
   long long rps = ceil_divll(ceil_divll(a.M, nslab), WG_BM) * WG_BM;
   nslab = (int)ceil_divll(a.M, rps);

@@ -668,27 +668,40 @@ __device__ __forceinline__ long long red_dest(long long e, int perm, int p0, int
 }
 __global__ void __launch_bounds__(256) multi_reduce_kernel(const float* __restrict__ arena, float* __restrict__ grads,
                                                            const m2t_red_desc* __restrict__ descs) {
+  // 64 consecutive elements per chunk; the four waves split the slabs (wave g takes s = g, g+4, ...), each
+  // with four independent partial sums in flight, then a fixed-order combine through LDS -> deterministic
   const m2t_red_desc d = descs[blockIdx.y];
   const float* slab = arena + d.src_off;
   float* out = grads + d.dst_off;
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < d.n; e += (long long)gridDim.x * blockDim.x) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long long nchunk = (d.n + 63) / 64;
+  for (long long ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+    const long long e = ch * 64 + lane;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = 0;
-    for (; s + 3 < d.ns; s += 4) {
-      a0 += slab[(long long)s * d.n + e];
-      a1 += slab[(long long)(s + 1) * d.n + e];
-      a2 += slab[(long long)(s + 2) * d.n + e];
-      a3 += slab[(long long)(s + 3) * d.n + e];
+    if (e < d.n) {
+      int s = g;
+      for (; s + 12 < d.ns; s += 16) {
+        a0 += slab[(long long)s * d.n + e];
+        a1 += slab[(long long)(s + 4) * d.n + e];
+        a2 += slab[(long long)(s + 8) * d.n + e];
+        a3 += slab[(long long)(s + 12) * d.n + e];
+      }
+      for (; s < d.ns; s += 4) a0 += slab[(long long)s * d.n + e];
     }
-    for (; s < d.ns; ++s) a0 += slab[(long long)s * d.n + e];
-    bool skip;
-    const long long dst = red_dest(e, d.perm, d.p0, d.p1, d.p2, skip);
-    if (!skip) out[dst] = (a0 + a1) + (a2 + a3);
+    sh[g][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (g == 0 && e < d.n) {
+      bool skip;
+      const long long dst = red_dest(e, d.perm, d.p0, d.p1, d.p2, skip);
+      if (!skip) out[dst] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    }
+    __syncthreads();
   }
 }
 int launch_multi_reduce(const float* arena, float* grads, const m2t_red_desc* descs, int ndesc, hipStream_t st) {
   if (ndesc <= 0) return 0;
-  hipLaunchKernelGGL(multi_reduce_kernel, dim3(48, ndesc), dim3(256), 0, st, arena, grads, descs);
+  hipLaunchKernelGGL(multi_reduce_kernel, dim3(96, ndesc), dim3(256), 0, st, arena, grads, descs);
   M2T_LAUNCH_CHECK();
   return 0;
 }

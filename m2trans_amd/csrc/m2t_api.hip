@@ -87,6 +87,7 @@ struct m2t_plan {
   bool use_side = true;
   bool use_fused_tail = false;     // measured: ties the three-kernel sequence (42 us per branch either way)
   bool debug_skip_side = false;    // timing experiments only: skip every parameter-gradient kernel (results are WRONG)      // halo gather + qkv dgrad GEMM + prep_bwd as one kernel (k_branch.hip)
+  bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
   bool use_fused_branch = false;   // fused forward branch kernel (k_branch.hip): correct, currently ties the unfused chain
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
   // region; the descriptor table is identical every step, so it is uploaded once
@@ -562,7 +563,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       // into gqkv for the weight-gradient GEMM, multiplies by Wqkv and applies IWT / branch mixing.
       // (gathering inside the TILED GEMM / wgrad loaders, M2T_A_HALO, was measured slower: the gather is then
       //  repeated once per column-block.)
-      CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 16 * i, gqkv, win, relw, B, h, w, C, st, L, !p->use_fused_tail));
+      CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 16 * i, gqkv, win, relw, B, h, w, C, st, L, !p->use_fused_tail, p->use_resident_attn_bwd));
       if (p->use_fused_tail)
         CK(launch_branch_bwd_tail(dt, L, gqkv, win, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T"), gxc, gn, i, B, h, w, st));
       fork();
@@ -630,6 +631,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "side_stream") { p->use_side = (value != 0); return 0; }
   if (std::string(key) == "fused_branch") { p->use_fused_branch = (value != 0); return 0; }
   if (std::string(key) == "fused_tail") { p->use_fused_tail = (value != 0); return 0; }
+  if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
   if (std::string(key) == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
   return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");
 }

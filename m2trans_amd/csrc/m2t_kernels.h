@@ -134,7 +134,11 @@ int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const fl
 int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
                            int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st,
                            int dwt_levels = 0,    // 1, 2: gout is the FULL-RES g_xc tensor; DWT^levels applied on load
-                           bool gather = true);   // false: leave dK|dV in `win` (consumers gather with M2T_A_HALO)
+                           bool gather = true,    // false: leave dK|dV in `win` (consumers gather with M2T_A_HALO)
+                           bool resident = true); // bf16, C = 64 / 256: whole-window-resident kernel (k_attn_res.hip)
+// the resident kernel alone (bf16); M2T_UNSUPPORTED when (C, dwt_levels) has no instantiation
+int launch_window_attn_bwd_resident(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
+                                    void* gqkv, void* win, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st);
 // relw [nwin][10][C] per-window partials -> grel_h / grel_w (torch layouts)
 int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st);
 int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int* nsplit_out, hipStream_t st);
