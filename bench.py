@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--all-kernel-events", action="store_true", help="time every kernel category in the timed region (adds ~8%% overhead)")
+    ap.add_argument("--null-stream", action="store_true", help="run on the legacy default stream instead of a torch stream")
     ap.add_argument("--no-side-stream", action="store_true", help="run the whole backward on one stream")
     ap.add_argument("--debug-skip-side", action="store_true", help="TIMING EXPERIMENT: skip all parameter-gradient kernels (wrong results)")
     ap.add_argument("--semantic-loss", action="store_true",
@@ -152,6 +153,11 @@ def main():
 
     from m2trans_amd import profile as m2t_profile
     dominant_mask = 0
+    # a non-default stream: the plan's CU-masked side stream is a blocking stream and would serialise
+    # against the legacy default stream
+    if not args.null_stream:
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.Stream(device=device))
     for s in range(args.warmup):
         if rank == 0 and not args.no_kernel_events and s == args.warmup - 1:
             m2t_profile.enable()      # last warm-up step: time every category to find the dominant kernel

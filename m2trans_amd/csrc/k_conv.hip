@@ -70,6 +70,44 @@ int launch_head_conv_fwd(int dt, const float* x, const float* w, const float* b,
   return 0;
 }
 
+// im2col of the (padded, reflect-extended) head input: cols[pixel][32], column k = ic*9 + ky*3 + kx (27 used,
+// the rest 0), so the head weight gradient is one [64 x M] x [M x 32] product for the generic wgrad GEMM
+// (gradient rows on the MFMA rows, contraction over pixels) and the bias gradient rides along in it.
+template <typename T>
+__global__ void __launch_bounds__(256) head_im2col_kernel(const float* __restrict__ x, T* __restrict__ cols, int B, int H0,
+                                                          int W0, int H, int W) {
+  const long long total = (long long)B * H * W * 4;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(t & 3);
+    const long long pix = t >> 2;
+    const int xx = (int)(pix % W);
+    const long long q = pix / W;
+    const int yy = (int)(q % H);
+    const int b = (int)(q / H);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * j + e;
+      v[e] = 0.f;
+      if (k < 27) {
+        const int ic = k / 9, tap = k - 9 * ic, ky = tap / 3, kx = tap - 3 * ky;
+        const int sy = head_src(yy + ky - 1, H, H0), sx = head_src(xx + kx - 1, W, W0);
+        v[e] = x[(((long long)b * 3 + ic) * H0 + sy) * W0 + sx];
+      }
+    }
+    store8f(cols + pix * 32 + 8 * j, v);
+  }
+}
+int launch_head_im2col(int dt, const float* x, void* cols, int B, int H0, int W0, int H, int W, hipStream_t st) {
+  const long long total = (long long)B * H * W * 4;
+  const int g = (int)std::min<long long>(ceil_divll(total, 256), 4096);
+  if (dt == M2T_F32) hipLaunchKernelGGL(head_im2col_kernel<float>, dim3(g), dim3(256), 0, st, x, (float*)cols, B, H0, W0, H, W);
+  else hipLaunchKernelGGL(head_im2col_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x, (bf16_t*)cols, B, H0, W0, H, W);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
 // head conv weight gradient: dW[oc][ic*9+tap] = sum_pixels g[p][oc] * xsrc(p, ic, tap)
 // thread (oc = tid&63, part = tid>>6); block = contiguous pixel range; slabs [nblk][64*27]
 template <typename T>

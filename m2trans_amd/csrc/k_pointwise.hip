@@ -660,6 +660,10 @@ __device__ __forceinline__ long long red_dest(long long e, int perm, int p0, int
     const int ic = (int)(e & 63), nn = (int)(e >> 6);
     if (nn >= 27) { skip = true; return 0; }
     return ((long long)(nn % 3) * 64 + ic) * 9 + nn / 3;
+  } else if (perm == 5) {    // rows padded from p1 to p0 columns (head conv: [64][32] -> [64][27])
+    const int kk = (int)(e % p0);
+    if (kk >= p1) { skip = true; return 0; }
+    return (e / p0) * p1 + kk;
   } else if (perm == 4) {    // rel-pos [10][C] -> rel_h [10][C/2] followed by rel_w [10][C/2]; p0 = C
     const int c = (int)(e % p0), i = (int)(e / p0);
     return (c < p0 / 2) ? ((long long)i * (p0 / 2) + c) : ((long long)10 * (p0 / 2) + (long long)i * (p0 / 2) + (c - p0 / 2));

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <cstdio>
 #include "m2t_kernels.h"
+#include <cstdlib>
 #include "../../include/m2t.h"
 
 static thread_local std::string g_err;
@@ -87,6 +88,7 @@ struct m2t_plan {
   bool use_side = true;
   bool use_fused_tail = false;     // measured: ties the three-kernel sequence (42 us per branch either way)
   bool debug_skip_side = false;    // timing experiments only: skip every parameter-gradient kernel (results are WRONG)      // halo gather + qkv dgrad GEMM + prep_bwd as one kernel (k_branch.hip)
+  bool use_gated_side = true;      // see the side-stream schedule in m2t_backward
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
   bool use_fused_branch = false;   // fused forward branch kernel (k_branch.hip): correct, currently ties the unfused chain
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
@@ -95,10 +97,23 @@ struct m2t_plan {
   bool red_uploaded = false;
   size_t arena_floats = 0;
   hipStream_t side = nullptr;
+  int side_cus = 0;                // CUs the side stream may use (0 = all; masking measured slower: 9.1-20 ms vs 8.7 ms)
   std::vector<hipEvent_t> events;
-  int ensure_side() {
+  int ensure_side(hipStream_t caller) {
     if (side) return 0;
-    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return -1;
+    // The parameter-gradient kernels are filler.  They run on a CU-masked stream (side_cus of the chip's CUs; the
+    // mask bits interleave over the XCDs) so that main-chain workgroups always find empty CUs: a 160 KB-LDS
+    // attention workgroup otherwise starves until a concurrent wgrad kernel has drained completely.
+    int ncu = 0;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
+    const char* ev = getenv("M2T_SIDE_CUS");
+    int cus = ev ? atoi(ev) : side_cus;
+    // (a CU-masked stream is a BLOCKING stream: against the legacy default stream it would serialise)
+    if (cus > 0 && cus < ncu && caller != nullptr) {
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+      for (int i = 0; i < cus; ++i) mask[i / 32] |= 1u << (i % 32);
+      if (hipExtStreamCreateWithCUMask(&side, (uint32_t)mask.size(), mask.data()) != hipSuccess) return -1;
+    } else if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return -1;
     events.resize(192);
     for (auto& e : events)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
@@ -227,12 +242,12 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("gn", BP * 64, es);
   p->add_ws("ga", BP * 16, es);
   p->add_ws("gd", BP * 16, es);
-  p->add_ws("gqkv0", BP * 48, es);
-  p->add_ws("gqkv1", BP * 48, es);
-  p->add_ws("win0", BP * 50, es);
-  p->add_ws("win1", BP * 50, es);
-  p->add_ws("relw0", (size_t)(BP / 64) * 10 * 16, 4);
-  p->add_ws("relw1", (size_t)(BP / 64) * 10 * 16, 4);
+  p->add_ws("head_cols", BP * 32, es);
+  for (int i = 0; i < 4; ++i) {     // one set per branch: the side stream may lag the main chain by a whole block
+    p->add_ws("gqkv" + std::to_string(i), BP * 48, es);
+    p->add_ws("win" + std::to_string(i), BP * 50, es);
+    p->add_ws("relw" + std::to_string(i), (size_t)(BP / 64) * 10 * 16, 4);
+  }
   p->add_ws("rel_part", 32 * 10 * 256, 4);
   {
     // arena: every slab set of one backward pass (see m2t_backward); sized from the launchers' slab rules
@@ -240,7 +255,7 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
     per_block += (size_t)1024 * 768 + (size_t)512 * 12288 + 2 * (size_t)32 * 196608; // qkv wgrads (upper bounds)
     per_block += 4 * (size_t)32 * 2560;                                               // rel-pos partials
     size_t tail = 2 * (size_t)256 * (16384 + 36864) + (size_t)1024 * 2048 + 4 * (size_t)256 * 768 + (size_t)256 * 1728 * 2;
-    p->arena_floats = per_block * n_blocks + tail + (1u << 20);
+    p->arena_floats = per_block * n_blocks + tail + (size_t)512 * (64 * 32 + 64) + (1u << 20);
     p->add_ws("arena", p->arena_floats, 4);
     p->add_ws("red_descs", 512 * sizeof(m2t_red_desc), 1);
   }
@@ -410,7 +425,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   if (!p->have_acts || !p->have_seed)
     return m2t_set_error(M2T_ERR_STATE, "m2t_backward: needs m2t_forward and a seed (m2t_l1_loss / m2t_set_output_grad)");
   hipStream_t st = (hipStream_t)stream;
-  if (p->ensure_side() != 0) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: cannot create the side stream / events");
+  if (p->ensure_side(st) != 0) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: cannot create the side stream / events");
   hipStream_t sd = p->use_side ? p->side : st;
   size_t evi = 0;
   auto next_event = [&]() -> hipEvent_t { return p->events[(evi++) % p->events.size()]; };
@@ -468,6 +483,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   void* g_last = (s == 4) ? WSP("g_t2pre") : WSP("g_t1pre");
   const bool skip = p->debug_skip_side;
   fork();
+  if (!skip) CK(launch_head_im2col(dt, x, WSP("head_cols"), B, p->H0, p->W0, H, W, sd));
   if (!skip) {
     float* slabs = arena_alloc((size_t)1024 * 32 * 64);
     { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, sd); CK(launch_final_conv_wgrad(dt, gpre, last_pre, slabs, &ns, B, p->Hsp, p->Wsp, sd)); }
@@ -516,12 +532,18 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   // ---- body, last block first.  gy = gradient of X[b+1] ----
   void* gy = WSP("gT");
   void* gnext[2] = {WSP("gA"), WSP("gB")};
-  void* gqkv_buf[2] = {WSP("gqkv0"), WSP("gqkv1")};
-  float* relw_buf[2] = {(float*)WSP("relw0"), (float*)WSP("relw1")};
-  void* win_buf[2] = {WSP("win0"), WSP("win1")};
-  hipEvent_t branch_done[2] = {nullptr, nullptr};
+  void* gqkv_buf[4] = {WSP("gqkv0"), WSP("gqkv1"), WSP("gqkv2"), WSP("gqkv3")};
+  float* relw_buf[4] = {(float*)WSP("relw0"), (float*)WSP("relw1"), (float*)WSP("relw2"), (float*)WSP("relw3")};
+  void* win_buf[4] = {WSP("win0"), WSP("win1"), WSP("win2"), WSP("win3")};
+  hipEvent_t branch_done[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t conv_done_prev = nullptr;      // side finished reading gy of the previously processed block
-  int counter = 0;
+  // Side-stream schedule.  The two C = 256 attention kernels that open a block need a whole CU's LDS per workgroup
+  // (k_attn_res.hip): any concurrent parameter-gradient kernel starves them until it has drained (measured:
+  // 70 us instead of 25 us per launch).  So the block's side work is GATED: nothing of it is enqueued before the
+  // second C = 256 attention (+ its halo gather) has been issued on the main stream; the conv / branch-4 / branch-3
+  // weight gradients then run under the C = 64 / C = 16 branches, the norm backward and the next block's conv
+  // data gradient, which leave LDS free.  Each branch has its own gqkv / win / relw buffers, so the lag is harmless.
+  const bool gated = p->use_gated_side && sd != st;
   for (int b = p->nb - 1; b >= 0; --b) {
     const std::string k = "b" + std::to_string(b) + ".";
     const std::string pre = "body." + std::to_string(b) + ".";
@@ -531,33 +553,56 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     void* xc = WSP(k + "xc");
     void* gxc = WSP("gxc");
     void* gn = WSP("gn");
+    void* gy_blk = gy;
     // feed_forward conv: weight / bias gradients on the side stream, data gradient on the main one
-    fork();
-    if (!skip) {
+    auto side_conv = [&]() -> int {
+      if (skip) return 0;
       float* slabs = arena_alloc((size_t)256 * 9 * 64 * 64);
       float* colp = arena_alloc((size_t)256 * 64);
-      { M2TProfScope ps(M2T_PROF_CONV3_WGRAD, sd); CK(launch_conv3x3_c64_wgrad(dt, xc, gy, slabs, &ns, B, H, W, sd)); }
+      { M2TProfScope ps(M2T_PROF_CONV3_WGRAD, sd); CK(launch_conv3x3_c64_wgrad(dt, xc, gy_blk, slabs, &ns, B, H, W, sd)); }
       defer(slabs, p->poff.at(pre + "feed_forward.0.weight"), ns, 9 * 64 * 64, 1, 64, 64, 0);
       int nb2 = 0;
-      CK(launch_colsum(dt, gy, 64, BP, 64, colp, 256, nullptr, 0, sd, 0, 0, 0, 1, 64, &nb2));
+      CK(launch_colsum(dt, gy_blk, 64, BP, 64, colp, 256, nullptr, 0, sd, 0, 0, 0, 1, 64, &nb2));
       defer(colp, p->poff.at(pre + "feed_forward.0.bias"), nb2, 64, 0, 0, 0, 0);
+      return 0;
+    };
+    auto side_branch = [&](int i) -> int {     // qkv weight gradient + rel-pos partial reduction of branch i
+      if (skip) return 0;
+      const int C = BR_C[i], L = BR_L[i];
+      const int h = H >> L, w = W >> L;
+      const long long M = (long long)B * h * w;
+      const std::string an = pre + "attn" + std::to_string(i + 1) + ".";
+      float* slabs = arena_alloc((size_t)wgrad_slab_count(M, 3 * C, C) * 3 * C * C);
+      m2t_wgrad_args wa{};
+      wa.G = gqkv_buf[i]; wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = WSP(k + "d" + std::to_string(i + 1)); wa.ldx = C; wa.xmode = M2T_A_PLAIN;
+      wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = h; wa.Wd = w; wa.r = 1; wa.C = C; wa.halo_win = win_buf[i];
+      { M2TProfScope ps(M2T_PROF_WGRAD_QKV, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
+      defer(slabs, p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0);
+      float* relp = arena_alloc((size_t)32 * 10 * C);
+      int nsp = 0;
+      CK(launch_rel_reduce1(relw_buf[i], relp, (int)(M / 64), C, &nsp, sd));
+      defer(relp, p->poff.at(an + "rel_h"), nsp, 10LL * C, 4, C, 0, 0);     // rel_h then rel_w are adjacent parameters
+      return 0;
+    };
+    hipEvent_t conv_done = nullptr;
+    if (!gated) {
+      fork();
+      CK(side_conv());
+      conv_done = side_marker();
     }
-    hipEvent_t conv_done = side_marker();
     { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st)); }
     for (int i = 3; i >= 0; --i) {
       const int C = BR_C[i], L = BR_L[i];
       const int h = H >> L, w = W >> L;
       const long long M = (long long)B * h * w;
       const std::string an = pre + "attn" + std::to_string(i + 1) + ".";
-      const void* d = WSP(k + "d" + std::to_string(i + 1));
       const void* qkv = WSP(k + "qkv" + std::to_string(i + 1));
       const float* rh = params + p->poff.at(an + "rel_h");
       const float* rw = params + p->poff.at(an + "rel_w");
-      const int bi = (counter++) & 1;
-      void* gqkv = gqkv_buf[bi];
-      void* win = win_buf[bi];
-      float* relw = relw_buf[bi];
-      main_wait(branch_done[bi]);            // side consumers of this gqkv / relw buffer (two branches ago) are done
+      void* gqkv = gqkv_buf[i];
+      void* win = win_buf[i];
+      float* relw = relw_buf[i];
+      main_wait(branch_done[i]);             // the side consumers of this branch's buffers (previous block) are done
       // gradient of IWT^L is DWT^L: applied while the kernel loads g_xc[chunk i]
       // dK|dV stay window-major in `win`; the fused tail kernel gathers them once per row, writes them back
       // into gqkv for the weight-gradient GEMM, multiplies by Wqkv and applies IWT / branch mixing.
@@ -566,20 +611,23 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 16 * i, gqkv, win, relw, B, h, w, C, st, L, !p->use_fused_tail, p->use_resident_attn_bwd));
       if (p->use_fused_tail)
         CK(launch_branch_bwd_tail(dt, L, gqkv, win, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T"), gxc, gn, i, B, h, w, st));
-      fork();
-      if (!skip) {
-        float* slabs = arena_alloc((size_t)wgrad_slab_count(M, 3 * C, C) * 3 * C * C);
-        m2t_wgrad_args wa{};
-        wa.G = gqkv; wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = d; wa.ldx = C; wa.xmode = M2T_A_PLAIN;
-        wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = h; wa.Wd = w; wa.r = 1; wa.C = C; wa.halo_win = win;
-        { M2TProfScope ps(M2T_PROF_WGRAD_QKV, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
-        defer(slabs, p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0);
-        relp = arena_alloc((size_t)32 * 10 * C);
-        int nsp = 0;
-        CK(launch_rel_reduce1(relw, relp, (int)(M / 64), C, &nsp, sd));
-        defer(relp, p->poff.at(an + "rel_h"), nsp, 10LL * C, 4, C, 0, 0);     // rel_h then rel_w are adjacent parameters
+      if (!gated) {
+        fork();
+        CK(side_branch(i));
+        branch_done[i] = side_marker();
+      } else if (i == 2) {
+        fork();                              // the gate: both C = 256 attention kernels are on their way
+        CK(side_conv());
+        conv_done = side_marker();
+        CK(side_branch(3));
+        branch_done[3] = side_marker();
+        CK(side_branch(2));
+        branch_done[2] = side_marker();
+      } else if (i < 2) {
+        fork();
+        CK(side_branch(i));
+        branch_done[i] = side_marker();
       }
-      branch_done[bi] = side_marker();
       if (!p->use_fused_tail) {
         m2t_gemm_args ga{};
         ga.A = gqkv; ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
@@ -600,13 +648,16 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   CK(launch_add(dt, gy, WSP("gT"), WSP("gxc"), BP * 64, st));
   fork();
   if (!skip) {
-    float* slabs = arena_alloc((size_t)256 * 64 * 27);
-    float* colp = arena_alloc((size_t)256 * 64);
-    CK(launch_head_conv_wgrad(dt, x, WSP("gxc"), slabs, &ns, B, p->H0, p->W0, H, W, sd));
-    defer(slabs, p->poff.at("head.weight"), ns, 64 * 27, 0, 0, 0, 0);
-    int nb2 = 0;
-    CK(launch_colsum(dt, WSP("gxc"), 64, BP, 64, colp, 256, nullptr, 0, sd, 0, 0, 0, 1, 64, &nb2));
-    defer(colp, p->poff.at("head.bias"), nb2, 64, 0, 0, 0, 0);
+    // head conv: im2col'd input (made at the start of this backward, off the critical path) x output gradient
+    const int nsl = wgrad_slab_count(BP, 64, 32);
+    float* slabs = arena_alloc((size_t)nsl * 64 * 32);
+    float* colp = arena_alloc((size_t)nsl * 64);
+    m2t_wgrad_args wa{};
+    wa.G = WSP("gxc"); wa.ldg = 64; wa.gmode = M2T_A_PLAIN; wa.X = WSP("head_cols"); wa.ldx = 32; wa.xmode = M2T_A_PLAIN;
+    wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = 64; wa.K = 32; wa.H = H; wa.Wd = W; wa.r = 1; wa.C = 64;
+    CK(launch_wgrad_tn(dt, wa, &ns, sd));
+    defer(slabs, p->poff.at("head.weight"), ns, 64 * 32, 5, 32, 27, 0);
+    defer(colp, p->poff.at("head.bias"), ns, 64, 0, 0, 0, 0);
   }
   if (!p->red_uploaded) {
     // first backward of this plan: publish the (step-invariant) descriptor table, then reduce everything
@@ -631,6 +682,8 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "side_stream") { p->use_side = (value != 0); return 0; }
   if (std::string(key) == "fused_branch") { p->use_fused_branch = (value != 0); return 0; }
   if (std::string(key) == "fused_tail") { p->use_fused_tail = (value != 0); return 0; }
+  if (std::string(key) == "gated_side") { p->use_gated_side = (value != 0); return 0; }
+  if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
   if (std::string(key) == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
   return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");

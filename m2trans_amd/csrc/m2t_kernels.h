@@ -96,6 +96,7 @@ int wgrad_slab_count(long long M, int N, int K);   // upper bound of the slabs l
 // ---- k_conv.hip -------------------------------------------------------------------------
 int launch_head_conv_fwd(int dt, const float* x, const float* w, const float* b, void* out, int B, int H0, int W0,
                          int H, int W, hipStream_t st);
+int launch_head_im2col(int dt, const float* x, void* cols, int B, int H0, int W0, int H, int W, hipStream_t st);   // cols [B*H*W][32] (T)
 int launch_head_conv_wgrad(int dt, const float* x, const void* gout, float* slabs, int* nslab, int B, int H0, int W0,
                            int H, int W, hipStream_t st);
 // 64->64 3x3, zero padding.  wp: packed [9][64 out][64 in] (T). y = conv(x) + bias + res1 + res2 (each optional)
