@@ -417,7 +417,8 @@ int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs
 }
 
 // =======================================================================================
-// tail conv 64 -> 3, reflect padding, no bias; input = GELU(tpre) applied while staging.
+// tail conv 64 -> 3, reflect padding, no bias; input = the activation gelu(t) stored by tail_expand (`tpre`
+// below names that tensor; `tder` the stored derivative gelu'(t)).
 // N = 3 is too thin for a direct MFMA mapping, so the 9 taps are folded into the N axis:
 //     Y[p][(tap,oc)] = sum_ic act[p][ic] * w[oc][ic][tap]          (K = 64, N = 27 -> 32)
 //     out[o][oc]     = sum_tap Y[o + off(tap)][(tap,oc)]            (9 shifted adds from LDS)
@@ -430,7 +431,7 @@ int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs
 #define FC_HPP 352                        // padded to 11 contraction chunks of 32
 #define FC_LD 72
 
-// halo tile of GELU(tpre) (reflect addressing), rows >= 324 zero
+// halo tile of the stored activation gelu(t) (reflect addressing), rows >= 324 zero
 template <typename T>
 __device__ __forceinline__ void final_stage_act(T (*As)[FC_LD], const T* __restrict__ tb, int y0, int x0, int H, int W, int tid) {
   constexpr int ITEMS = FC_HPP * 8 / 256;   // 11
@@ -450,10 +451,6 @@ __device__ __forceinline__ void final_stage_act(T (*As)[FC_LD], const T* __restr
   for (int it = 0; it < ITEMS; ++it) {
     const int idx = tid + it * 256;
     const int cv = idx & 7, p = idx >> 3;
-    if (p < FC_HP) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[it].set(e, gelu_erf(f[it].get(e)));
-    }
     store8(&As[p][cv * 8], f[it]);
   }
 }
@@ -544,7 +541,7 @@ int launch_final_conv_fwd(int dt, const void* tpre, const float* w, float* out, 
 
 // ---------------------------------------------------------------------------------------
 // tail conv data gradient (+ GELU backward):
-//   g_act[p][ic] = sum_{(tap,oc)} Geff[p][(tap,oc)] * w[oc][ic][tap],   g_tpre = g_act * GELU'(tpre)
+//   g_act[p][ic] = sum_{(tap,oc)} Geff[p][(tap,oc)] * w[oc][ic][tap],   g_t = g_act * gelu'(t)  (tpre = stored derivative)
 // Geff gathers gout at the output positions that read input pixel p through `tap`, INCLUDING the
 // reads that reached p through the reflect padding (rows/cols 1 and n-2 also serve the padded
 // ring positions -1 and n).  GEMM: M = 256 tile pixels, K = 27 -> 32, N = 64.
@@ -632,7 +629,7 @@ __global__ void __launch_bounds__(256) final_conv_dgrad_kernel(const float* __re
       for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[nt][r];
     load16f(tpre + pix * 64 + 16 * g, pp);
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] *= gelu_erf_grad(pp[e]);
+    for (int e = 0; e < 16; ++e) v[e] *= pp[e];          // stored gelu'(t)
     store16f(gt + pix * 64 + 16 * g, v);
   }
 }

@@ -22,8 +22,8 @@
 template <typename T, int AMODE, int EMODE>
 __global__ void __launch_bounds__(256)
 gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __restrict__ Y, int ldy,
-               const float* __restrict__ bias, const T* __restrict__ aux, int ldaux, long long M, int N, int K,
-               ShufGeom sg) {
+               const float* __restrict__ bias, const T* __restrict__ aux, int ldaux, T* __restrict__ Y2, long long M, int N,
+               int K, ShufGeom sg) {
   __shared__ __attribute__((aligned(16))) T As[GEMM_BM][GEMM_BK + GEMM_PAD];
   __shared__ __attribute__((aligned(16))) T Ws[GEMM_BN][GEMM_BK + GEMM_PAD];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -103,14 +103,16 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __r
       const int sub = nn / sg.C, c0 = nn - sub * sg.C;
       const int i = sub / sg.r, j = sub - i * sg.r;
       const int rr = sg.r * sg.r;
+      float dv[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] += bias[(c0 + e) * rr + sub];
+      for (int e = 0; e < 16; ++e) gelu_erf_both(v[e] + bias[(c0 + e) * rr + sub], v[e], dv[e]);   // activation + derivative
       const int w = (int)(m % sg.W);
       const long long q = m / sg.W;
       const int h = (int)(q % sg.H);
       const long long b = q / sg.H;
       const long long pix = (b * sg.H * sg.r + (h * sg.r + i)) * ((long long)sg.W * sg.r) + (w * sg.r + j);
       store16f(Y + pix * sg.C + c0, v);
+      store16f(Y2 + pix * sg.C + c0, dv);
     } else if (EMODE == M2T_E_BIAS_GELU) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = gelu_erf(v[e] + bias[nn + e]);
@@ -121,11 +123,11 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] += (bias ? bias[nn + e] : 0.f) + p[e];
       store16f(Y + m * ldy + nn, v);
-    } else {   // M2T_E_GELU_GRAD
+    } else {   // M2T_E_GELU_GRAD: aux holds the stored derivative gelu'(t)
       float p[16];
       load16f(aux + m * ldaux + nn, p);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] *= gelu_erf_grad(p[e]);
+      for (int e = 0; e < 16; ++e) v[e] *= p[e];
       store16f(Y + m * ldy + nn, v);
     }
   }
@@ -138,11 +140,10 @@ static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStr
   ShufGeom sg{a.H, a.Wd, a.r, a.C, a.halo_win};
 #define GO(AM, EM)                                                                                              \
   hipLaunchKernelGGL((gemm_nt_kernel<T, AM, EM>), grid, dim3(256), 0, st, (const T*)a.A, a.lda, (const T*)a.W, \
-                     (T*)a.Y, a.ldy, a.bias, (const T*)a.aux, a.ldaux, a.M, a.N, a.K, sg)
+                     (T*)a.Y, a.ldy, a.bias, (const T*)a.aux, a.ldaux, (T*)a.Y2, a.M, a.N, a.K, sg)
   if (amode == M2T_A_PLAIN && emode == M2T_E_PLAIN) GO(M2T_A_PLAIN, M2T_E_PLAIN);
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS) GO(M2T_A_PLAIN, M2T_E_BIAS);
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_SHUF) GO(M2T_A_PLAIN, M2T_E_BIAS_SHUF);
-  else if (amode == M2T_A_GELU && emode == M2T_E_BIAS_SHUF) GO(M2T_A_GELU, M2T_E_BIAS_SHUF);
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_GELU) GO(M2T_A_PLAIN, M2T_E_BIAS_GELU);
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_RESID) GO(M2T_A_PLAIN, M2T_E_BIAS_RESID);
   else if (amode == M2T_A_HALO && emode == M2T_E_PLAIN) GO(M2T_A_HALO, M2T_E_PLAIN);
@@ -165,11 +166,15 @@ int launch_gemm_nt(int dt, int amode, int emode, const m2t_gemm_args& a, hipStre
 // weight matrix in LDS and sweeps 128-row tiles: the activation tile is staged once (GELU applied once, not
 // once per 64-column block), the next tile's global loads fly while the current one is multiplied, and each
 // 64-column group is exactly one sub-pixel, so a lane stores 16 consecutive channels of one output pixel.
+// Every expansion of the reference's tail is followed by GELU (:43-46,52-53), and the erf behind it is what
+// bounds the high-resolution kernels (VALU, not HBM): so the epilogue evaluates it ONCE per element and stores
+// both the activation Y = gelu(t) and the derivative Yd = gelu'(t); the consumers (next expansion, tail conv,
+// their weight / data gradients) read those instead of re-evaluating erf on every (halo-inflated) pass.
 // =======================================================================================
-template <typename T, bool GELU_IN, int NSUB>
+template <typename T, int NSUB>
 __global__ void __launch_bounds__(256)
 tail_expand_kernel(const T* __restrict__ X, const T* __restrict__ Wp, const float* __restrict__ bias, T* __restrict__ Y,
-                   long long M, int H, int Wd, int r, int tiles_per_block) {
+                   T* __restrict__ Yd, long long M, int H, int Wd, int r, int tiles_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T(*Ws)[72] = reinterpret_cast<T(*)[72]>(smem);                                   // [64 NSUB][72]
   T(*As)[72] = reinterpret_cast<T(*)[72]>(smem + sizeof(T) * 64 * NSUB * 72);      // [128][72]
@@ -195,12 +200,7 @@ tail_expand_kernel(const T* __restrict__ X, const T* __restrict__ Wp, const floa
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int idx = tid + it * 256;
-      Frag8<T> f = ra[it];
-      if (GELU_IN) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f.set(e, gelu_erf(f.get(e)));
-      }
-      store8(&As[idx >> 3][(idx & 7) * 8], f);
+      store8(&As[idx >> 3][(idx & 7) * 8], ra[it]);
     }
     __syncthreads();
     if (t + 1 < t1) fetch(t + 1);
@@ -245,48 +245,50 @@ tail_expand_kernel(const T* __restrict__ X, const T* __restrict__ Wp, const floa
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         if (!ok[mt]) continue;
-        float v[16];
+        float v[16], dv[16];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) v[4 * nt + q4] = acc[mt][nt][q4] + bv[4 * nt + q4];
+          for (int q4 = 0; q4 < 4; ++q4) gelu_erf_both(acc[mt][nt][q4] + bv[4 * nt + q4], v[4 * nt + q4], dv[4 * nt + q4]);
         const long long pix = pixbase[mt] + (long long)i * Wd * r + j;
         store16f(Y + pix * 64 + 16 * g, v);
+        store16f(Yd + pix * 64 + 16 * g, dv);
       }
     }
   }
 }
 template <typename T>
-static int launch_tail_expand_t(const T* X, const T* Wp, const float* bias, T* Y, long long M, int H, int Wd, int r, bool gelu_in,
+static int launch_tail_expand_t(const T* X, const T* Wp, const float* bias, T* Y, T* Yd, long long M, int H, int Wd, int r,
                                 hipStream_t st) {
   const long long ntiles = (M + 127) / 128;
   int nblk = (int)std::min<long long>(ntiles, 1024);
   const int tpb = (int)ceil_divll(ntiles, nblk);
   nblk = (int)ceil_divll(ntiles, tpb);
-#define GO(G_, NS_)                                                                                                    \
+#define GO(NS_)                                                                                                        \
   {                                                                                                                    \
     const size_t sh = sizeof(T) * (64 * NS_ + 128) * 72;                                                               \
-    (void)hipFuncSetAttribute((const void*)tail_expand_kernel<T, G_, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-    hipLaunchKernelGGL((tail_expand_kernel<T, G_, NS_>), dim3(nblk), dim3(256), sh, st, X, Wp, bias, Y, M, H, Wd, r, tpb); \
+    (void)hipFuncSetAttribute((const void*)tail_expand_kernel<T, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+    hipLaunchKernelGGL((tail_expand_kernel<T, NS_>), dim3(nblk), dim3(256), sh, st, X, Wp, bias, Y, Yd, M, H, Wd, r, tpb); \
   }
-  if (r == 2) { if (gelu_in) GO(true, 4) else GO(false, 4) }
-  else if (r == 3) { if (gelu_in) GO(true, 9) else GO(false, 9) }
+  if (r == 2) GO(4)
+  else if (r == 3) GO(9)
   else return m2t_set_error(-2, "tail_expand: r must be 2 or 3");
 #undef GO
   M2T_LAUNCH_CHECK();
   return 0;
 }
-int launch_tail_expand(int dt, const void* X, const void* Wp, const float* bias, void* Y, long long M, int H, int Wd, int r,
-                       bool gelu_in, hipStream_t st) {
+int launch_tail_expand(int dt, const void* X, const void* Wp, const float* bias, void* Y, void* Yd, long long M, int H, int Wd,
+                       int r, hipStream_t st) {
   if (dt == M2T_F32 && r == 3) {
     // fp32 x3: the 576 x 64 fp32 weight matrix does not fit LDS beside the tile -> generic tiled GEMM
     m2t_gemm_args ga{};
     ga.A = X; ga.lda = 64; ga.W = Wp; ga.Y = Y; ga.ldy = 64; ga.bias = bias; ga.M = M; ga.N = 64 * r * r; ga.K = 64;
     ga.H = H; ga.Wd = Wd; ga.r = r; ga.C = 64;
-    return launch_gemm_nt(dt, gelu_in ? M2T_A_GELU : M2T_A_PLAIN, M2T_E_BIAS_SHUF, ga, st);
+    ga.Y2 = Yd;
+    return launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_BIAS_SHUF, ga, st);
   }
-  if (dt == M2T_F32) return launch_tail_expand_t<float>((const float*)X, (const float*)Wp, bias, (float*)Y, M, H, Wd, r, gelu_in, st);
-  return launch_tail_expand_t<bf16_t>((const bf16_t*)X, (const bf16_t*)Wp, bias, (bf16_t*)Y, M, H, Wd, r, gelu_in, st);
+  if (dt == M2T_F32) return launch_tail_expand_t<float>((const float*)X, (const float*)Wp, bias, (float*)Y, (float*)Yd, M, H, Wd, r, st);
+  return launch_tail_expand_t<bf16_t>((const bf16_t*)X, (const bf16_t*)Wp, bias, (bf16_t*)Y, (bf16_t*)Yd, M, H, Wd, r, st);
 }
 
 // =======================================================================================
@@ -407,7 +409,6 @@ static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_
   if (a.gmode == M2T_A_PLAIN && a.xmode == M2T_A_PLAIN) GO(M2T_A_PLAIN, M2T_A_PLAIN);
   else if (a.gmode == M2T_A_HALO && a.xmode == M2T_A_PLAIN) GO(M2T_A_HALO, M2T_A_PLAIN);
   else if (a.gmode == M2T_A_UNSHUF && a.xmode == M2T_A_PLAIN) GO(M2T_A_UNSHUF, M2T_A_PLAIN);
-  else if (a.gmode == M2T_A_UNSHUF && a.xmode == M2T_A_GELU) GO(M2T_A_UNSHUF, M2T_A_GELU);
   else return m2t_set_error(-2, "wgrad_tn: unsupported operand modes");
 #undef GO
   M2T_LAUNCH_CHECK();

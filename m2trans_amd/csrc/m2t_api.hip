@@ -227,8 +227,10 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("norm_part", (size_t)B * M2T_NORM_SPLIT * 64 * 3, 4);
   p->add_ws("norm_s", (size_t)B * 64 * 2, 4);
   const int r0 = (s == 4) ? 2 : s;
-  p->add_ws("t1pre", BP * r0 * r0 * 64, es);
-  if (s == 4) p->add_ws("t2pre", BP * 16 * 64, es);
+  // tail activations: gelu(t) and gelu'(t) of each expansion (the pre-activation t itself is never needed again)
+  p->add_ws("t1act", BP * r0 * r0 * 64, es);
+  p->add_ws("t1der", BP * r0 * r0 * 64, es);
+  if (s == 4) { p->add_ws("t2act", BP * 16 * 64, es); p->add_ws("t2der", BP * 16 * 64, es); }
   p->add_ws("srpre", (size_t)B * 3 * p->Hsp * p->Wsp, 4);
   p->add_ws("loss_part", M2T_LOSS_BLOCKS, 4);
   // backward
@@ -354,16 +356,16 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
   void* Y = WSP("X" + std::to_string(p->nb));
   const int r0 = (s == 4) ? 2 : s;
   { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st);
-    CK(launch_tail_expand(dt, Y, packed_ptr(p, workspace, "t0"), params + p->poff.at("tail.0.bias"), WSP("t1pre"), BP, H, W, r0, false, st)); }
-  const void* last_pre = WSP("t1pre");
+    CK(launch_tail_expand(dt, Y, packed_ptr(p, workspace, "t0"), params + p->poff.at("tail.0.bias"), WSP("t1act"), WSP("t1der"), BP, H, W, r0, st)); }
+  const void* last_act = WSP("t1act");
   if (s == 4) {
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st);
-      CK(launch_tail_expand(dt, WSP("t1pre"), packed_ptr(p, workspace, "t3"), params + p->poff.at("tail.3.bias"), WSP("t2pre"), BP * 4,
-                            2 * H, 2 * W, 2, true, st)); }
-    last_pre = WSP("t2pre");
+      CK(launch_tail_expand(dt, WSP("t1act"), packed_ptr(p, workspace, "t3"), params + p->poff.at("tail.3.bias"), WSP("t2act"), WSP("t2der"),
+                            BP * 4, 2 * H, 2 * W, 2, st)); }
+    last_act = WSP("t2act");
   }
   const float* wlast = params + p->poff.at(s == 4 ? "tail.6.weight" : "tail.3.weight");
-  { M2TProfScope ps(M2T_PROF_FINAL_FWD, st); CK(launch_final_conv_fwd(dt, last_pre, wlast, (float*)WSP("srpre"), B, p->Hsp, p->Wsp, st)); }
+  { M2TProfScope ps(M2T_PROF_FINAL_FWD, st); CK(launch_final_conv_fwd(dt, last_act, wlast, (float*)WSP("srpre"), B, p->Hsp, p->Wsp, st)); }
   if (sr)
     CK(launch_clamp_l1((const float*)WSP("srpre"), nullptr, sr, nullptr, nullptr, nullptr, B, p->Hsp, p->Wsp, p->Hs,
                        p->Ws, rgb_range, 0.f, 0.f, st));
@@ -479,25 +481,26 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   const int r0 = (s == 4) ? 2 : s;
   // ---- tail ----
   const std::string wl = (s == 4) ? "tail.6.weight" : "tail.3.weight";
-  const void* last_pre = (s == 4) ? WSP("t2pre") : WSP("t1pre");
+  const void* last_act = (s == 4) ? WSP("t2act") : WSP("t1act");
+  const void* last_der = (s == 4) ? WSP("t2der") : WSP("t1der");
   void* g_last = (s == 4) ? WSP("g_t2pre") : WSP("g_t1pre");
   const bool skip = p->debug_skip_side;
   fork();
   if (!skip) CK(launch_head_im2col(dt, x, WSP("head_cols"), B, p->H0, p->W0, H, W, sd));
   if (!skip) {
     float* slabs = arena_alloc((size_t)1024 * 32 * 64);
-    { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, sd); CK(launch_final_conv_wgrad(dt, gpre, last_pre, slabs, &ns, B, p->Hsp, p->Wsp, sd)); }
+    { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, sd); CK(launch_final_conv_wgrad(dt, gpre, last_act, slabs, &ns, B, p->Hsp, p->Wsp, sd)); }
     defer(slabs, p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0);
   }
-  { M2TProfScope ps(M2T_PROF_FINAL_DGRAD, st); CK(launch_final_conv_dgrad(dt, gpre, params + p->poff.at(wl), last_pre, g_last, B, p->Hsp, p->Wsp, st)); }
+  { M2TProfScope ps(M2T_PROF_FINAL_DGRAD, st); CK(launch_final_conv_dgrad(dt, gpre, params + p->poff.at(wl), last_der, g_last, B, p->Hsp, p->Wsp, st)); }
   if (s == 4) {
-    // tail.3: u = gelu(t1pre) W3^T + b3, shuffled into t2pre
+    // tail.3: u = t1act W3^T + b3 (t1act = gelu(t1)), shuffled; g(t1) = (g_u W3) * t1der
     fork();
     float* slabs = arena_alloc((size_t)wgrad_slab_count(BP * 4, 256, 64) * 256 * 64);
     float* colp = arena_alloc((size_t)wgrad_slab_count(BP * 4, 256, 64) * 256);
     m2t_wgrad_args wa{};
     if (!skip) {
-    wa.G = WSP("g_t2pre"); wa.gmode = M2T_A_UNSHUF; wa.X = WSP("t1pre"); wa.ldx = 64; wa.xmode = M2T_A_GELU;
+    wa.G = WSP("g_t2pre"); wa.gmode = M2T_A_UNSHUF; wa.X = WSP("t1act"); wa.ldx = 64; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP * 4; wa.N = 256; wa.K = 64; wa.H = 2 * H; wa.Wd = 2 * W; wa.r = 2; wa.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
     defer(slabs, p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64);
@@ -505,7 +508,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     }
     m2t_gemm_args ga{};
     ga.A = WSP("g_t2pre"); ga.W = packed_ptr(p, workspace, "t3T"); ga.Y = WSP("g_t1pre"); ga.ldy = 64;
-    ga.aux = WSP("t1pre"); ga.ldaux = 64; ga.M = BP * 4; ga.N = 64; ga.K = 256;
+    ga.aux = WSP("t1der"); ga.ldaux = 64; ga.M = BP * 4; ga.N = 64; ga.K = 256;
     ga.H = 2 * H; ga.Wd = 2 * W; ga.r = 2; ga.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_GELU_GRAD, ga, st)); }
   }

@@ -159,6 +159,14 @@ __device__ __forceinline__ float gelu_erf(float x) {
   erf_parts(x, e, ex);
   return 0.5f * x * (1.0f + e);
 }
+// GELU and its derivative from one erf / exp evaluation
+__device__ __forceinline__ void gelu_erf_both(float x, float& act, float& der) {
+  float e, ex;
+  erf_parts(x, e, ex);
+  const float cdf = 0.5f * (1.0f + e);
+  act = x * cdf;
+  der = cdf + x * (0.39894228040143267794f * ex);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   float e, ex;
   erf_parts(x, e, ex);

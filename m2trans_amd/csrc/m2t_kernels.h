@@ -71,15 +71,17 @@ struct m2t_gemm_args {
   const void* W;                // [N][K] element type T
   void* Y; int ldy;             // output (or, SHUF: the [B][H*r][W*r][C] tensor)
   const float* bias;            // [N] fp32 (E_BIAS*)
-  const void* aux; int ldaux;   // E_GELU_GRAD: pre-activation tensor, same shape as Y
+  const void* aux; int ldaux;   // E_GELU_GRAD: stored derivative gelu'(t), same shape as Y; E_BIAS_RESID: residual
+  void* Y2 = nullptr;           // E_BIAS_SHUF: second output, the derivative gelu'(t) (Y receives gelu(t))
   long long M; int N, K;
   int H, Wd, r, C;              // shuffle geometry: rows m = (b, h, w) over [B][H][Wd]; C channels after shuffle
   const void* halo_win = nullptr;   // M2T_A_HALO: per-window dK|dV scratch (H, Wd = branch grid, C = branch channels)
 };
 int launch_gemm_nt(int dt, int amode, int emode, const m2t_gemm_args& a, hipStream_t st);
-// upsampler 1x1 conv + bias + pixel-shuffle scatter, K = 64, N = 64 r^2; X rows over [B][H][Wd], optional GELU on load
-int launch_tail_expand(int dt, const void* X, const void* Wp, const float* bias, void* Y, long long M, int H, int Wd, int r,
-                       bool gelu_in, hipStream_t st);
+// upsampler 1x1 conv + bias + pixel-shuffle scatter + GELU, K = 64, N = 64 r^2; X rows over [B][H][Wd];
+// Y = gelu(t), Yd = gelu'(t) (both [B][H r][Wd r][64])
+int launch_tail_expand(int dt, const void* X, const void* Wp, const float* bias, void* Y, void* Yd, long long M, int H, int Wd,
+                       int r, hipStream_t st);
 // dW[N][K] (fp32 slabs) = sum_m G[m][N]^T X[m][K];  G/X side variants as above
 struct m2t_wgrad_args {
   const void* G; int ldg; int gmode;   // M2T_A_PLAIN or M2T_A_UNSHUF
@@ -104,7 +106,7 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
                        void* y, int B, int H, int W, hipStream_t st);
 int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, int* nslab, int B, int H, int W,
                              hipStream_t st);
-// tail conv 64->3, reflect padding, input = GELU(tpre); output NCHW fp32 [B][3][H][W]
+// tail conv 64->3, reflect padding, input = the stored activation gelu(t); output NCHW fp32 [B][3][H][W]
 int launch_final_conv_fwd(int dt, const void* tpre, const float* w, float* out, int B, int H, int W, hipStream_t st);
 int launch_final_conv_dgrad(int dt, const float* gout, const float* w, const void* tpre, void* gtpre, int B, int H, int W,
                             hipStream_t st);

@@ -250,17 +250,24 @@ def conv3x3_reflect(x: Tensor, w: Tensor, b=None) -> Tensor:
     return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b)
 
 
+def gelu_derivative(t: Tensor) -> Tensor:
+    """d/dt of the exact (erf) GELU that nn.GELU() applies (models/M2Trans_network.py:44,46,53)."""
+    return 0.5 * (1.0 + torch.erf(t * 0.7071067811865476)) + t * torch.exp(-0.5 * t * t) * 0.3989422804014327
+
+
 def tail(x: Tensor, p: Params, scale: int, cap=None) -> Tensor:
-    """models/M2Trans_network.py:41-56."""
+    """models/M2Trans_network.py:41-56.  The HIP path stores gelu(t) and gelu'(t) of each expansion
+    (workspace tensors t1act/t1der, t2act/t2der) instead of the pre-activation t."""
     if scale == 4:
         t1 = F.pixel_shuffle(F.conv2d(x, p["tail.0.weight"], p["tail.0.bias"]), 2)
         t2 = F.pixel_shuffle(F.conv2d(F.gelu(t1), p["tail.3.weight"], p["tail.3.bias"]), 2)
         if cap is not None:
-            cap["t1pre"], cap["t2pre"] = t1, t2
+            cap["t1act"], cap["t2act"] = F.gelu(t1), F.gelu(t2)
+            cap["t1der"], cap["t2der"] = gelu_derivative(t1), gelu_derivative(t2)
         return conv3x3_reflect(F.gelu(t2), p["tail.6.weight"])
     t1 = F.pixel_shuffle(F.conv2d(x, p["tail.0.weight"], p["tail.0.bias"]), scale)
     if cap is not None:
-        cap["t1pre"] = t1
+        cap["t1act"], cap["t1der"] = F.gelu(t1), gelu_derivative(t1)
     return conv3x3_reflect(F.gelu(t1), p["tail.3.weight"])
 
 

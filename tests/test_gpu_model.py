@@ -27,9 +27,11 @@ def _forward_table(model, plan, cap, B, H, W, scale, nb):
         rows.append((f"b{b}.xc", rel(ws_nchw(plan, f"b{b}.xc", B, H, W, 64), cap[f"b{b}.xc"])))
         rows.append((f"X{b+1}", rel(ws_nchw(plan, f"X{b+1}", B, H, W, 64), cap[f"X{b+1}"])))
     r0 = 2 if scale == 4 else scale
-    rows.append(("t1pre", rel(ws_nchw(plan, "t1pre", B, H * r0, W * r0, 64), cap["t1pre"])))
+    for nm in ("t1act", "t1der"):
+        rows.append((nm, rel(ws_nchw(plan, nm, B, H * r0, W * r0, 64), cap[nm])))
     if scale == 4:
-        rows.append(("t2pre", rel(ws_nchw(plan, "t2pre", B, H * 4, W * 4, 64), cap["t2pre"])))
+        for nm in ("t2act", "t2der"):
+            rows.append((nm, rel(ws_nchw(plan, nm, B, H * 4, W * 4, 64), cap[nm])))
     pre = plan.ws_tensor("srpre", dtype=torch.float32).view(B, 3, H * scale, W * scale).cpu()
     rows.append(("srpre", rel(pre, cap["srpre_padded"])))
     return rows
