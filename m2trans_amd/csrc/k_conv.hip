@@ -286,24 +286,25 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
 
 // =======================================================================================
 // 64 -> 64 3x3 conv weight gradient:  dW[tap][oc][ic] = sum_p gy[p][oc] * x[p + tap][ic]
-// Workgroup sweeps tiles of TH x 16 pixels; per tile it stages, TRANSPOSED (pixel index
-// contiguous), gy as GT[oc][m] and three column-shifted copies of x as XT[dx][ic][m'] with
-// m' = (row+1)*16 + col over TH+2 rows, so that every tap's operand is an aligned run of 8
-// pixels.  Wave w owns oc rows 16w..16w+15 for all 4 ic tiles and all 9 taps (36 accumulators).
-// Output: fp32 slabs [nblk][9][64][64], summed (and permuted to torch layout) by reduce_slabs.
+// Workgroup sweeps tiles of TH x 16 pixels.  Both operands are contracted over PIXELS, so they are needed
+// pixel-contiguous per channel: the tiles are staged row-major exactly as they lie in HBM (16-byte stores:
+// gy as Gs[m][oc], the zero-padded x halo as Xs[(row+1)*18 + col+1][ic]) and transposed by the LDS read
+// (ds_read_b64_tr_b16): 8 consecutive pixels of a tile row are 8 consecutive rows of either array, at any tap
+// offset.  Wave w owns oc rows 16w..16w+15 for all 4 ic tiles and all 9 taps (36 accumulators).
+// Output: fp32 slabs [nblk][9][64][64], summed (and permuted to torch layout) by the batched reduction.
 // =======================================================================================
 template <typename T, int TH>
 __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ gy,
                                                                 float* __restrict__ slabs, int B, int H, int W,
                                                                 int tiles_per_block) {
-  constexpr int MT = TH * 16;          // pixels per tile
-  constexpr int MX = (TH + 2) * 16;    // rows incl. halo
-  constexpr int LG = MT + 8, LX = MX + 8;
+  constexpr int MT = TH * 16;              // pixels per tile
+  constexpr int HX = (TH + 2) * 18;        // halo pixels
+  constexpr int LD = 72;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T(*GT)[LG] = reinterpret_cast<T(*)[LG]>(smem);
-  T(*XT)[64][LX] = reinterpret_cast<T(*)[64][LX]>(smem + sizeof(T) * 64 * LG);
+  T(*Gs)[LD] = reinterpret_cast<T(*)[LD]>(smem);                          // [MT][72]
+  T(*Xs)[LD] = reinterpret_cast<T(*)[LD]>(smem + sizeof(T) * MT * LD);    // [HX][72]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int lr = lane & 15, g = lane >> 4;
+  const int g = lane >> 4;
   const int tw = W / 16, th = H / TH;
   const long long ntiles = (long long)B * th * tw;
   f32x4 acc[9][4];
@@ -314,75 +315,66 @@ __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restr
 
   const long long t0 = (long long)blockIdx.x * tiles_per_block;
   const long long t1 = min(ntiles, t0 + tiles_per_block);
-  for (long long t = t0; t < t1; ++t) {
+  constexpr int NG = MT * 8 / 256;
+  constexpr int TOTX = HX * 8, NX = (TOTX + 255) / 256;
+  Frag8<T> fg[NG], fx[NX];
+  auto fetch = [&](long long t) {          // all global loads of a tile, into registers
     const int tx = (int)(t % tw);
     const long long q = t / tw;
     const int ty = (int)(q % th);
     const int b = (int)(q / th);
     const int x0 = tx * 16, y0 = ty * TH;
+#pragma unroll
+    for (int it = 0; it < NG; ++it) {
+      const int idx = tid + it * 256;
+      const int m = idx >> 3, cv = idx & 7;
+      fg[it] = load8(gy + (((long long)b * H + y0 + (m >> 4)) * W + x0 + (m & 15)) * 64 + cv * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NX; ++it) {
+      const int idx = tid + it * 256;
+      const int p = idx >> 3, cv = idx & 7;
+      const int row = p / 18, xs = p - row * 18 - 1;        // xs in [-1, 16]
+      const int gyy = y0 + row - 1, gxx = x0 + xs;
+      fx[it] = frag_zero<T>();
+      if (idx < TOTX && gyy >= 0 && gyy < H && gxx >= 0 && gxx < W)
+        fx[it] = load8(x + (((long long)b * H + gyy) * W + gxx) * 64 + cv * 8);
+    }
+  };
+  if (t0 < t1) fetch(t0);
+  for (long long t = t0; t < t1; ++t) {
     __syncthreads();
-    // gy tile -> GT[oc][m], m = row*16 + col ; x halo -> three shifted transposed copies.
-    // All global loads first (registers), then the transposing LDS stores.
-    {
-      constexpr int NG = MT * 8 / 256;
-      constexpr int TOTX = (TH + 2) * 18 * 8, NX = (TOTX + 255) / 256;
-      Frag8<T> fg[NG], fx[NX];
 #pragma unroll
-      for (int it = 0; it < NG; ++it) {
-        const int idx = tid + it * 256;
-        const int m = idx % MT, cv = idx / MT;
-        fg[it] = load8(gy + (((long long)b * H + y0 + (m >> 4)) * W + x0 + (m & 15)) * 64 + cv * 8);
-      }
+    for (int it = 0; it < NG; ++it) {
+      const int idx = tid + it * 256;
+      store8(&Gs[idx >> 3][(idx & 7) * 8], fg[it]);
+    }
 #pragma unroll
-      for (int it = 0; it < NX; ++it) {
-        const int idx = tid + it * 256;
-        const int p = idx % ((TH + 2) * 18), cv = idx / ((TH + 2) * 18);
-        const int row = p / 18, xs = p - row * 18 - 1;        // xs in [-1, 16]
-        const int gyy = y0 + row - 1, gxx = x0 + xs;
-        fx[it] = frag_zero<T>();
-        if (idx < TOTX && gyy >= 0 && gyy < H && gxx >= 0 && gxx < W)
-          fx[it] = load8(x + (((long long)b * H + gyy) * W + gxx) * 64 + cv * 8);
-      }
-#pragma unroll
-      for (int it = 0; it < NG; ++it) {
-        const int idx = tid + it * 256;
-        const int m = idx % MT, cv = idx / MT;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) GT[cv * 8 + e][m] = fg[it].v_elem(e);
-      }
-#pragma unroll
-      for (int it = 0; it < NX; ++it) {
-        const int idx = tid + it * 256;
-        if (idx < TOTX) {
-          const int p = idx % ((TH + 2) * 18), cv = idx / ((TH + 2) * 18);
-          const int row = p / 18, xs = p - row * 18 - 1;
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx) {
-            const int col = xs - (dx - 1);                      // copy dx holds x[.., col + dx - 1]
-            if (col >= 0 && col < 16) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) XT[dx][cv * 8 + e][row * 16 + col] = fx[it].v_elem(e);
-            }
-          }
-        }
-      }
+    for (int it = 0; it < NX; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < TOTX) store8(&Xs[idx >> 3][(idx & 7) * 8], fx[it]);
     }
     __syncthreads();
+    if (t + 1 < t1) fetch(t + 1);          // the next tile's loads fly under this tile's products
 #pragma unroll 1
     for (int ch = 0; ch < MT / 32; ++ch) {
       // k-slot (g, j) <-> pixel m = 32 ch + 8 g + j : row = 2 ch + (g >> 1), col = 8 (g & 1) + j
-      const Frag8<T> gf = load8(&GT[16 * wv + lr][32 * ch + 8 * g]);
+      const int m0 = 32 * ch + 8 * g;
+      const Frag8<T> gf = load8_tr(&Gs[m0][16 * wv], &Gs[m0 + 4][16 * wv], LD, lane);
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+        for (int kx = 0; kx < 3; ++kx) {
+          const int hp = (2 * ch + (g >> 1) + ky) * 18 + 8 * (g & 1) + kx;
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
-            const Frag8<T> xf = load8(&XT[kx][16 * it + lr][(2 * ch + (g >> 1) + ky) * 16 + 8 * (g & 1)]);
+            const Frag8<T> xf = load8_tr(&Xs[hp][16 * it], &Xs[hp + 4][16 * it], LD, lane);
             mma16(acc[ky * 3 + kx][it], gf, xf);
           }
+        }
     }
   }
+  const int lr = lane & 15;
   float* out = slabs + (long long)blockIdx.x * (9 * 64 * 64);
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
@@ -401,13 +393,11 @@ int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs
   const int tpb = (int)ceil_divll(ntiles, nblk);
   nblk = (int)ceil_divll(ntiles, tpb);
   if (dt == M2T_F32) {
-    constexpr int MT = 4 * 16, MX = 6 * 16;
-    const size_t sh = sizeof(float) * (64 * (MT + 8) + 3 * 64 * (MX + 8));
+    const size_t sh = sizeof(float) * 72 * (4 * 16 + 6 * 18);
     (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<float, 4>), dim3(nblk), dim3(256), sh, st, (const float*)x, (const float*)gy, slabs, B, H, W, tpb);
   } else {
-    constexpr int MT = 8 * 16, MX = 10 * 16;
-    const size_t sh = sizeof(bf16_t) * (64 * (MT + 8) + 3 * 64 * (MX + 8));
+    const size_t sh = sizeof(bf16_t) * 72 * (8 * 16 + 10 * 18);
     (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<bf16_t, 8>), dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)gy, slabs, B, H, W, tpb);
   }
