@@ -175,51 +175,91 @@ __device__ __forceinline__ Wf wf_merge(const Wf& a, const Wf& b) {
 template <typename T>
 __global__ void __launch_bounds__(256) instnorm_stats1_kernel(const T* __restrict__ x, float* __restrict__ part, int P,
                                                               int nsplit) {
-  // part [B][nsplit][64][3]
+  // part [B][nsplit][64][3] = (n, mean, M2).  A thread owns 8 channels of every 32nd pixel of the split; it takes
+  // them 16 pixels at a time: all loads first, then an exact two-pass (mean, then squared deviations) on the
+  // registers -- no per-element division -- and one Welford merge per 16 pixels.
   const int b = blockIdx.y, sp = blockIdx.x;
-  const int cgp = threadIdx.x & 7, pl = threadIdx.x >> 3;   // 8 groups x 32 lanes
+  const int cgp = threadIdx.x & 7, pl = threadIdx.x >> 3;   // 8 channel groups x 32 pixel lanes
   const int per = ceil_div(P, nsplit);
   const int p0 = sp * per, p1 = min(P, p0 + per);
   Wf w[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) { w[c].n = 0.f; w[c].mean = 0.f; w[c].m2 = 0.f; }
-  for (int p = p0 + pl; p < p1; p += 32) {
-    float v[8];
-    load8f(x + ((long long)b * P + p) * 64 + cgp * 8, v);
+  for (int pb = p0 + pl; pb < p1; pb += 32 * 16) {
+    float v[16][8];
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = pb + 32 * i;
+      if (p < p1) { load8f(x + ((long long)b * P + p) * 64 + cgp * 8, v[i]); ++cnt; }
+      else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[i][c] = 0.f;
+      }
+    }
+    const float fn = (float)cnt, inv = 1.0f / fn;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      w[c].n += 1.f;
-      const float d = v[c] - w[c].mean;
-      w[c].mean += d / w[c].n;
-      w[c].m2 += d * (v[c] - w[c].mean);
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sum += v[i][c];            // invalid slots hold 0
+      Wf q; q.n = fn; q.mean = sum * inv; q.m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float d = v[i][c] - q.mean; q.m2 += (i < cnt) ? d * d : 0.f; }
+      w[c] = wf_merge(w[c], q);
     }
   }
   __shared__ float sh[256][8][3];
 #pragma unroll
   for (int c = 0; c < 8; ++c) { sh[threadIdx.x][c][0] = w[c].n; sh[threadIdx.x][c][1] = w[c].mean; sh[threadIdx.x][c][2] = w[c].m2; }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int ch = threadIdx.x, g = ch >> 3, c = ch & 7;
-    Wf a; a.n = 0.f; a.mean = 0.f; a.m2 = 0.f;
-    for (int l = 0; l < 32; ++l) {
-      Wf q; q.n = sh[l * 8 + g][c][0]; q.mean = sh[l * 8 + g][c][1]; q.m2 = sh[l * 8 + g][c][2];
-      a = wf_merge(a, q);
+  // fixed pairwise tree over the 32 pixel lanes
+  for (int stride = 16; stride > 0; stride >>= 1) {
+    __syncthreads();
+    if (pl < stride) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        Wf a, q;
+        a.n = sh[threadIdx.x][c][0]; a.mean = sh[threadIdx.x][c][1]; a.m2 = sh[threadIdx.x][c][2];
+        q.n = sh[threadIdx.x + 8 * stride][c][0]; q.mean = sh[threadIdx.x + 8 * stride][c][1]; q.m2 = sh[threadIdx.x + 8 * stride][c][2];
+        a = wf_merge(a, q);
+        sh[threadIdx.x][c][0] = a.n; sh[threadIdx.x][c][1] = a.mean; sh[threadIdx.x][c][2] = a.m2;
+      }
     }
-    float* o = part + (((long long)b * nsplit + sp) * 64 + ch) * 3;
-    o[0] = a.n; o[1] = a.mean; o[2] = a.m2;
+  }
+  if (pl == 0) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float* o = part + (((long long)b * nsplit + sp) * 64 + cgp * 8 + c) * 3;
+      o[0] = sh[threadIdx.x][c][0]; o[1] = sh[threadIdx.x][c][1]; o[2] = sh[threadIdx.x][c][2];
+    }
   }
 }
-__global__ void instnorm_stats2_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
+__global__ void __launch_bounds__(64) instnorm_stats2_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
                                        int nsplit, float eps) {
+  // every partial is fetched before the first merge (independent loads in flight), then a fixed pairwise tree:
+  // depth 5 instead of a 32-step dependent chain of loads and divisions
   const int b = blockIdx.x, ch = threadIdx.x;   // 64 threads
-  Wf a; a.n = 0.f; a.mean = 0.f; a.m2 = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float* o = part + (((long long)b * nsplit + s) * 64 + ch) * 3;
-    Wf q; q.n = o[0]; q.mean = o[1]; q.m2 = o[2];
-    a = wf_merge(a, q);
+  Wf w[M2T_NORM_SPLIT];
+#pragma unroll
+  for (int s = 0; s < M2T_NORM_SPLIT; ++s) {
+    w[s].n = 0.f; w[s].mean = 0.f; w[s].m2 = 0.f;
+    if (s < nsplit) {
+      const float* o = part + (((long long)b * nsplit + s) * 64 + ch) * 3;
+      w[s].n = o[0]; w[s].mean = o[1]; w[s].m2 = o[2];
+    }
   }
-  mean[b * 64 + ch] = a.mean;
-  rstd[b * 64 + ch] = 1.0f / sqrtf(a.m2 / a.n + eps);   // biased variance
+  static_assert(M2T_NORM_SPLIT == 32, "the fixed tree below is written for 32 partials");
+#pragma unroll
+  for (int s = 0; s < 32; s += 2) w[s] = wf_merge(w[s], w[s + 1]);
+#pragma unroll
+  for (int s = 0; s < 32; s += 4) w[s] = wf_merge(w[s], w[s + 2]);
+#pragma unroll
+  for (int s = 0; s < 32; s += 8) w[s] = wf_merge(w[s], w[s + 4]);
+#pragma unroll
+  for (int s = 0; s < 32; s += 16) w[s] = wf_merge(w[s], w[s + 8]);
+  const Wf r = wf_merge(w[0], w[16]);
+  mean[b * 64 + ch] = r.mean;
+  rstd[b * 64 + ch] = 1.0f / sqrtf(r.m2 / r.n + eps);   // biased variance
 }
 int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float* part, int B, int P, hipStream_t st) {
   const int nsplit = M2T_NORM_SPLIT;
@@ -475,15 +515,26 @@ __global__ void __launch_bounds__(256) instnorm_bwd_red1_kernel(const T* __restr
     o[0] = a1; o[1] = a2;
   }
 }
-__global__ void instnorm_bwd_red2_kernel(const float* __restrict__ part, float* __restrict__ s, int nsplit, float invP) {
+__global__ void __launch_bounds__(64) instnorm_bwd_red2_kernel(const float* __restrict__ part, float* __restrict__ s, int nsplit, float invP) {
+  // eight independent partial chains (q = j, j + 8, ...) keep the loads in flight; fixed combine order
   const int b = blockIdx.x, ch = threadIdx.x;
-  float a1 = 0.f, a2 = 0.f;
-  for (int q = 0; q < nsplit; ++q) {
-    const float* o = part + (((long long)b * nsplit + q) * 64 + ch) * 2;
-    a1 += o[0]; a2 += o[1];
+  const float* o = part + ((long long)b * nsplit * 64 + ch) * 2;
+  float a1[8], a2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a1[j] = 0.f; a2[j] = 0.f; }
+  for (int q = 0; q < nsplit; q += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (q + j < nsplit) {
+        const float2 v = *reinterpret_cast<const float2*>(o + (long long)(q + j) * 128);
+        a1[j] += v.x; a2[j] += v.y;
+      }
+    }
   }
-  s[(b * 64 + ch) * 2 + 0] = a1 * invP;
-  s[(b * 64 + ch) * 2 + 1] = a2 * invP;
+  const float t1 = ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
+  const float t2 = ((a2[0] + a2[1]) + (a2[2] + a2[3])) + ((a2[4] + a2[5]) + (a2[6] + a2[7]));
+  s[(b * 64 + ch) * 2 + 0] = t1 * invP;
+  s[(b * 64 + ch) * 2 + 1] = t2 * invP;
 }
 template <typename T>
 __global__ void __launch_bounds__(256) instnorm_bwd_apply_kernel(const T* __restrict__ gn, const T* __restrict__ x,
