@@ -133,9 +133,114 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// gemm_nt_wide: the plain/plain case for the wide shapes (the C = 256 qkv projection 256 -> 768 and its data
+// gradient 768 -> 256).  BM x 128 output tile, 64-deep stages, double-buffered LDS with ONE barrier per stage and
+// the next stage's global loads in registers while the current one is multiplied: 32 (BM = 128) or 16 (BM = 64)
+// MFMAs per wave per barrier instead of 8.
+// ---------------------------------------------------------------------------------------
+template <typename T, int BM>
+__global__ void __launch_bounds__(256)
+gemm_nt_wide_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __restrict__ Y, int ldy, long long M, int N,
+                    int K) {
+  constexpr int BN = 128, BK = 64, LD = BK + 8, MT = BM / 64, NA = BM / 32, NW = 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T(*As)[BM][LD] = reinterpret_cast<T(*)[BM][LD]>(smem);
+  T(*Ws)[BN][LD] = reinterpret_cast<T(*)[BN][LD]>(smem + sizeof(T) * 2 * BM * LD);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  f32x4 acc[MT][8];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  Frag8<T> ra[NA], rw[NW];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int idx = tid + it * 256;
+      const long long m = m0 + (idx >> 3);
+      ra[it] = frag_zero<T>();
+      if (m < M) ra[it] = load8(A + m * lda + k0 + (idx & 7) * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int idx = tid + it * 256;
+      rw[it] = load8(W + (long long)(n0 + (idx >> 3)) * K + k0 + (idx & 7) * 8);
+    }
+  };
+  fetch(0);
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += BK, buf ^= 1) {
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int idx = tid + it * 256;
+      store8(&As[buf][idx >> 3][(idx & 7) * 8], ra[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < NW; ++it) {
+      const int idx = tid + it * 256;
+      store8(&Ws[buf][idx >> 3][(idx & 7) * 8], rw[it]);
+    }
+    __syncthreads();      // (the buffer written next iteration was last read before this barrier)
+    if (k0 + BK < K) fetch(k0 + BK);
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      Frag8<T> xf[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xf[mt] = load8(&As[buf][16 * MT * wv + 16 * mt + lr][32 * kc + 8 * g]);
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const int nl = 64 * (nt >> 2) + 16 * (lr >> 2) + 4 * (nt & 3) + (lr & 3);
+        const Frag8<T> wf = load8(&Ws[buf][nl][32 * kc + 8 * g]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) mma16(acc[mt][nt], wf, xf[mt]);
+      }
+    }
+  }
+  // lane (m = lr, g) holds channels n0 + 64 h + 16 g + 0..15 for h = 0, 1
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const long long m = m0 + 16 * MT * wv + 16 * mt + lr;
+    if (m >= M) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float v[16];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][4 * h + nt][r];
+      store16f(Y + m * ldy + n0 + 64 * h + 16 * g, v);
+    }
+  }
+}
+template <typename T, int BM>
+static int launch_gemm_nt_wide(const m2t_gemm_args& a, hipStream_t st) {
+  const size_t sh = sizeof(T) * 2 * (BM + 128) * 72;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<T, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+    attr_set = true;
+  }
+  dim3 grid((unsigned)ceil_divll(a.M, BM), (unsigned)(a.N / 128));
+  hipLaunchKernelGGL((gemm_nt_wide_kernel<T, BM>), grid, dim3(256), sh, st, (const T*)a.A, a.lda, (const T*)a.W, (T*)a.Y, a.ldy,
+                     a.M, a.N, a.K);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
 template <typename T>
 static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStream_t st) {
   if (a.K % 8 || a.N % 16) return m2t_set_error(-2, "gemm_nt: K must be a multiple of 8 and N of 16");
+  if (amode == M2T_A_PLAIN && emode == M2T_E_PLAIN && a.N % 128 == 0 && a.K % 64 == 0 && a.K >= 128) {
+    // enough 128-column blocks to fill the chip with BM = 128?  otherwise halve the row tile
+    const long long blocks128 = ceil_divll(a.M, 128) * (a.N / 128);
+    if (sizeof(T) == 2 && blocks128 >= 512) return launch_gemm_nt_wide<T, 128>(a, st);
+    return launch_gemm_nt_wide<T, 64>(a, st);
+  }
   dim3 grid((unsigned)ceil_divll(a.M, GEMM_BM), (unsigned)ceil_div(a.N, GEMM_BN));
   ShufGeom sg{a.H, a.Wd, a.r, a.C, a.halo_win};
 #define GO(AM, EM)                                                                                              \
