@@ -631,7 +631,10 @@ static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const floa
   }
   m2t_prof_begin(C == 16 ? M2T_PROF_ATTN_BWD_16 : (C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256), st);
   int res_rc = M2T_UNSUPPORTED;
-  if (resident && sizeof(T) == 2) {
+  if (resident && sizeof(T) == 2 && C == 16 && dwt_levels == 0) {
+    res_rc = launch_window_attn_bwd_c16(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, B, h, w, st);
+    if (res_rc != 0) return res_rc;
+  } else if (resident && sizeof(T) == 2) {
     res_rc = launch_window_attn_bwd_resident(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, B, h, w, C, dwt_levels, st);
     if (res_rc != 0 && res_rc != M2T_UNSUPPORTED) return res_rc;
   }

@@ -1,0 +1,256 @@
+// k_attn_c16.hip -- backward of the 8x8 / 10x10 halo window attention for the C = 16 branch (bf16):
+// ONE WAVE PER WINDOW, no workgroup barriers.
+//
+// Same mathematics as window_attn_bwd_kernel (k_attn.hip; models/M2Trans_network.py:310-332 under autograd).
+// The full-resolution branch has 4096 windows per 16-patch batch and only 16 channels: a workgroup per window
+// spends its time in barriers and exposed latencies (57 us per launch; this kernel: 33 us, bound by the
+// issue rate of the softmax VALU work), while the arithmetic is tiny.  Here a
+// 64-lane wave owns a window and four independent waves share a workgroup:
+//   * with K = 16 the contraction of S^T = K^ Q^T and dP^T = V dO^T is exactly one v_mfma_f32_16x16x16_bf16,
+//     whose operands (4 channels per lane) are loaded straight from HBM in operand layout -- no staging;
+//   * the accumulator layout of a 16x16 tile (lane holds rows 4g..4g+3 of column l) IS the B-operand layout
+//     of the next product when the contraction runs over the tile's rows: dS^T feeds dq from registers;
+//   * for the products that contract over queries (dV, dK^) the P^T / dS^T tiles take one 8-byte LDS write
+//     per lane ([query][key] rows) and come back through the transposing read ds_read_b64_tr_b16;
+//   * K^, q and dO are also kept row-major in (wave-private) LDS so that the channel-major operands of
+//     dq / dV / dK^ are one transposing read each;
+//   * LDS accesses of a wave execute in order, so wave-private buffers need no barrier at all.
+// 15 KB of LDS per wave: nothing here can starve (or be starved by) the parameter-gradient kernels.
+#include "m2t_kernels.h"
+#include "m2t_window.h"
+
+namespace {
+
+constexpr int C16 = 16;
+constexpr int C16_PLD = 120;   // P / dS rows: 112 keys + 8 pad
+
+struct __attribute__((aligned(16))) C16WaveLds {
+  bf16_t Kh[112][16];          // K^ = k + rel-pos, row-major [key][c]   (keys >= 100 are zero)
+  bf16_t Qs[64][16];           // q  [query][c]
+  bf16_t DOs[64][16];          // dO [query][c]
+  bf16_t Pq[16][C16_PLD];      // P  of the current query tile, [query][key]
+  bf16_t Dq[16][C16_PLD];      // dS of the current query tile
+};
+static_assert(sizeof(C16WaveLds) == 15360, "wave LDS layout");
+static_assert(sizeof(float) * 16 * 113 <= sizeof(bf16_t) * (112 + 64 + 64) * 16, "KA must fit over Kh | Qs | DOs");
+
+__device__ __forceinline__ void mma4(f32x4& acc, bf16x4 a, bf16x4 b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
+}
+// transposing read: the lane passes the address of ITS 8-byte piece (row r0 + (i >> 2), columns 4 (i & 3) ..)
+// and receives column i of rows r0 .. r0 + 3  (i = lane & 15; r0 may differ per 16-lane group)
+__device__ __forceinline__ bf16x4 tr4(const bf16_t* p) {
+  typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)p);
+}
+__device__ __forceinline__ bf16x4 ld4(const bf16_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
+__device__ __forceinline__ void st4(bf16_t* p, bf16x4 v) { *reinterpret_cast<bf16x4*>(p) = v; }
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+  bf16x4 v;
+  v[0] = (bf16_t)a; v[1] = (bf16_t)b; v[2] = (bf16_t)c; v[3] = (bf16_t)d;
+  return v;
+}
+__device__ __forceinline__ bf16x4 zero4() { return pack4(0.f, 0.f, 0.f, 0.f); }
+// LDS operations of one wave execute in issue order, so a wave-private buffer needs no hardware wait between
+// its writes and the reads of other lanes -- only the compiler must not reorder them (a wavefront-scope fence
+// would also wait for the outstanding GLOBAL stores: measured 2x slower).
+__device__ __forceinline__ void wave_sync() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__global__ void __launch_bounds__(256, 2) window_attn_bwd_c16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                                  const float* __restrict__ rel_w, const bf16_t* __restrict__ go,
+                                                                  int ldg, int gc0, bf16_t* __restrict__ gqkv, bf16_t* __restrict__ win,
+                                                                  float* __restrict__ relw, int h, int w, int nwin) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wi = blockIdx.x * 4 + wv;
+  if (wi >= nwin) return;                         // no workgroup barrier anywhere: a wave may leave alone
+  C16WaveLds& L = reinterpret_cast<C16WaveLds*>(smem)[wv];
+  const int lr = lane & 15, g = lane >> 4;
+  const int nw = w / 8, nh = h / 8;
+  const int wx = wi % nw, wy = (wi / nw) % nh, b = wi / (nw * nh);
+  const long long img = (long long)b * h * w;
+
+  // ---- every global load of the window, in MFMA operand layout: row = 16 t + lr, channels 4g .. 4g+3 ----
+  bf16x4 kA[WA_KT], vA[WA_KT];
+  {
+    bf16x4 kraw[WA_KT];
+    f32x4 rel[WA_KT];
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const int key = 16 * t + lr;
+      const int kr = key / 10, kc = key - kr * 10;
+      const int y = 8 * wy + kr - 1, x = 8 * wx + kc - 1;
+      kraw[t] = zero4();
+      vA[t] = zero4();
+      rel[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (key < WA_NK) {
+        if (y >= 0 && y < h && x >= 0 && x < w) {
+          const bf16_t* pk = qkv + (img + (long long)y * w + x) * (3 * C16) + 4 * g;
+          kraw[t] = ld4(pk + C16);
+          vA[t] = ld4(pk + 2 * C16);
+        }
+        const float* rp = (g < 2) ? (rel_h + kr * (C16 / 2) + 4 * g) : (rel_w + kc * (C16 / 2) + 4 * g - C16 / 2);
+        rel[t] = *reinterpret_cast<const f32x4*>(rp);
+      }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const int q = 16 * qt + lr;
+      const long long qpix = img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
+      const bf16x4 qv = ld4(qkv + qpix * (3 * C16) + 4 * g);
+      st4(&L.Qs[q][4 * g], pack4(0.25f * (float)qv[0], 0.25f * (float)qv[1], 0.25f * (float)qv[2], 0.25f * (float)qv[3]));   // exact
+      st4(&L.DOs[q][4 * g], ld4(go + qpix * ldg + gc0 + 4 * g));
+    }
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      kA[t] = pack4((float)kraw[t][0] + rel[t][0], (float)kraw[t][1] + rel[t][1], (float)kraw[t][2] + rel[t][2],
+                    (float)kraw[t][3] + rel[t][3]);
+      st4(&L.Kh[16 * t + lr][4 * g], kA[t]);
+    }
+  }
+  wave_sync();
+  // channel-major K^ operands (rows = channel lr, contraction = keys 16 t + 4g ..)
+  bf16x4 kT[WA_KT];
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) kT[t] = tr4(&L.Kh[16 * t + 4 * g + (lr >> 2)][4 * (lr & 3)]);
+
+  f32x4 dvT[WA_KT], dkT[WA_KT];
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) { dvT[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dkT[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  // C^-1/2 = 1/4 is a power of two: q is pre-scaled exactly when it is staged, so S^T arrives scaled, dK^ = dS'^T q
+  // needs no further factor (dS' = P (dP - delta), unscaled) and dq = dS' K^ takes the factor on its 4 outputs.
+  const float scale = 0.25f;
+  const f32x4 L2E = (f32x4){1.4426950408889634f, 1.4426950408889634f, 1.4426950408889634f, 1.4426950408889634f};
+
+#pragma unroll 1
+  for (int qt = 0; qt < 4; ++qt) {
+    const bf16x4 qB = ld4(&L.Qs[16 * qt + lr][4 * g]);
+    const bf16x4 gB = ld4(&L.DOs[16 * qt + lr][4 * g]);
+    const bf16x4 qT = tr4(&L.Qs[16 * qt + 4 * g + (lr >> 2)][4 * (lr & 3)]);
+    const bf16x4 gT = tr4(&L.DOs[16 * qt + 4 * g + (lr >> 2)][4 * (lr & 3)]);
+    // S^T and dP^T for this query tile: rows = keys 16 t + 4g + r, column = query lr
+    f32x4 s[WA_KT], dp[WA_KT];
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      mma4(s[t], kA[t], qB);
+      mma4(dp[t], vA[t], gB);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * g + r >= 4) s[6][r] = -3.0e38f;                  // keys 100..111 (only the last tile has any)
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float nml = -mx * 1.4426950408889634f;
+    const f32x4 NM = (f32x4){nml, nml, nml, nml};
+    f32x4 sum4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const f32x4 x = s[t] * L2E + NM;                          // packed fma; exp(s - mx) = 2^x
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(x[r]);   // masked keys: 2^-huge = 0
+      sum4 += s[t];
+    }
+    f32x4 del4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) del4 += s[t] * dp[t];       // sum_keys e * dP (normalised below)
+    float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+    float delta = (del4[0] + del4[1]) + (del4[2] + del4[3]);
+    {                                                           // the two reductions travel together
+      const float s1 = __shfl_xor(sum, 16), d1 = __shfl_xor(delta, 16);
+      sum += s1; delta += d1;
+      const float s2 = __shfl_xor(sum, 32), d2 = __shfl_xor(delta, 32);
+      sum += s2; delta += d2;
+    }
+    const float inv = 1.0f / sum;
+    delta *= inv;
+    const f32x4 INV = (f32x4){inv, inv, inv, inv};
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) s[t] *= INV;                // P
+    const f32x4 DEL = (f32x4){delta, delta, delta, delta};
+    // dq^T [c][q] = scale * sum_keys K^[key][c] dS'^T[key][q], straight from the accumulator layout
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const f32x4 d4 = s[t] * (dp[t] - DEL);
+      const bf16x4 pb = pack4(s[t][0], s[t][1], s[t][2], s[t][3]);
+      const bf16x4 db = pack4(d4[0], d4[1], d4[2], d4[3]);
+      st4(&L.Pq[lr][16 * t + 4 * g], pb);
+      st4(&L.Dq[lr][16 * t + 4 * g], db);
+      mma4(o, kT[t], db);
+    }
+    o *= (f32x4){scale, scale, scale, scale};
+    {
+      const int q = 16 * qt + lr;
+      const long long qpix = img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
+      st4(gqkv + qpix * (3 * C16) + 4 * g, pack4(o[0], o[1], o[2], o[3]));
+    }
+    wave_sync();
+    // dV^T [c][key] += dO^T P ; dK^^T [c][key] += q^T dS   (contraction over this tile's 16 queries)
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const bf16x4 pB = tr4(&L.Pq[4 * g + (lr >> 2)][16 * t + 4 * (lr & 3)]);
+      const bf16x4 dB = tr4(&L.Dq[4 * g + (lr >> 2)][16 * t + 4 * (lr & 3)]);
+      mma4(dvT[t], gT, pB);
+      mma4(dkT[t], qT, dB);
+    }
+    wave_sync();
+  }
+
+  // ---- dK^ | dV rows of this window: lane holds channels 4g .. 4g+3 of key 16 t + lr ----
+  const long long wbase = (long long)wi * WA_NK * (2 * C16);
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) {
+    const int key = 16 * t + lr;
+    if (key < WA_NK) {
+      bf16_t* wp = win + wbase + (long long)key * (2 * C16) + 4 * g;
+      st4(wp, pack4(dkT[t][0], dkT[t][1], dkT[t][2], dkT[t][3]));
+      st4(wp + C16, pack4(dvT[t][0], dvT[t][1], dvT[t][2], dvT[t][3]));
+    }
+  }
+  // ---- rel-pos gradient: dK^ summed over key columns (c < 8) / key rows (c >= 8), phantom keys included ----
+  float(*KA)[113] = reinterpret_cast<float(*)[113]>(&L);
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) KA[4 * g + r][16 * t + lr] = dkT[t][r];
+  wave_sync();
+  for (int idx = lane; idx < 10 * C16; idx += 64) {
+    const int i = idx >> 4, c = idx & 15;
+    float a = 0.f;
+    if (c < C16 / 2) {
+#pragma unroll
+      for (int j = 0; j < 10; ++j) a += KA[c][i * 10 + j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 10; ++j) a += KA[c][j * 10 + i];
+    }
+    relw[((long long)wi * 10 + i) * C16 + c] = a;
+  }
+}
+
+}  // namespace
+
+int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
+                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st) {
+  const int nwin = B * (h / 8) * (w / 8);
+  const size_t sh = 4 * sizeof(C16WaveLds);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)window_attn_bwd_c16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(window_attn_bwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), sh, st, (const bf16_t*)qkv, rel_h, rel_w,
+                     (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, h, w, nwin);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}

@@ -139,6 +139,9 @@ int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const fl
                            int dwt_levels = 0,    // 1, 2: gout is the FULL-RES g_xc tensor; DWT^levels applied on load
                            bool gather = true,    // false: leave dK|dV in `win` (consumers gather with M2T_A_HALO)
                            bool resident = true); // bf16, C = 64 / 256: whole-window-resident kernel (k_attn_res.hip)
+// C = 16, bf16, no fused DWT: one wave per window (k_attn_c16.hip)
+int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
+                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st);
 // the resident kernel alone (bf16); M2T_UNSUPPORTED when (C, dwt_levels) has no instantiation
 int launch_window_attn_bwd_resident(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
                                     void* gqkv, void* win, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st);
