@@ -254,6 +254,8 @@ int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const fl
     return m2t_set_error(-2, "window_attn: fused IWT epilogue needs (levels, C) = (1, 64) or (2, 256) and the residual");
   const int nwin = B * (h / 8) * (w / 8);
   M2TProfScope ps(C == 16 ? M2T_PROF_ATTN_FWD_16 : (C == 64 ? M2T_PROF_ATTN_FWD_64 : M2T_PROF_ATTN_FWD_256), st);
+  if (dt != M2T_F32 && C == 16 && post_levels == 0)      // bf16 full-resolution branch: one wave per window
+    return launch_window_attn_fwd_c16(qkv, rel_h, rel_w, out, ldo, oc0, res, ldr, B, h, w, st);
 #define GO(T_, C_, L_) hipLaunchKernelGGL((window_attn_fwd_kernel<T_, C_, L_>), dim3(nwin), dim3(256), 0, st, (const T_*)qkv, rel_h, rel_w, (T_*)out, ldo, oc0, (const T_*)res, ldr, h, w)
 #define GOT(T_)                                                                                   \
   if (post_levels == 1) GO(T_, 64, 1); else if (post_levels == 2) GO(T_, 256, 2);                   \

@@ -1,4 +1,4 @@
-// k_attn_c16.hip -- backward of the 8x8 / 10x10 halo window attention for the C = 16 branch (bf16):
+// k_attn_c16.hip -- the 8x8 / 10x10 halo window attention of the C = 16 branch (bf16), backward and forward:
 // ONE WAVE PER WINDOW, no workgroup barriers.
 //
 // Same mathematics as window_attn_bwd_kernel (k_attn.hip; models/M2Trans_network.py:310-332 under autograd).
@@ -237,6 +237,108 @@ __global__ void __launch_bounds__(256, 2) window_attn_bwd_c16_kernel(const bf16_
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// forward, same organisation: S^T = K^ Q^T (one MFMA per tile), softmax on the accumulators, and
+// O^T = V^T P^T with P^T fed back from the accumulator layout; V is the only tensor that touches LDS
+// (row-major copy, read back channel-major by ds_read_b64_tr_b16).  out[q][oc0 + c] = O (+ res).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 4) window_attn_fwd_c16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                                     const float* __restrict__ rel_w, bf16_t* __restrict__ out, int ldo,
+                                                                     int oc0, const bf16_t* __restrict__ res, int ldr, int h, int w,
+                                                                     int nwin) {
+  __shared__ __attribute__((aligned(16))) bf16_t VsAll[4][112][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wi = blockIdx.x * 4 + wv;
+  if (wi >= nwin) return;
+  bf16_t(*Vs)[16] = VsAll[wv];
+  const int lr = lane & 15, g = lane >> 4;
+  const int nw = w / 8, nh = h / 8;
+  const int wx = wi % nw, wy = (wi / nw) % nh, b = wi / (nw * nh);
+  const long long img = (long long)b * h * w;
+  bf16x4 kA[WA_KT];
+  {
+    bf16x4 kraw[WA_KT], vraw[WA_KT];
+    f32x4 rel[WA_KT];
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const int key = 16 * t + lr;
+      const int kr = key / 10, kc = key - kr * 10;
+      const int y = 8 * wy + kr - 1, x = 8 * wx + kc - 1;
+      kraw[t] = zero4();
+      vraw[t] = zero4();
+      rel[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (key < WA_NK) {
+        if (y >= 0 && y < h && x >= 0 && x < w) {
+          const bf16_t* pk = qkv + (img + (long long)y * w + x) * (3 * C16) + 4 * g;
+          kraw[t] = ld4(pk + C16);
+          vraw[t] = ld4(pk + 2 * C16);
+        }
+        const float* rp = (g < 2) ? (rel_h + kr * (C16 / 2) + 4 * g) : (rel_w + kc * (C16 / 2) + 4 * g - C16 / 2);
+        rel[t] = *reinterpret_cast<const f32x4*>(rp);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      kA[t] = pack4((float)kraw[t][0] + rel[t][0], (float)kraw[t][1] + rel[t][1], (float)kraw[t][2] + rel[t][2],
+                    (float)kraw[t][3] + rel[t][3]);
+      st4(&Vs[16 * t + lr][4 * g], vraw[t]);
+    }
+  }
+  wave_sync();
+  bf16x4 vT[WA_KT];                               // rows = channel lr, contraction = keys 16 t + 4g ..
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) vT[t] = tr4(&Vs[16 * t + 4 * g + (lr >> 2)][4 * (lr & 3)]);
+  const f32x4 L2E = (f32x4){1.4426950408889634f, 1.4426950408889634f, 1.4426950408889634f, 1.4426950408889634f};
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int q = 16 * qt + lr;
+    const long long qpix = img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
+    const bf16x4 qv = ld4(qkv + qpix * (3 * C16) + 4 * g);
+    const bf16x4 qB = pack4(0.25f * (float)qv[0], 0.25f * (float)qv[1], 0.25f * (float)qv[2], 0.25f * (float)qv[3]);   // C^-1/2, exact
+    f32x4 s[WA_KT];
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      mma4(s[t], kA[t], qB);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * g + r >= 4) s[6][r] = -3.0e38f;                  // keys 100..111
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float nml = -mx * 1.4426950408889634f;
+    const f32x4 NM = (f32x4){nml, nml, nml, nml};
+    f32x4 sum4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const f32x4 x = s[t] * L2E + NM;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(x[r]);
+      sum4 += s[t];
+    }
+    float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    const f32x4 INV = (f32x4){inv, inv, inv, inv};
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const f32x4 pv = s[t] * INV;
+      mma4(o, vT[t], pack4(pv[0], pv[1], pv[2], pv[3]));
+    }
+    if (res) {
+      const bf16x4 rv = ld4(res + qpix * ldr + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] += (float)rv[r];
+    }
+    st4(out + qpix * ldo + oc0 + 4 * g, pack4(o[0], o[1], o[2], o[3]));
+  }
+}
+
 }  // namespace
 
 int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
@@ -251,6 +353,15 @@ int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float*
   }
   hipLaunchKernelGGL(window_attn_bwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), sh, st, (const bf16_t*)qkv, rel_h, rel_w,
                      (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, h, w, nwin);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_window_attn_fwd_c16(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0, const void* res,
+                               int ldr, int B, int h, int w, hipStream_t st) {
+  const int nwin = B * (h / 8) * (w / 8);
+  hipLaunchKernelGGL(window_attn_fwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), 0, st, (const bf16_t*)qkv, rel_h, rel_w,
+                     (bf16_t*)out, ldo, oc0, (const bf16_t*)res, ldr, h, w, nwin);
   M2T_LAUNCH_CHECK();
   return 0;
 }

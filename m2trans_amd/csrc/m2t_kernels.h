@@ -140,6 +140,8 @@ int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const fl
                            bool gather = true,    // false: leave dK|dV in `win` (consumers gather with M2T_A_HALO)
                            bool resident = true); // bf16, C = 64 / 256: whole-window-resident kernel (k_attn_res.hip)
 // C = 16, bf16, no fused DWT: one wave per window (k_attn_c16.hip)
+int launch_window_attn_fwd_c16(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0, const void* res,
+                               int ldr, int B, int h, int w, hipStream_t st);
 int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
                                void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st);
 // the resident kernel alone (bf16); M2T_UNSUPPORTED when (C, dwt_levels) has no instantiation
