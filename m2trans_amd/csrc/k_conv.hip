@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) head_conv_fwd_kernel(const float* __restr
           for (int e = 0; e < 16; ++e) acc[e] = fmaf(v, wr[e], acc[e]);
         }
       }
-    store16f(out + pix * 64 + og * 16, acc);
+    store16f(out + ((long long)og * B * H * W + pix) * 16, acc);     // P64: chunk og is a dense plane
   }
 }
 int launch_head_conv_fwd(int dt, const float* x, const float* w, const float* b, void* out, int B, int H0, int W0,
@@ -108,60 +108,8 @@ int launch_head_im2col(int dt, const float* x, void* cols, int B, int H0, int W0
   return 0;
 }
 
-// head conv weight gradient: dW[oc][ic*9+tap] = sum_pixels g[p][oc] * xsrc(p, ic, tap)
-// thread (oc = tid&63, part = tid>>6); block = contiguous pixel range; slabs [nblk][64*27]
-template <typename T>
-__global__ void __launch_bounds__(256) head_conv_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ g,
-                                                              float* __restrict__ slabs, int B, int H0, int W0, int H,
-                                                              int W, long long pix_per_block) {
-  const int oc = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const long long P = (long long)B * H * W;
-  const long long p0 = blockIdx.x * pix_per_block, p1 = min(P, p0 + pix_per_block);
-  float acc[27];
-#pragma unroll
-  for (int i = 0; i < 27; ++i) acc[i] = 0.f;
-  for (long long pix = p0 + part; pix < p1; pix += 4) {
-    const int xx = (int)(pix % W);
-    const long long q = pix / W;
-    const int yy = (int)(q % H);
-    const int b = (int)(q / H);
-    const float gv = to_f(g[pix * 64 + oc]);
-#pragma unroll
-    for (int ic = 0; ic < 3; ++ic)
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int sy = head_src(yy + ky - 1, H, H0);
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int sx = head_src(xx + kx - 1, W, W0);
-          acc[ic * 9 + ky * 3 + kx] = fmaf(gv, x[(((long long)b * 3 + ic) * H0 + sy) * W0 + sx], acc[ic * 9 + ky * 3 + kx]);
-        }
-      }
-  }
-  __shared__ float sh[4][27][64];
-#pragma unroll
-  for (int i = 0; i < 27; ++i) sh[part][i][oc] = acc[i];
-  __syncthreads();
-  for (int i = threadIdx.x; i < 27 * 64; i += 256) {
-    const int o = i / 27, q = i % 27;
-    slabs[(long long)blockIdx.x * (27 * 64) + i] = sh[0][q][o] + sh[1][q][o] + sh[2][q][o] + sh[3][q][o];
-  }
-}
-int launch_head_conv_wgrad(int dt, const float* x, const void* gout, float* slabs, int* nslab, int B, int H0, int W0,
-                           int H, int W, hipStream_t st) {
-  const long long P = (long long)B * H * W;
-  int nblk = (int)std::min<long long>(256, ceil_divll(P, 256));
-  const long long ppb = ceil_divll(P, nblk);
-  nblk = (int)ceil_divll(P, ppb);
-  if (dt == M2T_F32) hipLaunchKernelGGL(head_conv_wgrad_kernel<float>, dim3(nblk), dim3(256), 0, st, x, (const float*)gout, slabs, B, H0, W0, H, W, ppb);
-  else hipLaunchKernelGGL(head_conv_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, x, (const bf16_t*)gout, slabs, B, H0, W0, H, W, ppb);
-  M2T_LAUNCH_CHECK();
-  *nslab = nblk;
-  return 0;
-}
-
 // =======================================================================================
-// 64 -> 64 3x3 conv, zero padding: implicit GEMM on the matrix cores.
+// 64 -> 64 3x3 conv, zero padding: implicit GEMM on the matrix cores.  All feature maps are P64.
 // Workgroup = 8 x 16 output pixels x 64 output channels; 4 waves, wave w owns pixel rows
 // 2w, 2w+1 (two 16-pixel m-tiles) x 4 channel tiles.  LDS: input halo tile 10x18x64 and the
 // current tap's 64x64 weight slice.  Lane (pixel = lane&15, g = lane>>4) ends with 16
@@ -180,7 +128,8 @@ __global__ void __launch_bounds__(256) conv3x3_c64_kernel(const T* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const int x0 = blockIdx.x * C3_TW, y0 = blockIdx.y * C3_TH, b = blockIdx.z;
-  const T* xb = x + (long long)b * H * W * 64;
+  const long long npix = (long long)gridDim.z * H * W;      // x, res1, res2, y are P64: [4][npix][16]
+  const long long pb = (long long)b * H * W;
 
   // stage the halo tile (zero outside the image): every load first, then the LDS stores
   {
@@ -193,7 +142,7 @@ __global__ void __launch_bounds__(256) conv3x3_c64_kernel(const T* __restrict__ 
       const int py = p / (C3_TW + 2), px = p - py * (C3_TW + 2);
       const int gy = y0 + py - 1, gx = x0 + px - 1;
       f[it] = frag_zero<T>();
-      if (idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W) f[it] = load8(xb + ((long long)gy * W + gx) * 64 + cv * 8);
+      if (idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W) f[it] = load8(x + p64(npix, pb + (long long)gy * W + gx, cv * 8));
     }
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
@@ -249,7 +198,7 @@ __global__ void __launch_bounds__(256) conv3x3_c64_kernel(const T* __restrict__ 
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int gy = y0 + 2 * wv + mt, gx = x0 + lr;
-    const long long off = (((long long)b * H + gy) * W + gx) * 64 + 16 * g;
+    const long long off = ((long long)g * npix + pb + (long long)gy * W + gx) * 16;      // channels 16 g .. = plane g
     float v[16];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -291,12 +240,13 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
 // gy as Gs[m][oc], the zero-padded x halo as Xs[(row+1)*18 + col+1][ic]) and transposed by the LDS read
 // (ds_read_b64_tr_b16): 8 consecutive pixels of a tile row are 8 consecutive rows of either array, at any tap
 // offset.  Wave w owns oc rows 16w..16w+15 for all 4 ic tiles and all 9 taps (36 accumulators).
-// Output: fp32 slabs [nblk][9][64][64], summed (and permuted to torch layout) by the batched reduction.
+// Output: fp32 slabs [nblk][9][64][64] (+ bias slabs [nblk][64]: the bias gradient is one extra MFMA per step
+// against a ones operand), summed (and permuted to torch layout) by the batched reduction.  x, gy are P64.
 // =======================================================================================
 template <typename T, int TH>
 __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ gy,
-                                                                float* __restrict__ slabs, int B, int H, int W,
-                                                                int tiles_per_block) {
+                                                                float* __restrict__ slabs, float* __restrict__ bias_slabs, int B,
+                                                                int H, int W, int tiles_per_block) {
   constexpr int MT = TH * 16;              // pixels per tile
   constexpr int HX = (TH + 2) * 18;        // halo pixels
   constexpr int LD = 72;
@@ -307,11 +257,15 @@ __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restr
   const int g = lane >> 4;
   const int tw = W / 16, th = H / TH;
   const long long ntiles = (long long)B * th * tw;
-  f32x4 acc[9][4];
+  const long long npix = (long long)B * H * W;              // x, gy are P64
+  f32x4 acc[9][4], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < 9; ++a)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  Frag8<T> ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones.set(e, 1.0f);
 
   const long long t0 = (long long)blockIdx.x * tiles_per_block;
   const long long t1 = min(ntiles, t0 + tiles_per_block);
@@ -328,7 +282,7 @@ __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restr
     for (int it = 0; it < NG; ++it) {
       const int idx = tid + it * 256;
       const int m = idx >> 3, cv = idx & 7;
-      fg[it] = load8(gy + (((long long)b * H + y0 + (m >> 4)) * W + x0 + (m & 15)) * 64 + cv * 8);
+      fg[it] = load8(gy + p64(npix, ((long long)b * H + y0 + (m >> 4)) * W + x0 + (m & 15), cv * 8));
     }
 #pragma unroll
     for (int it = 0; it < NX; ++it) {
@@ -338,7 +292,7 @@ __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restr
       const int gyy = y0 + row - 1, gxx = x0 + xs;
       fx[it] = frag_zero<T>();
       if (idx < TOTX && gyy >= 0 && gyy < H && gxx >= 0 && gxx < W)
-        fx[it] = load8(x + (((long long)b * H + gyy) * W + gxx) * 64 + cv * 8);
+        fx[it] = load8(x + p64(npix, ((long long)b * H + gyy) * W + gxx, cv * 8));
     }
   };
   if (t0 < t1) fetch(t0);
@@ -361,6 +315,7 @@ __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restr
       // k-slot (g, j) <-> pixel m = 32 ch + 8 g + j : row = 2 ch + (g >> 1), col = 8 (g & 1) + j
       const int m0 = 32 * ch + 8 * g;
       const Frag8<T> gf = load8_tr(&Gs[m0][16 * wv], &Gs[m0 + 4][16 * wv], LD, lane);
+      mma16(accb, gf, ones);                 // bias gradient: row sums of gy^T ride along (every column equal)
 #pragma unroll
       for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -383,8 +338,12 @@ __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         out[((long long)tap * 64 + 16 * wv + 4 * g + r) * 64 + 16 * it + lr] = acc[tap][it][r];
+  if (lr == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias_slabs[(long long)blockIdx.x * 64 + 16 * wv + 4 * g + r] = accb[r];
+  }
 }
-int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, int* nslab, int B, int H, int W,
+int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, float* bias_slabs, int* nslab, int B, int H, int W,
                              hipStream_t st) {
   if (W % 16 || H % 8) return m2t_set_error(-2, "conv3x3_c64_wgrad: H%8 or W%16");
   const int TH = (dt == M2T_F32) ? 4 : 8;
@@ -395,11 +354,11 @@ int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs
   if (dt == M2T_F32) {
     const size_t sh = sizeof(float) * 72 * (4 * 16 + 6 * 18);
     (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<float, 4>), dim3(nblk), dim3(256), sh, st, (const float*)x, (const float*)gy, slabs, B, H, W, tpb);
+    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<float, 4>), dim3(nblk), dim3(256), sh, st, (const float*)x, (const float*)gy, slabs, bias_slabs, B, H, W, tpb);
   } else {
     const size_t sh = sizeof(bf16_t) * 72 * (8 * 16 + 10 * 18);
     (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<bf16_t, 8>), dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)gy, slabs, B, H, W, tpb);
+    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<bf16_t, 8>), dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)gy, slabs, bias_slabs, B, H, W, tpb);
   }
   M2T_LAUNCH_CHECK();
   *nslab = nblk;

@@ -93,7 +93,8 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __r
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
     if (EMODE == M2T_E_PLAIN) {
-      store16f(Y + m * ldy + nn, v);
+      if (ldy == M2T_LD_P64) store16f(Y + p64(M, m, nn), v);
+      else store16f(Y + m * ldy + nn, v);
     } else if (EMODE == M2T_E_BIAS) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] += bias[nn + e];
@@ -242,7 +243,7 @@ static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStr
     return launch_gemm_nt_wide<T, 64>(a, st);
   }
   dim3 grid((unsigned)ceil_divll(a.M, GEMM_BM), (unsigned)ceil_div(a.N, GEMM_BN));
-  ShufGeom sg{a.H, a.Wd, a.r, a.C, a.halo_win};
+  ShufGeom sg{a.H, a.Wd, a.r, a.C, a.halo_win, a.M};
 #define GO(AM, EM)                                                                                              \
   hipLaunchKernelGGL((gemm_nt_kernel<T, AM, EM>), grid, dim3(256), 0, st, (const T*)a.A, a.lda, (const T*)a.W, \
                      (T*)a.Y, a.ldy, a.bias, (const T*)a.aux, a.ldaux, (T*)a.Y2, a.M, a.N, a.K, sg)
@@ -279,7 +280,7 @@ int launch_gemm_nt(int dt, int amode, int emode, const m2t_gemm_args& a, hipStre
 template <typename T, int NSUB>
 __global__ void __launch_bounds__(256)
 tail_expand_kernel(const T* __restrict__ X, const T* __restrict__ Wp, const float* __restrict__ bias, T* __restrict__ Y,
-                   T* __restrict__ Yd, long long M, int H, int Wd, int r, int tiles_per_block) {
+                   T* __restrict__ Yd, long long M, int H, int Wd, int r, int tiles_per_block, int x_p64) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T(*Ws)[72] = reinterpret_cast<T(*)[72]>(smem);                                   // [64 NSUB][72]
   T(*As)[72] = reinterpret_cast<T(*)[72]>(smem + sizeof(T) * 64 * NSUB * 72);      // [128][72]
@@ -295,7 +296,7 @@ tail_expand_kernel(const T* __restrict__ X, const T* __restrict__ Wp, const floa
       const int idx = tid + it * 256;
       const long long m = t * 128 + (idx >> 3);
       ra[it] = frag_zero<T>();
-      if (m < M) ra[it] = load8(X + m * 64 + (idx & 7) * 8);
+      if (m < M) ra[it] = load8(X + (x_p64 ? p64(M, m, (idx & 7) * 8) : m * 64 + (idx & 7) * 8));
     }
   };
   if (t0 < t1) fetch(t0);
@@ -364,7 +365,7 @@ tail_expand_kernel(const T* __restrict__ X, const T* __restrict__ Wp, const floa
 }
 template <typename T>
 static int launch_tail_expand_t(const T* X, const T* Wp, const float* bias, T* Y, T* Yd, long long M, int H, int Wd, int r,
-                                hipStream_t st) {
+                                bool x_p64, hipStream_t st) {
   const long long ntiles = (M + 127) / 128;
   int nblk = (int)std::min<long long>(ntiles, 1024);
   const int tpb = (int)ceil_divll(ntiles, nblk);
@@ -373,7 +374,7 @@ static int launch_tail_expand_t(const T* X, const T* Wp, const float* bias, T* Y
   {                                                                                                                    \
     const size_t sh = sizeof(T) * (64 * NS_ + 128) * 72;                                                               \
     (void)hipFuncSetAttribute((const void*)tail_expand_kernel<T, NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-    hipLaunchKernelGGL((tail_expand_kernel<T, NS_>), dim3(nblk), dim3(256), sh, st, X, Wp, bias, Y, Yd, M, H, Wd, r, tpb); \
+    hipLaunchKernelGGL((tail_expand_kernel<T, NS_>), dim3(nblk), dim3(256), sh, st, X, Wp, bias, Y, Yd, M, H, Wd, r, tpb, x_p64 ? 1 : 0); \
   }
   if (r == 2) GO(4)
   else if (r == 3) GO(9)
@@ -383,17 +384,17 @@ static int launch_tail_expand_t(const T* X, const T* Wp, const float* bias, T* Y
   return 0;
 }
 int launch_tail_expand(int dt, const void* X, const void* Wp, const float* bias, void* Y, void* Yd, long long M, int H, int Wd,
-                       int r, hipStream_t st) {
+                       int r, bool x_p64, hipStream_t st) {
   if (dt == M2T_F32 && r == 3) {
     // fp32 x3: the 576 x 64 fp32 weight matrix does not fit LDS beside the tile -> generic tiled GEMM
     m2t_gemm_args ga{};
-    ga.A = X; ga.lda = 64; ga.W = Wp; ga.Y = Y; ga.ldy = 64; ga.bias = bias; ga.M = M; ga.N = 64 * r * r; ga.K = 64;
+    ga.A = X; ga.lda = x_p64 ? M2T_LD_P64 : 64; ga.W = Wp; ga.Y = Y; ga.ldy = 64; ga.bias = bias; ga.M = M; ga.N = 64 * r * r; ga.K = 64;
     ga.H = H; ga.Wd = Wd; ga.r = r; ga.C = 64;
     ga.Y2 = Yd;
     return launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_BIAS_SHUF, ga, st);
   }
-  if (dt == M2T_F32) return launch_tail_expand_t<float>((const float*)X, (const float*)Wp, bias, (float*)Y, (float*)Yd, M, H, Wd, r, st);
-  return launch_tail_expand_t<bf16_t>((const bf16_t*)X, (const bf16_t*)Wp, bias, (bf16_t*)Y, (bf16_t*)Yd, M, H, Wd, r, st);
+  if (dt == M2T_F32) return launch_tail_expand_t<float>((const float*)X, (const float*)Wp, bias, (float*)Y, (float*)Yd, M, H, Wd, r, x_p64, st);
+  return launch_tail_expand_t<bf16_t>((const bf16_t*)X, (const bf16_t*)Wp, bias, (bf16_t*)Y, (bf16_t*)Yd, M, H, Wd, r, x_p64, st);
 }
 
 // =======================================================================================
@@ -506,7 +507,7 @@ static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_
   int nslab = wgrad_slab_count(a.M, a.N, a.K);
   long long rps = ceil_divll(ceil_divll(a.M, nslab), WG_BM) * WG_BM;
   nslab = (int)ceil_divll(a.M, rps);
-  ShufGeom sg{a.H, a.Wd, a.r, a.C, a.halo_win};
+  ShufGeom sg{a.H, a.Wd, a.r, a.C, a.halo_win, a.M};
   dim3 grid(tn, tk, nslab);
 #define GO(GM, XM)                                                                                               \
   hipLaunchKernelGGL((wgrad_tn_kernel<T, GM, XM>), grid, dim3(256), 0, st, (const T*)a.G, a.ldg, (const T*)a.X, \

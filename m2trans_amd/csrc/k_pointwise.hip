@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(256) instnorm_stats1_kernel(const T* __restric
   // them 16 pixels at a time: all loads first, then an exact two-pass (mean, then squared deviations) on the
   // registers -- no per-element division -- and one Welford merge per 16 pixels.
   const int b = blockIdx.y, sp = blockIdx.x;
+  const long long npix = (long long)gridDim.y * P;          // x is P64
   const int cgp = threadIdx.x & 7, pl = threadIdx.x >> 3;   // 8 channel groups x 32 pixel lanes
   const int per = ceil_div(P, nsplit);
   const int p0 = sp * per, p1 = min(P, p0 + per);
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(256) instnorm_stats1_kernel(const T* __restric
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int p = pb + 32 * i;
-      if (p < p1) { load8f(x + ((long long)b * P + p) * 64 + cgp * 8, v[i]); ++cnt; }
+      if (p < p1) { load8f(x + p64(npix, (long long)b * P + p, cgp * 8), v[i]); ++cnt; }
       else {
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[i][c] = 0.f;
@@ -285,6 +286,7 @@ __global__ void __launch_bounds__(256) branch_prep_kernel(const T* __restrict__ 
                                                           int k, T* __restrict__ xin, T* __restrict__ d, int B, int H, int W) {
   constexpr int S = Haar<L>::S, N = Haar<L>::N;
   const int hb = H / S, wb = W / S;
+  const long long npix = (long long)B * H * W;
   const long long total = (long long)B * hb * wb * 4;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
@@ -303,12 +305,12 @@ __global__ void __launch_bounds__(256) branch_prep_kernel(const T* __restrict__ 
       for (int xx = 0; xx < S; ++xx) {
         const long long pix = ((long long)b * H + (i * S + y)) * W + (j * S + xx);
         float q[4];
-        load4(x + pix * 64 + k * 16 + g * 4, q);
+        load4(x + ((long long)k * npix + pix) * 16 + g * 4, q);            // P64: chunk k is a dense plane
 #pragma unroll
         for (int c = 0; c < 4; ++c) q[c] = (q[c] - mu[c]) * rs[c];
         if (k > 0) {
           float p[4];
-          load4(xc + pix * 64 + (k - 1) * 16 + g * 4, p);
+          load4(xc + ((long long)(k - 1) * npix + pix) * 16 + g * 4, p);
 #pragma unroll
           for (int c = 0; c < 4; ++c) q[c] = (q[c] + p[c]) * 0.5f;
         }
@@ -387,7 +389,7 @@ __global__ void __launch_bounds__(256) branch_post_kernel(const T* __restrict__ 
         float p[4];
         load4(xin + pix * 16 + g * 4, p);
         float q[4] = {v[0][y][xx] + p[0], v[1][y][xx] + p[1], v[2][y][xx] + p[2], v[3][y][xx] + p[3]};
-        store4(xc + pix * 64 + k * 16 + g * 4, q);
+        store4(xc + ((long long)k * B * H * W + pix) * 16 + g * 4, q);
       }
   }
 }
@@ -416,13 +418,14 @@ int launch_branch_post_bwd(int dt, int L, const void* gxc, int k, void* ga, int 
 //   g_xin = IWT^L(g_d) + g_xc[chunk k]                 (k >= 1, L >= 1)
 //   g_n[chunk k]     = g_xin / 2 ;   g_xc[chunk k-1] += g_xin / 2
 // and for k = 0 (L = 0):   g_n[chunk 0] = g_d + g_xc[chunk 0]
-// g_n, g_xc: [B][H][W][64]
+// g_n, g_xc: P64 ([4][B*H*W][16])
 // =======================================================================================
 template <typename T, int L>
 __global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restrict__ gd, T* __restrict__ gxc,
                                                               T* __restrict__ gn, int k, int B, int H, int W) {
   constexpr int S = Haar<L>::S, N = Haar<L>::N;
   const int hb = H / S, wb = W / S;
+  const long long npix = (long long)B * H * W;          // gxc, gn are P64
   const long long total = (long long)B * hb * wb * 4;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
@@ -449,19 +452,19 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restric
       for (int xx = 0; xx < S; ++xx) {
         const long long pix = ((long long)b * H + (i * S + y)) * W + (j * S + xx);
         float p[4];
-        load4(gxc + pix * 64 + k * 16 + g * 4, p);
+        load4(gxc + ((long long)k * npix + pix) * 16 + g * 4, p);
         float q[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) q[c] = v[c][y][xx] + p[c];
         if (k == 0) {
-          store4(gn + pix * 64 + g * 4, q);
+          store4(gn + pix * 16 + g * 4, q);
         } else {
           float pp[4];
-          load4(gxc + pix * 64 + (k - 1) * 16 + g * 4, pp);
+          load4(gxc + ((long long)(k - 1) * npix + pix) * 16 + g * 4, pp);
 #pragma unroll
           for (int c = 0; c < 4; ++c) { q[c] *= 0.5f; pp[c] += q[c]; }
-          store4(gn + pix * 64 + k * 16 + g * 4, q);
-          store4(gxc + pix * 64 + (k - 1) * 16 + g * 4, pp);
+          store4(gn + ((long long)k * npix + pix) * 16 + g * 4, q);
+          store4(gxc + ((long long)(k - 1) * npix + pix) * 16 + g * 4, pp);
         }
       }
   }
@@ -490,6 +493,7 @@ __global__ void __launch_bounds__(256) instnorm_bwd_red1_kernel(const T* __restr
                                                                 float* __restrict__ part, int P, int nsplit) {
   // part [B][nsplit][64][2]
   const int b = blockIdx.y, sp = blockIdx.x;
+  const long long npix = (long long)gridDim.y * P;          // gn, x are P64
   const int cgp = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int per = ceil_div(P, nsplit);
   const int p0 = sp * per, p1 = min(P, p0 + per);
@@ -498,8 +502,8 @@ __global__ void __launch_bounds__(256) instnorm_bwd_red1_kernel(const T* __restr
   for (int c = 0; c < 8; ++c) { mu[c] = mean[b * 64 + cgp * 8 + c]; rs[c] = rstd[b * 64 + cgp * 8 + c]; s1[c] = 0.f; s2[c] = 0.f; }
   for (int p = p0 + pl; p < p1; p += 32) {
     float g[8], v[8];
-    load8f(gn + ((long long)b * P + p) * 64 + cgp * 8, g);
-    load8f(x + ((long long)b * P + p) * 64 + cgp * 8, v);
+    load8f(gn + p64(npix, (long long)b * P + p, cgp * 8), g);
+    load8f(x + p64(npix, (long long)b * P + p, cgp * 8), v);
 #pragma unroll
     for (int c = 0; c < 8; ++c) { s1[c] += g[c]; s2[c] += g[c] * ((v[c] - mu[c]) * rs[c]); }
   }
@@ -548,9 +552,10 @@ __global__ void __launch_bounds__(256) instnorm_bwd_apply_kernel(const T* __rest
     const long long pix = t >> 3;
     const int b = (int)(pix / P);
     float g[8], v[8], r[8];
-    load8f(gn + pix * 64 + cgp * 8, g);
-    load8f(x + pix * 64 + cgp * 8, v);
-    load8f(gres + pix * 64 + cgp * 8, r);
+    const long long o64 = p64((long long)B * P, pix, cgp * 8);     // all four tensors are P64
+    load8f(gn + o64, g);
+    load8f(x + o64, v);
+    load8f(gres + o64, r);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int ch = b * 64 + cgp * 8 + c;
@@ -558,7 +563,7 @@ __global__ void __launch_bounds__(256) instnorm_bwd_apply_kernel(const T* __rest
       const float xh = (v[c] - mean[ch]) * rs;
       r[c] += rs * (g[c] - s[ch * 2] - xh * s[ch * 2 + 1]);
     }
-    store8f(gx + pix * 64 + cgp * 8, r);
+    store8f(gx + o64, r);
   }
 }
 int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean, const float* rstd, const void* gres,

@@ -86,11 +86,9 @@ struct m2t_plan {
   long long npacked = 0;
   bool have_seed = false, have_acts = false;
   bool use_side = true;
-  bool use_fused_tail = false;     // measured: ties the three-kernel sequence (42 us per branch either way)
   bool debug_skip_side = false;    // timing experiments only: skip every parameter-gradient kernel (results are WRONG)      // halo gather + qkv dgrad GEMM + prep_bwd as one kernel (k_branch.hip)
   bool use_gated_side = true;      // see the side-stream schedule in m2t_backward
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
-  bool use_fused_branch = false;   // fused forward branch kernel (k_branch.hip): correct, currently ties the unfused chain
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
   // region; the descriptor table is identical every step, so it is uploaded once
   std::vector<m2t_red_desc> red_descs;
@@ -329,11 +327,8 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
       void* qkv = WSP(k + "qkv" + std::to_string(i + 1));
       const float* rh = params + p->poff.at(an + "rel_h");
       const float* rw = params + p->poff.at(an + "rel_w");
-      // fused branch kernel (prep + projection + attention + IWT/residual in one launch per window)
-      int rc = p->use_fused_branch ? launch_branch_fwd(dt, L, X, mean, rstd, xc, i, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1)),
-                                                       rh, rw, WSP("xin"), d, qkv, B, h, w, st) : M2T_UNSUPPORTED;
-      if (rc != 0 && rc != M2T_UNSUPPORTED) return rc;
-      if (rc == M2T_UNSUPPORTED) {
+      {
+        void* xc_i = (char*)xc + (size_t)i * BP * 16 * p->esz;       // chunk i of the P64 concat buffer: a dense plane
         CK(launch_branch_prep(dt, L, X, mean, rstd, xc, i, WSP("xin"), d, B, H, W, st));
         m2t_gemm_args ga{};
         ga.A = d; ga.lda = C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1));
@@ -341,10 +336,10 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
         { M2TProfScope ps(M2T_PROF_GEMM_QKV, st); CK(launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_PLAIN, ga, st)); }
         if (i == 0) {
           // x1 = attn1(x1) + x1 written straight into the concat buffer (:139,163)
-          CK(launch_window_attn_fwd(dt, qkv, rh, rw, xc, 64, 0, d, 16, B, h, w, C, st));
+          CK(launch_window_attn_fwd(dt, qkv, rh, rw, xc_i, 16, 0, d, 16, B, h, w, C, st));
         } else {
           // x_k = IWT^L(attn_k(.)) + x_k_in written straight into the concat buffer (:145,153,161,163)
-          CK(launch_window_attn_fwd(dt, qkv, rh, rw, xc, 64, 16 * i, WSP("xin"), 16, B, h, w, C, st, L));
+          CK(launch_window_attn_fwd(dt, qkv, rh, rw, xc_i, 16, 0, WSP("xin"), 16, B, h, w, C, st, L));
         }
       }
     }
@@ -356,12 +351,12 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
   void* Y = WSP("X" + std::to_string(p->nb));
   const int r0 = (s == 4) ? 2 : s;
   { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st);
-    CK(launch_tail_expand(dt, Y, packed_ptr(p, workspace, "t0"), params + p->poff.at("tail.0.bias"), WSP("t1act"), WSP("t1der"), BP, H, W, r0, st)); }
+    CK(launch_tail_expand(dt, Y, packed_ptr(p, workspace, "t0"), params + p->poff.at("tail.0.bias"), WSP("t1act"), WSP("t1der"), BP, H, W, r0, true, st)); }
   const void* last_act = WSP("t1act");
   if (s == 4) {
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st);
       CK(launch_tail_expand(dt, WSP("t1act"), packed_ptr(p, workspace, "t3"), params + p->poff.at("tail.3.bias"), WSP("t2act"), WSP("t2der"),
-                            BP * 4, 2 * H, 2 * W, 2, st)); }
+                            BP * 4, 2 * H, 2 * W, 2, false, st)); }
     last_act = WSP("t2act");
   }
   const float* wlast = params + p->poff.at(s == 4 ? "tail.6.weight" : "tail.3.weight");
@@ -519,7 +514,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     float* slabs = arena_alloc((size_t)wgrad_slab_count(BP, N0, 64) * N0 * 64);
     float* colp = arena_alloc((size_t)wgrad_slab_count(BP, N0, 64) * N0);
     m2t_wgrad_args wa{};
-    wa.G = WSP("g_t1pre"); wa.gmode = M2T_A_UNSHUF; wa.X = Y; wa.ldx = 64; wa.xmode = M2T_A_PLAIN;
+    wa.G = WSP("g_t1pre"); wa.gmode = M2T_A_UNSHUF; wa.X = Y; wa.ldx = M2T_LD_P64; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = N0; wa.K = 64; wa.H = H; wa.Wd = W; wa.r = r0; wa.C = 64;
     if (!skip) {
     { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
@@ -527,7 +522,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     defer(colp, p->poff.at("tail.0.bias"), ns, N0, 2, 64, r0 * r0, 1);
     }
     m2t_gemm_args ga{};
-    ga.A = WSP("g_t1pre"); ga.W = packed_ptr(p, workspace, "t0T"); ga.Y = WSP("gT"); ga.ldy = 64;
+    ga.A = WSP("g_t1pre"); ga.W = packed_ptr(p, workspace, "t0T"); ga.Y = WSP("gT"); ga.ldy = M2T_LD_P64;
     ga.M = BP; ga.N = 64; ga.K = N0; ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_PLAIN, ga, st)); }
   }
@@ -562,11 +557,9 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       if (skip) return 0;
       float* slabs = arena_alloc((size_t)256 * 9 * 64 * 64);
       float* colp = arena_alloc((size_t)256 * 64);
-      { M2TProfScope ps(M2T_PROF_CONV3_WGRAD, sd); CK(launch_conv3x3_c64_wgrad(dt, xc, gy_blk, slabs, &ns, B, H, W, sd)); }
+      { M2TProfScope ps(M2T_PROF_CONV3_WGRAD, sd); CK(launch_conv3x3_c64_wgrad(dt, xc, gy_blk, slabs, colp, &ns, B, H, W, sd)); }
       defer(slabs, p->poff.at(pre + "feed_forward.0.weight"), ns, 9 * 64 * 64, 1, 64, 64, 0);
-      int nb2 = 0;
-      CK(launch_colsum(dt, gy_blk, 64, BP, 64, colp, 256, nullptr, 0, sd, 0, 0, 0, 1, 64, &nb2));
-      defer(colp, p->poff.at(pre + "feed_forward.0.bias"), nb2, 64, 0, 0, 0, 0);
+      defer(colp, p->poff.at(pre + "feed_forward.0.bias"), ns, 64, 0, 0, 0, 0);     // bias gradient rode along
       return 0;
     };
     auto side_branch = [&](int i) -> int {     // qkv weight gradient + rel-pos partial reduction of branch i
@@ -611,9 +604,8 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       // into gqkv for the weight-gradient GEMM, multiplies by Wqkv and applies IWT / branch mixing.
       // (gathering inside the TILED GEMM / wgrad loaders, M2T_A_HALO, was measured slower: the gather is then
       //  repeated once per column-block.)
-      CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc, 64, 16 * i, gqkv, win, relw, B, h, w, C, st, L, !p->use_fused_tail, p->use_resident_attn_bwd));
-      if (p->use_fused_tail)
-        CK(launch_branch_bwd_tail(dt, L, gqkv, win, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T"), gxc, gn, i, B, h, w, st));
+      const void* gxc_i = (const char*)gxc + (size_t)i * BP * 16 * p->esz;       // chunk i of the P64 gradient: a dense plane
+      CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, st, L, true, p->use_resident_attn_bwd));
       if (!gated) {
         fork();
         CK(side_branch(i));
@@ -631,7 +623,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         CK(side_branch(i));
         branch_done[i] = side_marker();
       }
-      if (!p->use_fused_tail) {
+      {
         m2t_gemm_args ga{};
         ga.A = gqkv; ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
         ga.Y = WSP("gd"); ga.ldy = C; ga.M = M; ga.N = C; ga.K = 3 * C; ga.H = h; ga.Wd = w; ga.r = 1; ga.C = C; ga.halo_win = win;
@@ -656,7 +648,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     float* slabs = arena_alloc((size_t)nsl * 64 * 32);
     float* colp = arena_alloc((size_t)nsl * 64);
     m2t_wgrad_args wa{};
-    wa.G = WSP("gxc"); wa.ldg = 64; wa.gmode = M2T_A_PLAIN; wa.X = WSP("head_cols"); wa.ldx = 32; wa.xmode = M2T_A_PLAIN;
+    wa.G = WSP("gxc"); wa.ldg = M2T_LD_P64; wa.gmode = M2T_A_PLAIN; wa.X = WSP("head_cols"); wa.ldx = 32; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = 64; wa.K = 32; wa.H = H; wa.Wd = W; wa.r = 1; wa.C = 64;
     CK(launch_wgrad_tn(dt, wa, &ns, sd));
     defer(slabs, p->poff.at("head.weight"), ns, 64 * 32, 5, 32, 27, 0);
@@ -683,8 +675,6 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
 extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (!p || !key) return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: null");
   if (std::string(key) == "side_stream") { p->use_side = (value != 0); return 0; }
-  if (std::string(key) == "fused_branch") { p->use_fused_branch = (value != 0); return 0; }
-  if (std::string(key) == "fused_tail") { p->use_fused_tail = (value != 0); return 0; }
   if (std::string(key) == "gated_side") { p->use_gated_side = (value != 0); return 0; }
   if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }

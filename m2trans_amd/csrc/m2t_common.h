@@ -225,5 +225,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 int m2t_set_hip_error(hipError_t e, const char* file, int line);
 int m2t_set_error(int code, const char* msg);
 
+// ---------------------------------------------------------------------------------------
+// "P64": the chunk-planar layout of every 64-channel low-resolution feature map (X_b, xc, their gradients):
+// [4 chunks][npix][16 channels].  Each CFTM branch works on ONE 16-channel chunk (models/M2Trans_network.py:
+// 129-161); with channel-interleaved rows [npix][64] every such access fetched the whole 128-byte row for 32
+// useful bytes (rocprof FETCH_SIZE: 33.6 MB per branch_prep launch for 8.4 MB of input).
+// ---------------------------------------------------------------------------------------
+__host__ __device__ static inline long long p64(long long npix, long long pix, int c) {
+  return ((long long)(c >> 4) * npix + pix) * 16 + (c & 15);
+}
+
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ static inline long long ceil_divll(long long a, long long b) { return (a + b - 1) / b; }

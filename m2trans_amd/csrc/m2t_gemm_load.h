@@ -2,7 +2,7 @@
 #pragma once
 #include "m2t_kernels.h"
 
-struct ShufGeom { int H, W, r, C; const void* aux = nullptr; };
+struct ShufGeom { int H, W, r, C; const void* aux = nullptr; long long npix = 0; };   // npix: rows of a P64 operand
 
 // logical A row m, logical column k..k+7  ->  8 elements
 template <typename T, int AMODE>
@@ -53,6 +53,7 @@ __device__ __forceinline__ Frag8<T> gemm_load_a(const T* __restrict__ A, int lda
     for (int e = 0; e < 8; ++e) r.set(e, acc[e]);
     return r;
   }
+  if (lda == M2T_LD_P64) return load8(A + p64(sg.npix, m, k));
   Frag8<T> f = load8(A + m * lda + k);
   if (AMODE == M2T_A_GELU) {
 #pragma unroll

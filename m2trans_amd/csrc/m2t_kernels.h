@@ -64,6 +64,8 @@ int launch_layout(int dt, const float* nchw, void* nhwc, float* nchw_out, int B,
 
 // ---- k_gemm.hip -------------------------------------------------------------------------
 // Y[M][N] = A[M][K] * W[N][K]^T  with A-side and epilogue variants
+// leading dimension sentinel: the operand / output is a P64 feature map ([4][M][16], m2t_common.h) with M rows
+#define M2T_LD_P64 (-64)
 enum m2t_gemm_a { M2T_A_PLAIN = 0, M2T_A_GELU = 1, M2T_A_UNSHUF = 2, M2T_A_HALO = 3 };
 enum m2t_gemm_epi { M2T_E_PLAIN = 0, M2T_E_BIAS = 1, M2T_E_BIAS_SHUF = 2, M2T_E_GELU_GRAD = 3, M2T_E_BIAS_GELU = 4, M2T_E_BIAS_RESID = 5 };
 struct m2t_gemm_args {
@@ -81,7 +83,7 @@ int launch_gemm_nt(int dt, int amode, int emode, const m2t_gemm_args& a, hipStre
 // upsampler 1x1 conv + bias + pixel-shuffle scatter + GELU, K = 64, N = 64 r^2; X rows over [B][H][Wd];
 // Y = gelu(t), Yd = gelu'(t) (both [B][H r][Wd r][64])
 int launch_tail_expand(int dt, const void* X, const void* Wp, const float* bias, void* Y, void* Yd, long long M, int H, int Wd,
-                       int r, hipStream_t st);
+                       int r, bool x_p64, hipStream_t st);   // x_p64: X is a P64 feature map (else rows of 64)
 // dW[N][K] (fp32 slabs) = sum_m G[m][N]^T X[m][K];  G/X side variants as above
 struct m2t_wgrad_args {
   const void* G; int ldg; int gmode;   // M2T_A_PLAIN or M2T_A_UNSHUF
@@ -99,13 +101,11 @@ int wgrad_slab_count(long long M, int N, int K);   // upper bound of the slabs l
 int launch_head_conv_fwd(int dt, const float* x, const float* w, const float* b, void* out, int B, int H0, int W0,
                          int H, int W, hipStream_t st);
 int launch_head_im2col(int dt, const float* x, void* cols, int B, int H0, int W0, int H, int W, hipStream_t st);   // cols [B*H*W][32] (T)
-int launch_head_conv_wgrad(int dt, const float* x, const void* gout, float* slabs, int* nslab, int B, int H0, int W0,
-                           int H, int W, hipStream_t st);
 // 64->64 3x3, zero padding.  wp: packed [9][64 out][64 in] (T). y = conv(x) + bias + res1 + res2 (each optional)
 int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias, const void* res1, const void* res2,
                        void* y, int B, int H, int W, hipStream_t st);
-int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, int* nslab, int B, int H, int W,
-                             hipStream_t st);
+int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, float* bias_slabs, int* nslab, int B, int H,
+                             int W, hipStream_t st);   // bias_slabs [nslab][64]: column sums of gy
 // tail conv 64->3, reflect padding, input = the stored activation gelu(t); output NCHW fp32 [B][3][H][W]
 int launch_final_conv_fwd(int dt, const void* tpre, const float* w, float* out, int B, int H, int W, hipStream_t st);
 int launch_final_conv_dgrad(int dt, const float* gout, const float* w, const void* tpre, void* gtpre, int B, int H, int W,
@@ -115,16 +115,7 @@ int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* 
 
 // ---- k_branch.hip -----------------------------------------------------------------------
 // one CFTM branch of the forward pass (prep + qkv projection + window attention + IWT/residual) per window;
-// returns M2T_UNSUPPORTED (and launches nothing) for the one unsupported combination (fp32, L = 2)
 #define M2T_UNSUPPORTED (-1000)
-int launch_branch_fwd(int dt, int L, const void* X, const float* mean, const float* rstd, void* xc, int k, const void* Wqkv,
-                      const float* rel_h, const float* rel_w, void* xin, void* dout, void* qkv, int B, int h, int w,
-                      hipStream_t st);
-
-// backward tail of one branch: halo gather of dK|dV (written back into gqkv) + qkv data-gradient GEMM + IWT/mix
-// (branch_prep_bwd) in one kernel.  gqkv [B][h][w][3C] (q part valid), win [B*L][100][2C], WT [C][3C]
-int launch_branch_bwd_tail(int dt, int L, void* gqkv, const void* win, const void* WT, void* gxc, void* gn, int k, int B, int h,
-                           int w, hipStream_t st);
 
 // ---- k_attn.hip -------------------------------------------------------------------------
 // qkv [B][h][w][3C] (q | k | v), rel_h/rel_w fp32 [10][C/2];  out rows at ldo (+ optional residual rows at ldr)

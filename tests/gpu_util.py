@@ -43,5 +43,11 @@ def rms_rel(a: torch.Tensor, b: torch.Tensor) -> float:
 
 
 def ws_nchw(plan, name, B, H, W, C):
-    """Workspace tensor (NHWC in the plan's dtype) -> float32 NCHW on the CPU."""
-    return nhwc_to_nchw(plan.ws_tensor(name).view(B, H, W, C).float()).cpu()
+    """Workspace tensor (NHWC in the plan's dtype) -> float32 NCHW on the CPU.  The 64-channel low-resolution
+    feature maps (X_b, b*.xc) are chunk-planar ("P64": [4][B*H*W][16], csrc/m2t_common.h)."""
+    import re
+    t = plan.ws_tensor(name)
+    if C == 64 and re.fullmatch(r"X\d+|b\d+\.xc", name):
+        t = t.view(4, B, H, W, 16).permute(1, 2, 3, 0, 4).reshape(B, H, W, 64)
+        return nhwc_to_nchw(t.float()).cpu()
+    return nhwc_to_nchw(t.view(B, H, W, C).float()).cpu()
