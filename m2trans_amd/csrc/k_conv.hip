@@ -239,12 +239,12 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
 // pixel-contiguous per channel: the tiles are staged row-major exactly as they lie in HBM (16-byte stores:
 // gy as Gs[m][oc], the zero-padded x halo as Xs[(row+1)*18 + col+1][ic]) and transposed by the LDS read
 // (ds_read_b64_tr_b16): 8 consecutive pixels of a tile row are 8 consecutive rows of either array, at any tap
-// offset.  Wave w owns oc rows 16w..16w+15 for all 4 ic tiles and all 9 taps (36 accumulators).
+// offset.  8 waves: wave (op, tq) owns two oc tiles for all 4 ic tiles and 2-3 taps (24 accumulators).
 // Output: fp32 slabs [nblk][9][64][64] (+ bias slabs [nblk][64]: the bias gradient is one extra MFMA per step
 // against a ones operand), summed (and permuted to torch layout) by the batched reduction.  x, gy are P64.
 // =======================================================================================
 template <typename T, int TH>
-__global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+__global__ void __launch_bounds__(512) conv3x3_c64_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ gy,
                                                                 float* __restrict__ slabs, float* __restrict__ bias_slabs, int B,
                                                                 int H, int W, int tiles_per_block) {
   constexpr int MT = TH * 16;              // pixels per tile
@@ -253,24 +253,31 @@ __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restr
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T(*Gs)[LD] = reinterpret_cast<T(*)[LD]>(smem);                          // [MT][72]
   T(*Xs)[LD] = reinterpret_cast<T(*)[LD]>(smem + sizeof(T) * MT * LD);    // [HX][72]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // 8 waves: wave (op, tq) owns the oc tiles 2 op, 2 op + 1 and the taps of quarter tq = {0,1,2} {3,4} {5,6} {7,8}:
+  // every transposed x operand feeds two MFMAs, which halves the LDS read traffic that bounds this kernel
+  const int tid = threadIdx.x, lane = tid & 63, op = (tid >> 6) & 1, tq = tid >> 7;
+  const int tap0 = (tq == 0) ? 0 : 2 * tq + 1, ntap = (tq == 0) ? 3 : 2;
   const int g = lane >> 4;
   const int tw = W / 16, th = H / TH;
   const long long ntiles = (long long)B * th * tw;
   const long long npix = (long long)B * H * W;              // x, gy are P64
-  f32x4 acc[9][4], accb = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[3][2][4], accb[2];
 #pragma unroll
-  for (int a = 0; a < 9; ++a)
+  for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][o][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  accb[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  accb[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   Frag8<T> ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones.set(e, 1.0f);
 
   const long long t0 = (long long)blockIdx.x * tiles_per_block;
   const long long t1 = min(ntiles, t0 + tiles_per_block);
-  constexpr int NG = MT * 8 / 256;
-  constexpr int TOTX = HX * 8, NX = (TOTX + 255) / 256;
+  constexpr int NG = MT * 8 / 512;
+  constexpr int TOTX = HX * 8, NX = (TOTX + 511) / 512;
   Frag8<T> fg[NG], fx[NX];
   auto fetch = [&](long long t) {          // all global loads of a tile, into registers
     const int tx = (int)(t % tw);
@@ -280,13 +287,13 @@ __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restr
     const int x0 = tx * 16, y0 = ty * TH;
 #pragma unroll
     for (int it = 0; it < NG; ++it) {
-      const int idx = tid + it * 256;
+      const int idx = tid + it * 512;
       const int m = idx >> 3, cv = idx & 7;
       fg[it] = load8(gy + p64(npix, ((long long)b * H + y0 + (m >> 4)) * W + x0 + (m & 15), cv * 8));
     }
 #pragma unroll
     for (int it = 0; it < NX; ++it) {
-      const int idx = tid + it * 256;
+      const int idx = tid + it * 512;
       const int p = idx >> 3, cv = idx & 7;
       const int row = p / 18, xs = p - row * 18 - 1;        // xs in [-1, 16]
       const int gyy = y0 + row - 1, gxx = x0 + xs;
@@ -300,12 +307,12 @@ __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restr
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < NG; ++it) {
-      const int idx = tid + it * 256;
+      const int idx = tid + it * 512;
       store8(&Gs[idx >> 3][(idx & 7) * 8], fg[it]);
     }
 #pragma unroll
     for (int it = 0; it < NX; ++it) {
-      const int idx = tid + it * 256;
+      const int idx = tid + it * 512;
       if (idx < TOTX) store8(&Xs[idx >> 3][(idx & 7) * 8], fx[it]);
     }
     __syncthreads();
@@ -314,33 +321,49 @@ __global__ void __launch_bounds__(256) conv3x3_c64_wgrad_kernel(const T* __restr
     for (int ch = 0; ch < MT / 32; ++ch) {
       // k-slot (g, j) <-> pixel m = 32 ch + 8 g + j : row = 2 ch + (g >> 1), col = 8 (g & 1) + j
       const int m0 = 32 * ch + 8 * g;
-      const Frag8<T> gf = load8_tr(&Gs[m0][16 * wv], &Gs[m0 + 4][16 * wv], LD, lane);
-      mma16(accb, gf, ones);                 // bias gradient: row sums of gy^T ride along (every column equal)
+      Frag8<T> gf[2];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+      for (int o = 0; o < 2; ++o) gf[o] = load8_tr(&Gs[m0][16 * (2 * op + o)], &Gs[m0 + 4][16 * (2 * op + o)], LD, lane);
+      if (tq == 0) {                         // bias gradient: row sums of gy^T ride along (every column equal)
+        mma16(accb[0], gf[0], ones);
+        mma16(accb[1], gf[1], ones);
+      }
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+      for (int tl = 0; tl < 3; ++tl) {
+        if (tl < ntap) {
+          const int tap = tap0 + tl;
+          const int ky = tap / 3, kx = tap - 3 * ky;
           const int hp = (2 * ch + (g >> 1) + ky) * 18 + 8 * (g & 1) + kx;
 #pragma unroll
           for (int it = 0; it < 4; ++it) {
             const Frag8<T> xf = load8_tr(&Xs[hp][16 * it], &Xs[hp + 4][16 * it], LD, lane);
-            mma16(acc[ky * 3 + kx][it], gf, xf);
+            mma16(acc[tl][0][it], gf[0], xf);
+            mma16(acc[tl][1][it], gf[1], xf);
           }
         }
+      }
     }
   }
   const int lr = lane & 15;
   float* out = slabs + (long long)blockIdx.x * (9 * 64 * 64);
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
+  for (int tl = 0; tl < 3; ++tl) {
+    if (tl < ntap) {
+      const int tap = tap0 + tl;
 #pragma unroll
-    for (int it = 0; it < 4; ++it)
+      for (int o = 0; o < 2; ++o)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        out[((long long)tap * 64 + 16 * wv + 4 * g + r) * 64 + 16 * it + lr] = acc[tap][it][r];
-  if (lr == 0) {
+        for (int it = 0; it < 4; ++it)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias_slabs[(long long)blockIdx.x * 64 + 16 * wv + 4 * g + r] = accb[r];
+          for (int r = 0; r < 4; ++r)
+            out[((long long)tap * 64 + 16 * (2 * op + o) + 4 * g + r) * 64 + 16 * it + lr] = acc[tl][o][it][r];
+    }
+  }
+  if (lr == 0 && tq == 0) {
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias_slabs[(long long)blockIdx.x * 64 + 16 * (2 * op + o) + 4 * g + r] = accb[o][r];
   }
 }
 int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, float* bias_slabs, int* nslab, int B, int H, int W,
@@ -354,11 +377,11 @@ int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs
   if (dt == M2T_F32) {
     const size_t sh = sizeof(float) * 72 * (4 * 16 + 6 * 18);
     (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<float, 4>), dim3(nblk), dim3(256), sh, st, (const float*)x, (const float*)gy, slabs, bias_slabs, B, H, W, tpb);
+    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<float, 4>), dim3(nblk), dim3(512), sh, st, (const float*)x, (const float*)gy, slabs, bias_slabs, B, H, W, tpb);
   } else {
     const size_t sh = sizeof(bf16_t) * 72 * (8 * 16 + 10 * 18);
     (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<bf16_t, 8>), dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)gy, slabs, bias_slabs, B, H, W, tpb);
+    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<bf16_t, 8>), dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)gy, slabs, bias_slabs, B, H, W, tpb);
   }
   M2T_LAUNCH_CHECK();
   *nslab = nblk;

@@ -741,6 +741,18 @@ __global__ void __launch_bounds__(256) multi_reduce_kernel(const float* __restri
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (e < d.n) {
       int s = g;
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      for (; s + 28 < d.ns; s += 32) {           // eight loads in flight per lane
+        a0 += slab[(long long)s * d.n + e];
+        a1 += slab[(long long)(s + 4) * d.n + e];
+        a2 += slab[(long long)(s + 8) * d.n + e];
+        a3 += slab[(long long)(s + 12) * d.n + e];
+        b0 += slab[(long long)(s + 16) * d.n + e];
+        b1 += slab[(long long)(s + 20) * d.n + e];
+        b2 += slab[(long long)(s + 24) * d.n + e];
+        b3 += slab[(long long)(s + 28) * d.n + e];
+      }
+      a0 += b0; a1 += b1; a2 += b2; a3 += b3;
       for (; s + 12 < d.ns; s += 16) {
         a0 += slab[(long long)s * d.n + e];
         a1 += slab[(long long)(s + 4) * d.n + e];
@@ -761,7 +773,7 @@ __global__ void __launch_bounds__(256) multi_reduce_kernel(const float* __restri
 }
 int launch_multi_reduce(const float* arena, float* grads, const m2t_red_desc* descs, int ndesc, hipStream_t st) {
   if (ndesc <= 0) return 0;
-  hipLaunchKernelGGL(multi_reduce_kernel, dim3(96, ndesc), dim3(256), 0, st, arena, grads, descs);
+  hipLaunchKernelGGL(multi_reduce_kernel, dim3(256, ndesc), dim3(256), 0, st, arena, grads, descs);
   M2T_LAUNCH_CHECK();
   return 0;
 }
