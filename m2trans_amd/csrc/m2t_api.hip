@@ -87,6 +87,8 @@ struct m2t_plan {
   bool have_seed = false, have_acts = false;
   bool use_side = true;
   bool debug_skip_side = false;    // timing experiments only: skip every parameter-gradient kernel (results are WRONG)      // halo gather + qkv dgrad GEMM + prep_bwd as one kernel (k_branch.hip)
+  bool use_persistent_conv = false;  // bf16 conv3x3 with LDS-resident weights: bit-identical, but measured SLOWER (53 vs 39 us:
+                                     // one 4-wave workgroup per CU cannot hide the LDS latency that 4 co-resident tiles do)
   bool use_gated_side = true;      // see the side-stream schedule in m2t_backward
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
@@ -346,7 +348,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     // x = feed_forward(xc) + x (:164); the last block also folds in `res + x` (:70)
     { M2TProfScope ps(M2T_PROF_CONV3_FWD, st);
       CK(launch_conv3x3_c64(dt, xc, packed_ptr(p, workspace, k + "wf"), params + p->poff.at(pre + "feed_forward.0.bias"), X,
-                            (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st)); }
+                            (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st, p->use_persistent_conv)); }
   }
   void* Y = WSP("X" + std::to_string(p->nb));
   const int r0 = (s == 4) ? 2 : s;
@@ -586,7 +588,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       CK(side_conv());
       conv_done = side_marker();
     }
-    { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st)); }
+    { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st, p->use_persistent_conv)); }
     for (int i = 3; i >= 0; --i) {
       const int C = BR_C[i], L = BR_L[i];
       const int h = H >> L, w = W >> L;
@@ -675,6 +677,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
 extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (!p || !key) return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: null");
   if (std::string(key) == "side_stream") { p->use_side = (value != 0); return 0; }
+  if (std::string(key) == "persistent_conv") { p->use_persistent_conv = (value != 0); return 0; }
   if (std::string(key) == "gated_side") { p->use_gated_side = (value != 0); return 0; }
   if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }

@@ -174,6 +174,37 @@ def test_bf16_forward_and_grads_close_to_fp32_oracle():
     assert not bad, (bad, table)
 
 
+def test_bf16_fast_kernels_match_plain_kernels():
+    """A/B inside bf16 mode, at a size where every specialised kernel is live (512 conv tiles, 1024 C=16
+    windows): weights-resident persistent conv3x3, whole-window-resident / wave-per-window attention backward and
+    the gated side-stream schedule against the plain kernels on one stream.  The persistent conv keeps the
+    accumulation order of the plain one, so the forward is bit-identical; the attention-backward variants round
+    P / dS at different points, so the gradients agree to bf16 noise (stated: rel-rms <= 2e-2 per tensor, or
+    <= 1e-3 of the whole gradient for the tiny-norm ones)."""
+    from m2trans_amd import _lib
+    scale, nb, B, H, W = 4, 2, 4, 128, 128
+    x = O.closed_form_image(B, 3, H, W).cuda()
+    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+    outs = []
+    for fast in (1, 0):
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(x)
+        for key in (b"persistent_conv", b"resident_attn_bwd", b"gated_side", b"side_stream"):
+            _lib.check(_lib.load().m2t_set_option(plan.handle, key, fast), "m2t_set_option")
+        sr = model(x)
+        torch.nn.L1Loss()(sr, hr).backward()
+        outs.append((sr.detach().clone(), {n: q.grad.detach().double().cpu() for n, q in model.named_parameters() if q.requires_grad}))
+    (sr_a, g_a), (sr_b, g_b) = outs
+    assert torch.equal(sr_a, sr_b)
+    total = float(torch.cat([v.reshape(-1) for v in g_b.values()]).norm())
+    bad = []
+    for n in g_b:
+        err, nrm = float((g_a[n] - g_b[n]).norm()), float(g_b[n].norm())
+        if not (err <= 2e-2 * nrm or err <= 1e-3 * total):
+            bad.append((n, err / (nrm + 1e-30), err / total))
+    assert not bad, bad
+
+
 def test_config1_x2_64_vs_reference_golden(golden_dir):
     """BASELINE.json configs[0]: x2 forward on one 64x64 LR patch, full 8-block model."""
     g = np.load(os.path.join(golden_dir, "config1_x2_64.npz"))
