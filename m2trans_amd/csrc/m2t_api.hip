@@ -89,6 +89,7 @@ struct m2t_plan {
   bool debug_skip_side = false;    // timing experiments only: skip every parameter-gradient kernel (results are WRONG)      // halo gather + qkv dgrad GEMM + prep_bwd as one kernel (k_branch.hip)
   bool use_persistent_conv = false;  // bf16 conv3x3 with LDS-resident weights: bit-identical, but measured SLOWER (53 vs 39 us:
                                      // one 4-wave workgroup per CU cannot hide the LDS latency that 4 co-resident tiles do)
+  bool tail_wgrad_main = true;     // tail weight gradients on the main stream (see m2t_backward)
   bool use_gated_side = true;      // see the side-stream schedule in m2t_backward
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
@@ -482,11 +483,14 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   const void* last_der = (s == 4) ? WSP("t2der") : WSP("t1der");
   void* g_last = (s == 4) ? WSP("g_t2pre") : WSP("g_t1pre");
   const bool skip = p->debug_skip_side;
+  // the tail's three weight-gradient kernels stream the high-resolution tensors at HBM speed, like the main-chain
+  // kernels they would overlap with: on the main stream they cost the same wall time and are not slowed 2-3x
+  hipStream_t tws = p->tail_wgrad_main ? st : sd;
   fork();
   if (!skip) CK(launch_head_im2col(dt, x, WSP("head_cols"), B, p->H0, p->W0, H, W, sd));
   if (!skip) {
     float* slabs = arena_alloc((size_t)1024 * 32 * 64);
-    { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, sd); CK(launch_final_conv_wgrad(dt, gpre, last_act, slabs, &ns, B, p->Hsp, p->Wsp, sd)); }
+    { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, tws); CK(launch_final_conv_wgrad(dt, gpre, last_act, slabs, &ns, B, p->Hsp, p->Wsp, tws)); }
     defer(slabs, p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0);
   }
   { M2TProfScope ps(M2T_PROF_FINAL_DGRAD, st); CK(launch_final_conv_dgrad(dt, gpre, params + p->poff.at(wl), last_der, g_last, B, p->Hsp, p->Wsp, st)); }
@@ -499,7 +503,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     if (!skip) {
     wa.G = WSP("g_t2pre"); wa.gmode = M2T_A_UNSHUF; wa.X = WSP("t1act"); wa.ldx = 64; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP * 4; wa.N = 256; wa.K = 64; wa.H = 2 * H; wa.Wd = 2 * W; wa.r = 2; wa.C = 64;
-    { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
+    { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, tws); CK(launch_wgrad_tn(dt, wa, &ns, tws)); }
     defer(slabs, p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64);
     defer(colp, p->poff.at("tail.3.bias"), ns, 256, 2, 64, 4, 1);   // bias gradient rode along in the wgrad kernel
     }
@@ -519,7 +523,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     wa.G = WSP("g_t1pre"); wa.gmode = M2T_A_UNSHUF; wa.X = Y; wa.ldx = M2T_LD_P64; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = N0; wa.K = 64; wa.H = H; wa.Wd = W; wa.r = r0; wa.C = 64;
     if (!skip) {
-    { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
+    { M2TProfScope ps(M2T_PROF_TAIL_WGRAD, tws); CK(launch_wgrad_tn(dt, wa, &ns, tws)); }
     defer(slabs, p->poff.at("tail.0.weight"), ns, (long long)N0 * 64, 2, 64, r0 * r0, 64);
     defer(colp, p->poff.at("tail.0.bias"), ns, N0, 2, 64, r0 * r0, 1);
     }
@@ -528,6 +532,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     ga.M = BP; ga.N = 64; ga.K = N0; ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_PLAIN, ga, st)); }
   }
+  if (p->tail_wgrad_main) fork();     // the reduction (side stream) follows the main-stream producers
   CK(flush());
   // ---- body, last block first.  gy = gradient of X[b+1] ----
   void* gy = WSP("gT");
@@ -678,6 +683,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (!p || !key) return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: null");
   if (std::string(key) == "side_stream") { p->use_side = (value != 0); return 0; }
   if (std::string(key) == "persistent_conv") { p->use_persistent_conv = (value != 0); return 0; }
+  if (std::string(key) == "tail_wgrad_main") { p->tail_wgrad_main = (value != 0); return 0; }
   if (std::string(key) == "gated_side") { p->use_gated_side = (value != 0); return 0; }
   if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
