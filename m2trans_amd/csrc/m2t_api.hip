@@ -90,6 +90,7 @@ struct m2t_plan {
   bool use_persistent_conv = false;  // bf16 conv3x3 with LDS-resident weights: bit-identical, but measured SLOWER (53 vs 39 us:
                                      // one 4-wave workgroup per CU cannot hide the LDS latency that 4 co-resident tiles do)
   bool tail_wgrad_main = true;     // tail weight gradients on the main stream (see m2t_backward)
+  int gate_branch = 2;             // 2: after the two C = 256 attentions; 1: after the C = 64 one too
   bool use_gated_side = true;      // see the side-stream schedule in m2t_backward
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
@@ -549,6 +550,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   // weight gradients then run under the C = 64 / C = 16 branches, the norm backward and the next block's conv
   // data gradient, which leave LDS free.  Each branch has its own gqkv / win / relw buffers, so the lag is harmless.
   const bool gated = p->use_gated_side && sd != st;
+  const int gate = p->gate_branch;          // branch index after whose attention launch the block's side work is released
   for (int b = p->nb - 1; b >= 0; --b) {
     const std::string k = "b" + std::to_string(b) + ".";
     const std::string pre = "body." + std::to_string(b) + ".";
@@ -617,15 +619,15 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         fork();
         CK(side_branch(i));
         branch_done[i] = side_marker();
-      } else if (i == 2) {
-        fork();                              // the gate: both C = 256 attention kernels are on their way
+      } else if (i == gate) {
+        fork();                              // the gate: the LDS-hungry attention kernels of this block are on their way
         CK(side_conv());
         conv_done = side_marker();
-        CK(side_branch(3));
-        branch_done[3] = side_marker();
-        CK(side_branch(2));
-        branch_done[2] = side_marker();
-      } else if (i < 2) {
+        for (int j = 3; j >= gate; --j) {
+          CK(side_branch(j));
+          branch_done[j] = side_marker();
+        }
+      } else if (i < gate) {
         fork();
         CK(side_branch(i));
         branch_done[i] = side_marker();
@@ -684,6 +686,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "side_stream") { p->use_side = (value != 0); return 0; }
   if (std::string(key) == "persistent_conv") { p->use_persistent_conv = (value != 0); return 0; }
   if (std::string(key) == "tail_wgrad_main") { p->tail_wgrad_main = (value != 0); return 0; }
+  if (std::string(key) == "gate_branch") { if (value < 0 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: 0..3"); p->gate_branch = (int)value; return 0; }
   if (std::string(key) == "gated_side") { p->use_gated_side = (value != 0); return 0; }
   if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
