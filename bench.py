@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--all-kernel-events", action="store_true", help="time every kernel category in the timed region (adds ~8%% overhead)")
     ap.add_argument("--null-stream", action="store_true", help="run on the legacy default stream instead of a torch stream")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=INT", help="m2t_set_option on the plan (experiments)")
     ap.add_argument("--gate-branch", type=int, default=None, help="side-stream gate position (experiment)")
     ap.add_argument("--tail-wgrad-side", action="store_true", help="tail weight gradients on the side stream (experiment)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the whole backward on one stream")
@@ -149,6 +150,10 @@ def main():
     if args.debug_skip_side:
         plan = model._plan_for(batches[0][0])
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"debug_skip_side", 1), "m2t_set_option")
+    for kv in args.option:
+        key, val = kv.split("=")
+        plan = model._plan_for(batches[0][0])
+        _lib.check(_lib.load().m2t_set_option(plan.handle, key.encode(), int(val)), "m2t_set_option")
     if args.gate_branch is not None:
         plan = model._plan_for(batches[0][0])
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"gate_branch", args.gate_branch), "m2t_set_option")

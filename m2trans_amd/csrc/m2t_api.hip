@@ -89,6 +89,7 @@ struct m2t_plan {
   bool debug_skip_side = false;    // timing experiments only: skip every parameter-gradient kernel (results are WRONG)      // halo gather + qkv dgrad GEMM + prep_bwd as one kernel (k_branch.hip)
   bool use_persistent_conv = false;  // bf16 conv3x3 with LDS-resident weights: bit-identical, but measured SLOWER (53 vs 39 us:
                                      // one 4-wave workgroup per CU cannot hide the LDS latency that 4 co-resident tiles do)
+  bool use_fused_tail_bwd = true;  // x4 bf16: k_tail_bwd.hip instead of four HR kernels
   bool tail_wgrad_main = true;     // tail weight gradients on the main stream (see m2t_backward)
   int gate_branch = 2;             // 2: after the two C = 256 attentions; 1: after the C = 64 one too
   bool use_gated_side = true;      // see the side-stream schedule in m2t_backward
@@ -489,6 +490,20 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   hipStream_t tws = p->tail_wgrad_main ? st : sd;
   fork();
   if (!skip) CK(launch_head_im2col(dt, x, WSP("head_cols"), B, p->H0, p->W0, H, W, sd));
+  const bool fused_tail = p->use_fused_tail_bwd && s == 4 && dt != M2T_F32;
+  if (fused_tail) {
+    // one pass over the high-resolution tensors (k_tail_bwd.hip): tail conv dgrad + wgrad, GELU', tail.3 dgrad + wgrad
+    const int nb = tail_bwd_fused_blocks(B, p->Hsp, p->Wsp);
+    float* swf = arena_alloc((size_t)nb * 32 * 64);
+    float* sw3 = arena_alloc((size_t)nb * 256 * 64);
+    float* sb3 = arena_alloc((size_t)nb * 256);
+    { M2TProfScope ps(M2T_PROF_FINAL_DGRAD, st);
+      CK(launch_tail_bwd_fused(gpre, params + p->poff.at(wl), WSP("t2act"), WSP("t2der"), WSP("t1act"), WSP("t1der"),
+                               packed_ptr(p, workspace, "t3T"), WSP("g_t1pre"), swf, sw3, sb3, &ns, B, p->Hsp, p->Wsp, st)); }
+    defer(swf, p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0);
+    defer(sw3, p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64);
+    defer(sb3, p->poff.at("tail.3.bias"), ns, 256, 2, 64, 4, 1);
+  } else {
   if (!skip) {
     float* slabs = arena_alloc((size_t)1024 * 32 * 64);
     { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, tws); CK(launch_final_conv_wgrad(dt, gpre, last_act, slabs, &ns, B, p->Hsp, p->Wsp, tws)); }
@@ -514,6 +529,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     ga.H = 2 * H; ga.Wd = 2 * W; ga.r = 2; ga.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_GELU_GRAD, ga, st)); }
   }
+  }
   void* Y = WSP("X" + std::to_string(p->nb));
   {
     const int N0 = 64 * r0 * r0;
@@ -533,7 +549,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     ga.M = BP; ga.N = 64; ga.K = N0; ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_PLAIN, ga, st)); }
   }
-  if (p->tail_wgrad_main) fork();     // the reduction (side stream) follows the main-stream producers
+  if (p->tail_wgrad_main || fused_tail) fork();     // the reduction (side stream) follows the main-stream producers
   CK(flush());
   // ---- body, last block first.  gy = gradient of X[b+1] ----
   void* gy = WSP("gT");
@@ -683,8 +699,10 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
 
 extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (!p || !key) return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: null");
+  p->red_uploaded = false;     // the deferred-reduction table depends on the schedule: rebuild it on the next backward
   if (std::string(key) == "side_stream") { p->use_side = (value != 0); return 0; }
   if (std::string(key) == "persistent_conv") { p->use_persistent_conv = (value != 0); return 0; }
+  if (std::string(key) == "fused_tail_bwd") { p->use_fused_tail_bwd = (value != 0); return 0; }
   if (std::string(key) == "tail_wgrad_main") { p->tail_wgrad_main = (value != 0); return 0; }
   if (std::string(key) == "gate_branch") { if (value < 0 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: 0..3"); p->gate_branch = (int)value; return 0; }
   if (std::string(key) == "gated_side") { p->use_gated_side = (value != 0); return 0; }

@@ -118,6 +118,15 @@ int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* 
 // one CFTM branch of the forward pass (prep + qkv projection + window attention + IWT/residual) per window;
 #define M2T_UNSUPPORTED (-1000)
 
+// ---- k_tail_bwd.hip ----------------------------------------------------------------------
+// x4 tail, bf16: tail conv data + weight gradient, GELU backward, tail.3 data + weight + bias gradient in one pass
+// over the stored activation / derivative tensors (g(t2) never reaches HBM).  Slabs: wf [n][32][64], w3 [n][256][64],
+// b3 [n][256]; n = *nslab_out <= tail_bwd_fused_blocks().
+int tail_bwd_fused_blocks(int B, int H, int W);
+int launch_tail_bwd_fused(const float* gout, const float* wf, const void* act, const void* der, const void* a1, const void* d1,
+                          const void* w3t, void* gt1, float* slab_wf, float* slab_w3, float* slab_b3, int* nslab_out, int B, int H,
+                          int W, hipStream_t st);
+
 // ---- k_attn.hip -------------------------------------------------------------------------
 // qkv [B][h][w][3C] (q | k | v), rel_h/rel_w fp32 [10][C/2];  out rows at ldo (+ optional residual rows at ldr)
 // post_levels = 1, 2: out/res are the FULL-RES xc (ld ldo, channel offset oc0) / xin (ld ldr) tensors and the

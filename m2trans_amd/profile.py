@@ -33,6 +33,16 @@ KERNEL_OF = {
     "final_conv_fwd": "final_conv_fwd_kernel", "final_conv_dgrad": "final_conv_dgrad_kernel",
     "final_conv_wgrad": "final_conv_wgrad_kernel",
 }
+KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these categories
+    "attn_fwd_c16": "window_attn_fwd_c16_kernel (wave per window)",
+    "attn_bwd_c16": "window_attn_bwd_c16_kernel (wave per window)",
+    "attn_bwd_c64": "window_attn_bwd_res_kernel<C=64,L=1> (window resident in LDS)",
+    "attn_bwd_c256": "window_attn_bwd_res_kernel<C=256,L=2> (window resident in LDS)",
+    "gemm_qkv": "gemm_nt_kernel / gemm_nt_wide_kernel (qkv projections)",
+    "gemm_qkv_dgrad": "gemm_nt_kernel / gemm_nt_wide_kernel (qkv data gradients)",
+    "tail_gemm": "tail_expand_kernel (fwd) + gemm_nt_kernel (data gradients)",
+    "final_conv_dgrad": "tail_bwd_fused_kernel (tail conv dgrad+wgrad, GELU', tail.3 dgrad+wgrad)",
+}
 HBM_PEAK_GBS = 8000.0
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
 ALL_MASK = (1 << len(CATS)) - 1
@@ -91,8 +101,14 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8)
         HR = r2 * B * P
     fin = 2.0 * HR * 64 * 27
     add("final_conv_fwd", fin, HR * (64 * es + 12), 1)
-    add("final_conv_dgrad", fin, HR * (2 * 64 * es + 12), 1)
-    add("final_conv_wgrad", fin, HR * (64 * es + 12), 1)
+    if scale == 4 and dtype == "bf16":
+        # fused tail backward (k_tail_bwd.hip): tail conv dgrad + wgrad, GELU', tail.3 dgrad + wgrad in one pass:
+        # reads gelu(t2), gelu'(t2) (HR), gelu(t1), gelu'(t1) (HR/4), g(sr); writes g(t1) (HR/4)
+        mid = HR // 4
+        w["final_conv_dgrad"] = (2 * fin + 2 * 2.0 * mid * 64 * 256, HR * (2 * 64 * es + 12) + mid * 3 * 64 * es, 1)
+    else:
+        add("final_conv_dgrad", fin, HR * (2 * 64 * es + 12), 1)
+        add("final_conv_wgrad", fin, HR * (64 * es + 12), 1)
     return w
 
 
@@ -121,7 +137,8 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
             ach, peak, unit = by_l / avg_s / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             ach, peak, unit = fl_l / avg_s / 1e12, MFMA_PEAK_TF[dtype], "TFLOP/s"
-        rows.append({"kernel": KERNEL_OF[name], "category": name, "bound": bound, "achieved": round(ach, 2),
+        kname = KERNEL_OF_BF16.get(name, KERNEL_OF[name]) if dtype == "bf16" else KERNEL_OF[name]
+        rows.append({"kernel": kname, "category": name, "bound": bound, "achieved": round(ach, 2),
                      "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic.get(name),
                      "avg_launch_us": round(avg_s * 1e6, 2), "launches": n, "total_ms": round(ms, 3),
                      "hbm_GBs": round(by_l / avg_s / 1e9, 1), "mfma_TFs": round(fl_l / avg_s / 1e12, 2)})

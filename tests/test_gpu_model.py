@@ -189,7 +189,7 @@ def test_bf16_fast_kernels_match_plain_kernels():
     for fast in (1, 0):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
-        for key in (b"persistent_conv", b"resident_attn_bwd", b"gated_side", b"side_stream"):
+        for key in (b"persistent_conv", b"resident_attn_bwd", b"gated_side", b"side_stream", b"fused_tail_bwd"):
             _lib.check(_lib.load().m2t_set_option(plan.handle, key, fast), "m2t_set_option")
         sr = model(x)
         torch.nn.L1Loss()(sr, hr).backward()
