@@ -535,9 +535,9 @@ int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs
 #define FC_LD 72
 
 // halo tile of the stored activation gelu(t) (reflect addressing), rows >= 324 zero
-template <typename T>
+template <typename T, int ROWS = FC_HPP>
 __device__ __forceinline__ void final_stage_act(T (*As)[FC_LD], const T* __restrict__ tb, int y0, int x0, int H, int W, int tid) {
-  constexpr int ITEMS = FC_HPP * 8 / 256;   // 11
+  constexpr int ITEMS = (ROWS * 8 + 255) / 256;   // 11
   Frag8<T> f[ITEMS];
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
@@ -554,7 +554,7 @@ __device__ __forceinline__ void final_stage_act(T (*As)[FC_LD], const T* __restr
   for (int it = 0; it < ITEMS; ++it) {
     const int idx = tid + it * 256;
     const int cv = idx & 7, p = idx >> 3;
-    store8(&As[p][cv * 8], f[it]);
+    if (p < ROWS) store8(&As[p][cv * 8], f[it]);
   }
 }
 
@@ -562,14 +562,14 @@ template <typename T>
 __global__ void __launch_bounds__(256) final_conv_fwd_kernel(const T* __restrict__ tpre, const float* __restrict__ w,
                                                              float* __restrict__ out, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T(*As)[FC_LD] = reinterpret_cast<T(*)[FC_LD]>(smem);                                   // [352][72]
-  constexpr size_t szAY = (sizeof(T) * FC_HPP * FC_LD > sizeof(float) * 336 * 33) ? sizeof(T) * FC_HPP * FC_LD : sizeof(float) * 336 * 33;
+  T(*As)[FC_LD] = reinterpret_cast<T(*)[FC_LD]>(smem);                                   // [336][72] (21 pixel tiles)
+  constexpr size_t szAY = (sizeof(T) * 336 * FC_LD > sizeof(float) * 336 * 33) ? sizeof(T) * 336 * FC_LD : sizeof(float) * 336 * 33;
   T(*Ws)[FC_LD] = reinterpret_cast<T(*)[FC_LD]>(smem + szAY);      // [32][72]
   float(*Ys)[33] = reinterpret_cast<float(*)[33]>(smem);   // [336][33] fp32, ALIASES As once the products are done
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const int x0 = blockIdx.x * FC_T, y0 = blockIdx.y * FC_T, b = blockIdx.z;
-  final_stage_act<T>(As, tpre + (long long)b * H * W * 64, y0, x0, H, W, tid);
+  final_stage_act<T, 336>(As, tpre + (long long)b * H * W * 64, y0, x0, H, W, tid);
   for (int i = tid; i < 32 * 64; i += 256) {
     const int n = i >> 6, ic = i & 63;              // n = tap*3 + oc
     float v = 0.f;
@@ -623,7 +623,8 @@ __global__ void __launch_bounds__(256) final_conv_fwd_kernel(const T* __restrict
   out[o + 2 * hw] = a2;
 }
 template <typename T> static size_t final_fwd_smem() {
-  const size_t a = sizeof(T) * FC_HPP * FC_LD, y = sizeof(float) * 336 * 33;   // Ys aliases As; Ws sits behind the larger of the two
+  const size_t a = sizeof(T) * 336 * FC_LD, y = sizeof(float) * 336 * 33;   // Ys aliases As; Ws sits behind the larger of the two
+  // (bf16: 48 384 + 4 608 B -> three workgroups per CU)
   return std::max(a, y) + sizeof(T) * 32 * FC_LD;
 }
 int launch_final_conv_fwd(int dt, const void* tpre, const float* w, float* out, int B, int H, int W, hipStream_t st) {

@@ -62,7 +62,8 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
   T(*Wt)[40] = reinterpret_cast<T(*)[40]>(smem + off);  off += sizeof(T) * 64 * 40;       // [ic][(tap,oc)]
   T(*A2)[TB_LD] = reinterpret_cast<T(*)[TB_LD]>(smem + off);  off += sizeof(T) * 256 * TB_LD;   // a2 tile [pixel][c]
   T(*Gz)[TB_LD] = reinterpret_cast<T(*)[TB_LD]>(smem + off);  off += sizeof(T) * 256 * TB_LD;   // g(t2) tile [pixel][c]
-  T(*A1)[TB_LD] = reinterpret_cast<T(*)[TB_LD]>(smem + off);                                   // a1 tile [mid pixel][k]
+  T(*A1)[TB_LD] = reinterpret_cast<T(*)[TB_LD]>(smem + off);  off += sizeof(T) * 64 * TB_LD;    // a1 tile [mid pixel][k]
+  T(*W3s)[264] = reinterpret_cast<T(*)[264]>(smem + off);                                      // W3^T [k][n'] (whole strip)
 
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
@@ -80,11 +81,9 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
     Wt[ic][n] = from_f<T>(v);
   }
   // tail.3 data gradient: wave (kt = w8 & 3, mh = w8 >> 2) owns output channels 16 kt .. of mid tiles 2 mh, 2 mh + 1;
-  // its W3^T rows stay in registers for the whole strip
+  // W3^T stays in LDS for the whole strip (in registers it pushed the prefetch registers into scratch: +37 % time)
   const int kt = w8 & 3, mh = w8 >> 2;
-  Frag8<T> w3f[8];
-#pragma unroll
-  for (int kc = 0; kc < 8; ++kc) w3f[kc] = load8(a.w3t + (long long)(16 * kt + lr) * 256 + 32 * kc + 8 * g);
+  for (int i = tid; i < 64 * 32; i += 512) store8(&W3s[i >> 5][(i & 31) * 8], load8(a.w3t + (long long)(i >> 5) * 256 + (i & 31) * 8));
   Frag8<T> ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones.set(e, 1.0f);
@@ -255,10 +254,11 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
 #pragma unroll
       for (int kc = 0; kc < 8; ++kc) {
         const int sub = kc >> 1, c0 = (kc & 1) * 32 + 8 * g;
+        const Frag8<T> w3k = load8(&W3s[16 * kt + lr][32 * kc + 8 * g]);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           const int m = 16 * (2 * mh + mt) + lr;
-          mma16(accD[mt], w3f[kc], load8(&Gz[hr_row(m, sub)][c0]));
+          mma16(accD[mt], w3k, load8(&Gz[hr_row(m, sub)][c0]));
         }
       }
 #pragma unroll
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
 }
 
 constexpr size_t tail_bwd_smem() {
-  return sizeof(float) * 3 * TB_HP + sizeof(bf16_t) * (256 * 40 + 64 * 40 + 2 * 256 * TB_LD + 64 * TB_LD);
+  return sizeof(float) * 3 * TB_HP + sizeof(bf16_t) * (256 * 40 + 64 * 40 + 2 * 256 * TB_LD + 64 * TB_LD + 64 * 264);
 }
 
 }  // namespace
