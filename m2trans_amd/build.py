@@ -18,7 +18,24 @@ LIB = os.path.join(HERE, "libm2t.so")
 SOURCES = ["k_pointwise.hip", "k_gemm.hip", "k_conv.hip", "k_attn.hip", "k_attn_res.hip", "k_attn_c16.hip", "k_tail_bwd.hip", "k_swin.hip", "m2t_api.hip", "m2t_swin.hip"]
 HEADERS = ["m2t_common.h", "m2t_kernels.h", "m2t_gemm_load.h", "m2t_haar.h", "m2t_window.h", os.path.join("..", "..", "include", "m2t.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-ffp-contract=off"]
+         "-Wno-unused-variable", "-ffp-contract=off", "-Rpass-analysis=kernel-resource-usage"]
+# kernels where register spills are known and accepted (fp32 parity-mode instantiations: speed is not their job)
+SPILL_OK = ("If", "IfL", "float")
+
+
+def _spill_report(src: str, remarks: str):
+    """Scan -Rpass-analysis=kernel-resource-usage output: a spilled prefetch register turns an asynchronous
+    global load into a synchronous one (the fused tail backward lost 37 % to a 4-register spill)."""
+    import re
+    name, out = None, []
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name and int(m.group(1)) > 0:
+            out.append((name, int(m.group(1))))
+    return out
 
 
 def _hipcc() -> str:
@@ -54,8 +71,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
-        if verbose and r.stderr.strip():
-            print(r.stderr)
+        import re as _re
+        other = "\n".join(l for l in r.stderr.splitlines()
+                          if "kernel-resource-usage" not in l and not _re.match(r"^\s*(\d+\s*)?\|", l) and l.strip())
+        if verbose and other.strip():
+            print(other)
+        for name, nbytes in _spill_report(src, r.stderr):
+            print(f"note: {os.path.basename(src)}: kernel {name[:90]} uses {nbytes} B/lane of scratch", flush=True)
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
