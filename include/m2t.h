@@ -51,7 +51,18 @@ void m2t_plan_destroy(m2t_plan* p);
  * "ws:<tensor>" (byte offset of a workspace tensor, e.g. "ws:b0.qkv3"), "wsn:<tensor>" (elements).
  * Returns -1 for an unknown key. */
 long long m2t_plan_query(const m2t_plan* p, const char* key);
-/* options: "side_stream" 1/0 -- run parameter-gradient kernels of m2t_backward on a second stream (default 1). */
+/* Scheduling / kernel-selection options (results are the same up to bf16 rounding; every pair is A/B-tested in
+ * tests/test_gpu_model.py).  Defaults in brackets.
+ *   "side_stream"       [1] parameter-gradient kernels of m2t_backward on a plan-owned second stream
+ *   "gated_side"        [1] release a block's side-stream work only after its LDS-hungry attention launches
+ *   "gate_branch"       [2] branch index (3..0) after whose attention launch the gate opens
+ *   "tail_wgrad_main"   [1] tail weight gradients on the caller's stream (they are HBM-bound like their neighbours)
+ *   "fused_tail_bwd"    [1] bf16 x4: one fused kernel for the high-resolution half of the tail backward
+ *   "resident_attn_bwd" [1] bf16: whole-window-resident / wave-per-window attention backward kernels
+ *   "persistent_conv"   [0] bf16: conv3x3 with LDS-resident weights (bit-identical, measured slower)
+ *   "side_cus"          [0] CU mask size of the side stream (0 = all CUs; masking measured slower); set before the
+ *                           first m2t_backward, and only effective when the caller's stream is not the NULL stream
+ *   "debug_skip_side"   [0] timing experiments only: skips every parameter-gradient kernel (results are WRONG) */
 int m2t_set_option(m2t_plan* p, const char* key, long long value);
 /* one-time initialisation of the workspace (uploads the weight-packing table). */
 int m2t_plan_init_workspace(m2t_plan* p, void* workspace, void* stream);
