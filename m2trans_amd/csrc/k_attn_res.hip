@@ -408,6 +408,178 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Resident FORWARD (bf16, C = 64 / 256): K^ and V of the whole window are loaded once (one exposed latency instead
+// of 2 x C/64 chunk stages), q comes straight from HBM in operand layout, S^T / P^T never leave the registers
+// (the accumulator layout of S^T is the B-operand layout of O^T = V^T P^T), and the branch epilogue
+// xc = IWT^L(O) + xin is applied on the accumulators exactly as in window_attn_fwd_kernel.
+// ---------------------------------------------------------------------------------------
+template <int C, int L>
+__global__ void __launch_bounds__(256) window_attn_fwd_res_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
+                                                                  const float* __restrict__ rel_w, bf16_t* __restrict__ out, int ldo,
+                                                                  int oc0, const bf16_t* __restrict__ res, int ldr, int h, int w) {
+  using T = bf16_t;
+  static_assert(L == 0 || C == (16 << (2 * L)), "fused IWT needs C = 16 * 4^L");
+  constexpr int LD = C + 8, VEC = C / 8, NT = C / 16, NKC = C / 32, ZR = 100;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T(*Kh)[LD] = reinterpret_cast<T(*)[LD]>(smem);
+  T(*Vs)[LD] = reinterpret_cast<T(*)[LD]>(smem + sizeof(T) * 101 * LD);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const WinGeom gm = make_geom(h, w);
+  const int q = 16 * wv + lr;
+  const long long qpix = gm.query_pixel(q);
+  {
+    constexpr int KIT = (WA_NK * VEC + 255) / 256;
+    Frag8<T> kf[KIT], vf[KIT];
+    f32x4 r0[KIT], r1[KIT];
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int idx = tid + it * 256;
+      const int cv = idx % VEC, key = idx / VEC;
+      kf[it] = frag_zero<T>();
+      vf[it] = frag_zero<T>();
+      r0[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      r1[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (key < WA_NK) {
+        long long pix;
+        if (gm.key_pixel(key, pix)) {
+          kf[it] = load8(qkv + pix * (3 * C) + C + cv * 8);
+          vf[it] = load8(qkv + pix * (3 * C) + 2 * C + cv * 8);
+        }
+        const int kr = key / 10, kc = key - kr * 10;
+        const int cc = cv * 8;
+        const float* rp = (cc < C / 2) ? (rel_h + kr * (C / 2) + cc) : (rel_w + kc * (C / 2) + (cc - C / 2));
+        r0[it] = *reinterpret_cast<const f32x4*>(rp);
+        r1[it] = *reinterpret_cast<const f32x4*>(rp + 4);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int idx = tid + it * 256;
+      const int cv = idx % VEC, key = idx / VEC;
+      if (key < WA_NK) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = kf[it].get(e) + r0[it][e]; v[4 + e] = kf[it].get(4 + e) + r1[it][e]; }
+        store8f(&Kh[key][cv * 8], v);
+        store8(&Vs[key][cv * 8], vf[it]);
+      }
+    }
+    if (tid < VEC) {
+      store8(&Kh[ZR][tid * 8], frag_zero<T>());
+      store8(&Vs[ZR][tid * 8], frag_zero<T>());
+    }
+  }
+  Frag8<T> qreg[NKC];
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) qreg[kc] = load8(qkv + qpix * (3 * C) + kc * 32 + 8 * g);
+  __syncthreads();
+  // ---- S^T = K^ Q^T ----
+  f32x4 s[WA_KT];
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) mma16(s[t], load8(&Kh[min(16 * t + lr, ZR)][kc * 32 + 8 * g]), qreg[kc]);
+  // ---- softmax over the 100 real keys; lane (q, g) holds keys 16 t + 4 g + r ----
+  const float scale = rsqrtf((float)C);
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * t + 4 * g + r;
+      s[t][r] = (key < WA_NK) ? s[t][r] * scale : -3.0e38f;
+      mx = fmaxf(mx, s[t][r]);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 16));
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = 16 * t + 4 * g + r;
+      const float e = (key < WA_NK) ? __expf(s[t][r] - mx) : 0.f;
+      s[t][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 16);
+  sum += __shfl_xor(sum, 32);
+  const float inv = 1.0f / sum;
+  // P^T as the B operand: k-chunk c4 covers key tiles 2c4, 2c4+1; slot (g, j) <-> key 16(2c4 + (j>>2)) + 4g + (j&3)
+  Frag8<T> pf[4];
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int t = 2 * c4 + (j >> 2);
+      pf[c4].set(j, (t < WA_KT) ? s[t < WA_KT ? t : 0][j & 3] * inv : 0.f);
+    }
+  // ---- O^T = V^T P^T: V^T fragments by transposing LDS reads in the same key order (rows >= 100 alias the zero row) ----
+  f32x4 o[NT];
+#pragma unroll
+  for (int mt = 0; mt < NT; ++mt) o[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) mma16(o[mt], tr8(&Vs[0][0], LD, 32 * c4 + 4 * g, 32 * c4 + 16 + 4 * g, 16 * mt, lane, ZR), pf[c4]);
+  if constexpr (L == 0) {
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+      float v[4] = {o[mt][0], o[mt][1], o[mt][2], o[mt][3]};
+      const int cc = 16 * mt + 4 * g;
+      if (res) {
+        float p[4];
+        load4(res + qpix * ldr + cc, p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p[e];
+      }
+      store4(out + qpix * ldo + oc0 + cc, v);
+    }
+  } else {
+    // channel = band * 16 + base channel (band-major nesting of repeated DWTs): tile mt = band mt, row = base channel
+    constexpr int S = Haar<L>::S, NB = Haar<L>::N;
+    static_assert(NB == NT, "one 16-channel tile per band");
+    float vv[4][S][S];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float bands[NB];
+#pragma unroll
+      for (int mt = 0; mt < NT; ++mt) bands[mt] = o[mt][r];
+      Haar<L>::inv(bands, vv[r]);
+    }
+    const int H = h * S, W = w * S;
+    const int by = 8 * gm.wy + (q >> 3), bx = 8 * gm.wx + (q & 7);
+#pragma unroll
+    for (int y = 0; y < S; ++y)
+#pragma unroll
+      for (int x = 0; x < S; ++x) {
+        const long long pix = ((long long)gm.b * H + S * by + y) * W + S * bx + x;
+        float p[4];
+        load4(res + pix * ldr + 4 * g, p);
+        float v[4] = {vv[0][y][x] + p[0], vv[1][y][x] + p[1], vv[2][y][x] + p[2], vv[3][y][x] + p[3]};
+        store4(out + pix * ldo + oc0 + 4 * g, v);
+      }
+  }
+}
+
+template <int C, int L>
+int go_fwd_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, bf16_t* out, int ldo, int oc0, const bf16_t* res, int ldr,
+               int nwin, int h, int w, hipStream_t st) {
+  const size_t sh = sizeof(bf16_t) * 2 * 101 * (C + 8);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)window_attn_fwd_res_kernel<C, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((window_attn_fwd_res_kernel<C, L>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, out, ldo, oc0, res, ldr, h, w);
+  return 0;
+}
+
 template <int C, int L, int NW>
 int go_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, const bf16_t* gout, int ldg, int gc0, bf16_t* gqkv,
            bf16_t* win, float* relw, int nwin, int h, int w, hipStream_t st) {
@@ -438,6 +610,23 @@ int launch_window_attn_bwd_resident(const void* qkv_, const float* rel_h, const 
   else if (C == 256 && dwt_levels == 0) rc = go_res<256, 0, 8>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st);
   else if (C == 64 && dwt_levels == 1) rc = go_res<64, 1, 4>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st);
   else if (C == 64 && dwt_levels == 0) rc = go_res<64, 0, 4>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st);
+  if (rc != 0) return rc;
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// forward: bf16, (C, post_levels) in {(64,0), (64,1), (256,0), (256,2)}; M2T_UNSUPPORTED otherwise
+int launch_window_attn_fwd_resident(const void* qkv_, const float* rel_h, const float* rel_w, void* out_, int ldo, int oc0,
+                                    const void* res_, int ldr, int B, int h, int w, int C, int post_levels, hipStream_t st) {
+  const bf16_t* qkv = (const bf16_t*)qkv_;
+  bf16_t* out = (bf16_t*)out_;
+  const bf16_t* res = (const bf16_t*)res_;
+  const int nwin = B * (h / 8) * (w / 8);
+  int rc = M2T_UNSUPPORTED;
+  if (C == 256 && post_levels == 2) rc = go_fwd_res<256, 2>(qkv, rel_h, rel_w, out, ldo, oc0, res, ldr, nwin, h, w, st);
+  else if (C == 256 && post_levels == 0) rc = go_fwd_res<256, 0>(qkv, rel_h, rel_w, out, ldo, oc0, res, ldr, nwin, h, w, st);
+  else if (C == 64 && post_levels == 1) rc = go_fwd_res<64, 1>(qkv, rel_h, rel_w, out, ldo, oc0, res, ldr, nwin, h, w, st);
+  else if (C == 64 && post_levels == 0) rc = go_fwd_res<64, 0>(qkv, rel_h, rel_w, out, ldo, oc0, res, ldr, nwin, h, w, st);
   if (rc != 0) return rc;
   M2T_LAUNCH_CHECK();
   return 0;
