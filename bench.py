@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--all-kernel-events", action="store_true", help="time every kernel category in the timed region (adds ~8%% overhead)")
     ap.add_argument("--null-stream", action="store_true", help="run on the legacy default stream instead of a torch stream")
+    ap.add_argument("--no-overlap-comm", action="store_true", help="one all-reduce after the backward instead of the bucketed overlap")
+    ap.add_argument("--force-comm-path", action="store_true", help="issue the gradient collectives even with one rank (needs an initialised process group)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=INT", help="m2t_set_option on the plan (experiments)")
     ap.add_argument("--gate-branch", type=int, default=None, help="side-stream gate position (experiment)")
     ap.add_argument("--tail-wgrad-side", action="store_true", help="tail weight gradients on the side stream (experiment)")
@@ -116,7 +118,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
-    if world > 1:
+    if world > 1 or (args.force_comm_path and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
@@ -145,7 +147,8 @@ def main():
         sem.load_image_encoder(state)
         captions = [f"synthetic ultrasound caption {i}" for i in range(B)]
     ts = TrainStep(model, lr=1e-4, lambda_l1=1.0, process_group=pg, world_size=world,
-                   semantic_loss=sem, lambda_clip=0.01 if sem is not None else 0.0)
+                   semantic_loss=sem, lambda_clip=0.01 if sem is not None else 0.0,
+                   overlap_comm=not args.no_overlap_comm, force_comm_path=args.force_comm_path)
     batches = [synthetic_batch(B, args.lr_size, args.scale, rank, s, device) for s in range(2)]
     if args.debug_skip_side:
         plan = model._plan_for(batches[0][0])
@@ -229,7 +232,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -64,6 +64,12 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           first m2t_backward, and only effective when the caller's stream is not the NULL stream
  *   "debug_skip_side"   [0] timing experiments only: skips every parameter-gradient kernel (results are WRONG) */
 int m2t_set_option(m2t_plan* p, const char* key, long long value);
+/* Gradient buckets for communication overlap (replaces the reduce-to-GPU-0 of nn.DataParallel, train.py:73):
+ * m2t_backward completes the flat gradient buffer in "grad_buckets" contiguous ranges, in this order: tail, block
+ * pairs from the last to the first, head.  m2t_plan_query("grad_bucket_lo:<i>" / "grad_bucket_hi:<i>") give bucket
+ * i's float range; after m2t_backward has been ENQUEUED, m2t_stream_wait_bucket makes `stream` wait until bucket i
+ * is final, so an all-reduce of that range can run under the rest of the backward pass. */
+int m2t_stream_wait_bucket(m2t_plan* p, int bucket, void* stream);
 /* one-time initialisation of the workspace (uploads the weight-packing table). */
 int m2t_plan_init_workspace(m2t_plan* p, void* workspace, void* stream);
 

@@ -64,6 +64,11 @@ class Plan:
             raise KeyError(key)
         return int(v)
 
+    def grad_buckets(self):
+        """[(lo, hi)] float ranges of the flat gradient buffer in the order m2t_backward completes them."""
+        n = self.query("grad_buckets")
+        return [(self.query(f"grad_bucket_lo:{i}"), self.query(f"grad_bucket_hi:{i}")) for i in range(n)]
+
     def ws_tensor(self, name: str, shape=None, dtype=None) -> torch.Tensor:
         """View of a named workspace tensor (tests / introspection)."""
         off, n = self.query("ws:" + name), self.query("wsn:" + name)

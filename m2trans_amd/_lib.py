@@ -23,6 +23,7 @@ SIGNATURES = {
     "m2t_plan_destroy": (None, [_vp]),
     "m2t_plan_query": (_ll, [_vp, C.c_char_p]),
     "m2t_set_option": (_i, [_vp, C.c_char_p, _ll]),
+    "m2t_stream_wait_bucket": (_i, [_vp, _i, _vp]),
     "m2t_plan_init_workspace": (_i, [_vp, _vp, _vp]),
     "m2t_forward": (_i, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
     "m2t_l1_loss": (_i, [_vp, _vp, _f, _d, _f, _vp, _vp, _vp]),

@@ -100,6 +100,10 @@ struct m2t_plan {
   bool red_uploaded = false;
   size_t arena_floats = 0;
   hipStream_t side = nullptr;
+  // gradient buckets: [lo, hi) float ranges of the flat gradient buffer in the order m2t_backward completes them
+  // (tail, block pairs from the last to the first, head); one event each, recorded behind the bucket's reduction
+  std::vector<std::pair<long long, long long>> buckets;
+  std::vector<hipEvent_t> bucket_events;
   int side_cus = 0;                // CUs the side stream may use (0 = all; masking measured slower: 9.1-20 ms vs 8.7 ms)
   std::vector<hipEvent_t> events;
   int ensure_side(hipStream_t caller) {
@@ -120,10 +124,14 @@ struct m2t_plan {
     events.resize(192);
     for (auto& e : events)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
+    bucket_events.resize(buckets.size());
+    for (auto& e : bucket_events)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
     return 0;
   }
   ~m2t_plan() {
     for (auto e : events) if (e) (void)hipEventDestroy(e);
+    for (auto e : bucket_events) if (e) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
   }
 
@@ -267,6 +275,27 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("col_part", (size_t)256 * 768, 4);
   p->ws_bytes = (p->ws_bytes + 255) & ~(size_t)255;
   *out = p;
+  {
+    // gradient buckets in completion order (see m2t_backward): the tail, then the blocks in the groups the
+    // deferred reductions are flushed in (after every even block index, walking from the last block to the first),
+    // then whatever precedes the lowest flushed block (the head).  state_dict order makes each a contiguous range.
+    auto first_of = [&](const std::string& prefix) {
+      long long lo = p->nparams;
+      for (const auto& n : p->pnames) if (n.rfind(prefix, 0) == 0) lo = std::min(lo, p->poff.at(n));
+      return lo;
+    };
+    long long hi = p->nparams;
+    const long long tail_lo = first_of("tail.");
+    p->buckets.push_back({tail_lo, hi});
+    hi = tail_lo;
+    for (int b = n_blocks - 1; b >= 0; --b)
+      if ((b & 1) == 0) {
+        const long long lo = first_of("body." + std::to_string(b) + ".");
+        p->buckets.push_back({lo, hi});
+        hi = lo;
+      }
+    p->buckets.push_back({0, hi});
+  }
   return 0;
 }
 extern "C" void m2t_plan_destroy(m2t_plan* p) { delete p; }
@@ -279,6 +308,9 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
   if (k == "num_param_tensors") return (long long)p->pnames.size();
   if (k == "padded_h") return p->H;
   if (k == "padded_w") return p->W;
+  if (k == "grad_buckets") return (long long)p->buckets.size();
+  if (k.rfind("grad_bucket_lo:", 0) == 0) { const size_t i = (size_t)atoll(k.c_str() + 15); return i < p->buckets.size() ? p->buckets[i].first : -1; }
+  if (k.rfind("grad_bucket_hi:", 0) == 0) { const size_t i = (size_t)atoll(k.c_str() + 15); return i < p->buckets.size() ? p->buckets[i].second : -1; }
   if (k.rfind("param:", 0) == 0) { auto it = p->poff.find(k.substr(6)); return it == p->poff.end() ? -1 : it->second; }
   if (k.rfind("numel:", 0) == 0) { auto it = p->pnum.find(k.substr(6)); return it == p->pnum.end() ? -1 : it->second; }
   if (k.rfind("ws:", 0) == 0) { auto it = p->ws.find(k.substr(3)); return it == p->ws.end() ? -1 : (long long)it->second.off; }
@@ -466,6 +498,11 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     d.src_off = (long long)(slab - arena); d.dst_off = dst_off; d.n = n; d.ns = ns; d.perm = perm; d.p0 = p0; d.p1 = p1; d.p2 = p2; d.pad_ = 0;
     descs.push_back(d);
   };
+  size_t bucket_i = 0;
+  auto mark_bucket = [&]() {         // the gradient range of bucket_i is final on the reduction stream from here on
+    if (bucket_i < p->bucket_events.size() && p->red_uploaded) (void)hipEventRecord(p->bucket_events[bucket_i], sd);
+    ++bucket_i;
+  };
   auto flush = [&]() -> int {        // one launch reduces everything deferred since the last flush
     if (overflow) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: slab arena too small");
     if (descs.size() > 512) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: too many deferred reductions");
@@ -551,6 +588,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   }
   if (p->tail_wgrad_main || fused_tail) fork();     // the reduction (side stream) follows the main-stream producers
   CK(flush());
+  mark_bucket();
   // ---- body, last block first.  gy = gradient of X[b+1] ----
   void* gy = WSP("gT");
   void* gnext[2] = {WSP("gA"), WSP("gB")};
@@ -662,7 +700,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     CK(launch_instnorm_bwd(dt, gn, X, mean, rstd, gy, gx, (float*)WSP("norm_part"), (float*)WSP("norm_s"), B, (int)p->P, st));
     conv_done_prev = conv_done;
     gy = gx;
-    if ((b & 1) == 0) CK(flush());
+    if ((b & 1) == 0) { CK(flush()); mark_bucket(); }
   }
   // head: g(res) = g(X0) from the chain + g(Y) from `res + x`
   CK(launch_add(dt, gy, WSP("gT"), WSP("gxc"), BP * 64, st));
@@ -679,6 +717,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     defer(slabs, p->poff.at("head.weight"), ns, 64 * 32, 5, 32, 27, 0);
     defer(colp, p->poff.at("head.bias"), ns, 64, 0, 0, 0, 0);
   }
+  const bool first_backward = !p->red_uploaded;
   if (!p->red_uploaded) {
     // first backward of this plan: publish the (step-invariant) descriptor table, then reduce everything
     if (overflow) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: slab arena too small");
@@ -692,8 +731,20 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     return m2t_set_error(M2T_ERR_STATE, "m2t_backward: reduction table changed between steps");
   }
   CK(flush());
+  mark_bucket();
+  if (first_backward)                // nothing was reduced before this point: every bucket completes here
+    for (auto e : p->bucket_events) (void)hipEventRecord(e, sd);
+  if (bucket_i != p->buckets.size()) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: gradient bucket table out of step");
   main_wait(side_marker());          // join: every gradient is complete in main-stream order
   p->have_seed = false;
+  return 0;
+}
+
+extern "C" int m2t_stream_wait_bucket(m2t_plan* p, int bucket, void* stream) {
+  if (!p || bucket < 0 || (size_t)bucket >= p->buckets.size()) return m2t_set_error(M2T_ERR_ARG, "m2t_stream_wait_bucket: bad bucket");
+  if (p->bucket_events.size() != p->buckets.size()) return m2t_set_error(M2T_ERR_STATE, "m2t_stream_wait_bucket: call m2t_backward first");
+  hipError_t e = hipStreamWaitEvent((hipStream_t)stream, p->bucket_events[bucket], 0);
+  if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
   return 0;
 }
 

@@ -55,7 +55,7 @@ class GradBucket:
     comm_dtype=torch.bfloat16 halves the bytes on the wire (7.3 MB); the sum is then carried out
     in bf16 by the collective, so fp32 is the default and the parity path."""
 
-    def __init__(self, flat: torch.Tensor, process_group=None, comm_dtype: torch.dtype = torch.float32):
+    def __init__(self, flat: torch.Tensor, process_group=None, comm_dtype: torch.dtype = torch.float32, force: bool = False):
         if flat.dim() != 1 or not flat.is_contiguous():
             raise ValueError("GradBucket needs a contiguous 1-D buffer")
         self.flat = flat
@@ -63,9 +63,11 @@ class GradBucket:
         self.comm_dtype = comm_dtype
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self._wire = None if comm_dtype == flat.dtype else torch.empty_like(flat, dtype=comm_dtype)
+        # force: issue the collectives even in a one-rank group (exercises the RCCL / stream path on a single GPU)
+        self.force = bool(force) and dist.is_available() and dist.is_initialized()
 
     def all_reduce(self, async_op: bool = False):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return None
         if self._wire is None:
             return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
@@ -73,6 +75,13 @@ class GradBucket:
         dist.all_reduce(self._wire, op=dist.ReduceOp.SUM, group=self.pg)
         self.flat.copy_(self._wire)
         return None
+
+    def all_reduce_range(self, lo: int, hi: int):
+        """SUM-all-reduce flat[lo:hi] in place on the CURRENT stream (fp32 wire; used by the overlapped exchange:
+        every rank issues the same ranges in the same order)."""
+        if (self.world == 1 and not self.force) or hi <= lo:
+            return None
+        return dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
 
 
 def broadcast_params(flat_params: torch.Tensor, src: int = 0, process_group=None):

@@ -5,8 +5,10 @@
     optimizer.zero_grad(); sr = model(lr); loss = L1Loss()(sr, hr) * lambda_l1 (+ const clip term);
     loss.backward(); optimizer.step()
 
-as five C-ABI calls on one stream (forward, loss+seed, backward, fused Adam; plus ONE RCCL
-all-reduce of the flat gradient bucket when world_size > 1), with no host synchronisation:
+as five C-ABI calls on one stream (forward, loss+seed, backward, fused Adam; plus the RCCL
+all-reduce of the flat gradient buffer when world_size > 1 -- in two contiguous pieces, the first of
+which (tail + 3/4 of the body) starts as soon as m2t_backward has finished it, on a communication
+stream that runs under the rest of the backward pass), with no host synchronisation:
 the loss stays on the device (the reference's three ``float(loss)`` syncs per step,
 train.py:212-214, are left to the caller's logging cadence).
 
@@ -35,7 +37,8 @@ def cosine_lr(epoch: int, lr0: float = 1e-4, eta_min: float = 1e-6, t_max: float
 class TrainStep:
     def __init__(self, model: M2Trans, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  lambda_l1: float = 1.0, process_group=None, world_size: Optional[int] = None,
-                 grad_bucket_dtype: torch.dtype = torch.float32, semantic_loss=None, lambda_clip: float = 0.0):
+                 grad_bucket_dtype: torch.dtype = torch.float32, semantic_loss=None, lambda_clip: float = 0.0,
+                 overlap_comm: bool = True, force_comm_path: bool = False):
         self.model = model
         self.lr = float(lr)
         self.betas = (float(betas[0]), float(betas[1]))
@@ -59,7 +62,12 @@ class TrainStep:
         self.exp_avg_sq = torch.zeros_like(flat)
         self.l1_loss = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.loss = self.l1_loss
-        self.bucket = GradBucket(self.grads, process_group, grad_bucket_dtype) if self.world_size > 1 else None
+        # force_comm_path: build the exchange machinery even for one rank (tests exercise the stream / event logic)
+        self.bucket = GradBucket(self.grads, process_group, grad_bucket_dtype, force=force_comm_path) if (self.world_size > 1 or force_comm_path) else None
+        # overlapped exchange: fp32 wire only (the bf16 wire format needs a staging copy of the whole buffer)
+        self.overlap_comm = bool(overlap_comm) and self.bucket is not None and grad_bucket_dtype == torch.float32
+        self.comm_stream = torch.cuda.Stream(device=flat.device) if self.overlap_comm else None
+        self._last_plan = None
 
     def set_lr(self, lr: float):
         self.lr = float(lr)
@@ -80,6 +88,7 @@ class TrainStep:
         use_clip = self.semantic_loss is not None and self.lambda_clip > 0 and captions is not None
         sr = torch.empty_like(hr_img) if use_clip else None
         plan.gen += 1
+        self._last_plan = plan
         with torch.cuda.device(lr_img.device):
             st = _lib.stream_ptr()
             ws = _lib.ptr(plan.workspace)
@@ -98,8 +107,30 @@ class TrainStep:
         return self.loss
 
     def all_reduce_grads(self):
-        if self.bucket is not None:
+        """SUM the gradients over the ranks.  Overlapped mode: m2t_backward (already enqueued) completes the flat
+        buffer in contiguous buckets (tail, block pairs from last to first, head); each bucket's all-reduce is
+        enqueued on the communication stream behind that bucket's event, so it runs under the remaining backward
+        kernels; the compute stream then waits for the communication stream (before Adam)."""
+        if self.bucket is None:
+            return
+        if not self.overlap_comm or self._last_plan is None:
             self.bucket.all_reduce()
+            return
+        lib = _lib.load()
+        plan = self._last_plan
+        main = torch.cuda.current_stream(self.grads.device)
+        buckets = plan.grad_buckets()
+        # two collectives: everything that is final once the third-last block pair has been reduced (the tail and
+        # 3/4 of the body: its exchange runs under the last quarter of the backward pass), then the rest.  More,
+        # smaller collectives cost more in launch latency than they hide (measured with one rank: +25 us each).
+        cut = max(0, len(buckets) - 3)
+        groups = [(cut, buckets[cut][0], buckets[0][1]), (len(buckets) - 1, 0, buckets[cut][0])] if cut > 0 else \
+                 [(len(buckets) - 1, 0, buckets[0][1])]
+        with torch.cuda.device(self.grads.device), torch.cuda.stream(self.comm_stream):
+            for last, lo, hi in groups:
+                _lib.check(lib.m2t_stream_wait_bucket(plan.handle, last, self.comm_stream.cuda_stream), "m2t_stream_wait_bucket")
+                self.bucket.all_reduce_range(lo, hi)
+        main.wait_stream(self.comm_stream)
 
     def optimizer_step(self):
         self.step_count += 1

@@ -205,6 +205,27 @@ def test_bf16_fast_kernels_match_plain_kernels():
     assert not bad, bad
 
 
+def test_overlapped_gradient_exchange_path_single_rank():
+    """The bucketed exchange (communication stream waiting on the per-bucket events of m2t_backward, then the compute
+    stream waiting on the communication stream before Adam) with ONE rank: the collectives are identities, so two
+    steps must give bit-identical parameters to the plain path, and the bucket events must order the streams
+    correctly (a missing wait would let Adam read unfinished gradients)."""
+    from m2trans_amd.train_step import TrainStep
+    scale, nb, B, H, W = 4, 2, 2, 64, 64
+    x = [O.closed_form_image(B, 3, H, W, phase=0.1 * i).cuda() for i in range(2)]
+    hr = [O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7 + 0.1 * i).cuda() for i in range(2)]
+    finals = []
+    for force in (False, True):
+        model, _ = build_model(scale, nb, "bf16")
+        ts = TrainStep(model, lr=1e-3, world_size=1, force_comm_path=force)
+        assert ts.overlap_comm == force
+        for i in range(2):
+            ts.step(x[i], hr[i])
+        torch.cuda.synchronize()
+        finals.append(model.flat_params.detach().clone())
+    assert torch.equal(finals[0], finals[1])
+
+
 def test_config1_x2_64_vs_reference_golden(golden_dir):
     """BASELINE.json configs[0]: x2 forward on one 64x64 LR patch, full 8-block model."""
     g = np.load(os.path.join(golden_dir, "config1_x2_64.npz"))

@@ -139,6 +139,33 @@ def test_product_package_never_imports_the_oracle():
             assert "oracle" not in src.replace("# oracle", ""), fn
 
 
+def test_gradient_buckets_tile_the_flat_buffer():
+    """The ranges m2t_backward completes one after the other (tail, block pairs from last to first, head) must be
+    contiguous, disjoint and cover the whole flat gradient buffer, in that order, for every configuration."""
+    from m2trans_amd.M2Trans_network import create_model, Plan
+    from m2trans_amd import _lib
+    for scale in (2, 3, 4):
+        for nb in (1, 2, 3, 8):
+            m = create_model(_args(scale, nb))
+            plan = Plan.__new__(Plan)
+            h = C.c_void_p()
+            _lib.check(_lib.load().m2t_plan_create(C.byref(h), 2, 32, 32, scale, nb, _lib.F32), "m2t_plan_create")
+            plan.handle = h
+            try:
+                buckets = plan.grad_buckets()
+                n = plan.query("num_params")
+                assert buckets[0][1] == n and buckets[-1][0] == 0
+                for (lo, hi), (lo2, hi2) in zip(buckets[:-1], buckets[1:]):
+                    assert lo < hi and hi2 == lo                      # walks downwards without gaps
+                assert buckets[0][0] == plan.query("param:tail.0.weight")
+                first_body0 = min(o for nme, (o, k) in m.param_offsets().items() if nme.startswith("body.0."))
+                assert buckets[-1][1] == first_body0
+                assert sum(hi - lo for lo, hi in buckets) == n == m.flat_params.numel()
+            finally:
+                plan.handle = None
+                _lib.load().m2t_plan_destroy(h)
+
+
 # ---- data parallel over gloo, world_size 2 ---------------------------------------------------
 def _dp_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -165,7 +192,16 @@ def _dp_worker(rank, world, port, ret):
         grads = model.attach_flat_grads()
         for n, (o, k) in model.param_offsets().items():
             grads[o:o + k].copy_(g[n].reshape(-1))
+        g_local = grads.clone()
         GradBucket(grads).all_reduce()
+        # the overlapped exchange issues the same SUM bucket by bucket (same ranges, same order on every rank)
+        gb = g_local.clone()
+        bucket = GradBucket(gb)
+        n = gb.numel()
+        cuts = [n, int(0.8 * n), int(0.35 * n), 0]
+        for hi, lo in zip(cuts[:-1], cuts[1:]):
+            bucket.all_reduce_range(lo, hi)
+        assert torch.equal(gb, grads)
         _, _, gfull = O.l1_loss_and_grads(x, hr, p, scale, nb)
         worst = 0.0
         for n, (o, k) in model.param_offsets().items():
