@@ -210,28 +210,45 @@ __global__ void __launch_bounds__(256) instnorm_stats1_kernel(const T* __restric
       w[c] = wf_merge(w[c], q);
     }
   }
-  __shared__ float sh[256][8][3];
+  // block merge without divisions in the tree: N = sum n_i, mean = sum n_i mean_i / N, then
+  // M2 = sum (M2_i + n_i (mean_i - mean)^2); the 32 pixel lanes of a channel group are 8 lanes per wave
+  // (xor 8, 16, 32) x 4 waves (LDS), all in a fixed order
+  __shared__ float sh[2][4][8][8];
+  const int wvi = threadIdx.x >> 6;
+  float nn[8], nm[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) { sh[threadIdx.x][c][0] = w[c].n; sh[threadIdx.x][c][1] = w[c].mean; sh[threadIdx.x][c][2] = w[c].m2; }
-  // fixed pairwise tree over the 32 pixel lanes
-  for (int stride = 16; stride > 0; stride >>= 1) {
-    __syncthreads();
-    if (pl < stride) {
+  for (int c = 0; c < 8; ++c) {
+    nn[c] = w[c].n; nm[c] = w[c].n * w[c].mean;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
-        Wf a, q;
-        a.n = sh[threadIdx.x][c][0]; a.mean = sh[threadIdx.x][c][1]; a.m2 = sh[threadIdx.x][c][2];
-        q.n = sh[threadIdx.x + 8 * stride][c][0]; q.mean = sh[threadIdx.x + 8 * stride][c][1]; q.m2 = sh[threadIdx.x + 8 * stride][c][2];
-        a = wf_merge(a, q);
-        sh[threadIdx.x][c][0] = a.n; sh[threadIdx.x][c][1] = a.mean; sh[threadIdx.x][c][2] = a.m2;
-      }
-    }
+    for (int o = 8; o < 64; o <<= 1) { nn[c] += __shfl_xor(nn[c], o); nm[c] += __shfl_xor(nm[c], o); }
   }
-  if (pl == 0) {
+  if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sh[0][wvi][cgp][c] = nn[c]; sh[1][wvi][cgp][c] = nm[c]; }
+  }
+  __syncthreads();
+  float N[8], mean_b[8], dev[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    N[c] = (sh[0][0][cgp][c] + sh[0][1][cgp][c]) + (sh[0][2][cgp][c] + sh[0][3][cgp][c]);
+    mean_b[c] = ((sh[1][0][cgp][c] + sh[1][1][cgp][c]) + (sh[1][2][cgp][c] + sh[1][3][cgp][c])) / fmaxf(N[c], 1.f);
+    const float d = w[c].mean - mean_b[c];
+    dev[c] = w[c].m2 + w[c].n * d * d;
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) dev[c] += __shfl_xor(dev[c], o);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sh[0][wvi][cgp][c] = dev[c];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       float* o = part + (((long long)b * nsplit + sp) * 64 + cgp * 8 + c) * 3;
-      o[0] = sh[threadIdx.x][c][0]; o[1] = sh[threadIdx.x][c][1]; o[2] = sh[threadIdx.x][c][2];
+      o[0] = N[c]; o[1] = mean_b[c];
+      o[2] = (sh[0][0][cgp][c] + sh[0][1][cgp][c]) + (sh[0][2][cgp][c] + sh[0][3][cgp][c]);
     }
   }
 }
@@ -500,7 +517,21 @@ __global__ void __launch_bounds__(256) instnorm_bwd_red1_kernel(const T* __restr
   float mu[8], rs[8], s1[8], s2[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) { mu[c] = mean[b * 64 + cgp * 8 + c]; rs[c] = rstd[b * 64 + cgp * 8 + c]; s1[c] = 0.f; s2[c] = 0.f; }
-  for (int p = p0 + pl; p < p1; p += 32) {
+  // four pixels per trip: eight 16-byte loads in flight per lane before the first use
+  int p = p0 + pl;
+  for (; p + 96 < p1; p += 128) {
+    float g[4][8], v[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      load8f(gn + p64(npix, (long long)b * P + p + 32 * i, cgp * 8), g[i]);
+      load8f(x + p64(npix, (long long)b * P + p + 32 * i, cgp * 8), v[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 8; ++c) { s1[c] += g[i][c]; s2[c] += g[i][c] * ((v[i][c] - mu[c]) * rs[c]); }
+  }
+  for (; p < p1; p += 32) {
     float g[8], v[8];
     load8f(gn + p64(npix, (long long)b * P + p, cgp * 8), g);
     load8f(x + p64(npix, (long long)b * P + p, cgp * 8), v);
