@@ -457,7 +457,6 @@ __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restric
       const int t = 2 * c4 + (j >> 2);
       dsf[c4].set(j, (t < WA_KT) ? dp[t < WA_KT ? t : 0][j & 3] : 0.f);
     }
-  const long long wbase = (long long)blockIdx.x * WA_NK * (2 * C);
 
   // ---- phase 2: per channel chunk: dq^T = K^^T dS^T ; dV^T = dO^T P ; dK^^T = q^T dS ----
 #pragma unroll 1
@@ -510,7 +509,7 @@ __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restric
         }
         const int key = 16 * t + lr;
         if (key < WA_NK) {
-          T* wp = win + wbase + (long long)key * (2 * C);
+          T* wp = dkv_row(gqkv, win, (long long)blockIdx.x, gm.b, gm.wy, gm.wx, h, w, C, key);
 #pragma unroll
           for (int mt = 0; mt < NT; ++mt) {
             float v[4] = {akk[tt][mt][0], akk[tt][mt][1], akk[tt][mt][2], akk[tt][mt][3]};
@@ -550,41 +549,50 @@ __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restric
   }
 }
 
-// sum the per-window dK^ / dV rows over the (<= 4) windows whose 10x10 neighbourhood covers a pixel
+// add to every window-border pixel's dK|dV (already holding its own window's contribution) the ring rows of the
+// (<= 3) neighbouring windows whose 10x10 neighbourhood covers it; interior pixels are final as written.
 template <typename T>
 __global__ void __launch_bounds__(256) halo_gather_kernel(const T* __restrict__ win, T* __restrict__ gqkv, int B, int h,
                                                           int w, int C) {
   const int nv = 2 * C / 8;
   const int nh = h / 8, nw = w / 8;
-  const long long total = (long long)B * h * w * nv;
+  const long long total = (long long)B * nh * nw * 28 * nv;       // 28 border pixels per window
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
     const int cv = (int)(t % nv);
-    const long long pix = t / nv;
-    const int x = (int)(pix % w);
-    const long long q = pix / w;
-    const int y = (int)(q % h);
-    const int b = (int)(q / h);
+    long long r = t / nv;
+    const int bp = (int)(r % 28); r /= 28;
+    const int wx0 = (int)(r % nw); r /= nw;
+    const int wy0 = (int)(r % nh);
+    const int b = (int)(r / nh);
+    // border pixel bp of the 8x8 window: rows 0 and 7 (8 each), then columns 0 and 7 of rows 1..6 (6 each)
+    int py, px;
+    if (bp < 8) { py = 0; px = bp; }
+    else if (bp < 16) { py = 7; px = bp - 8; }
+    else if (bp < 22) { py = bp - 15; px = 0; }
+    else { py = bp - 21; px = 7; }
+    const int y = 8 * wy0 + py, x = 8 * wx0 + px;
     int wys[2], krs[2], ny = 1, wxs[2], kcs[2], nx = 1;
-    wys[0] = y >> 3; krs[0] = (y & 7) + 1;
-    if ((y & 7) == 0 && wys[0] > 0) { wys[1] = wys[0] - 1; krs[1] = 9; ny = 2; }
-    else if ((y & 7) == 7 && wys[0] < nh - 1) { wys[1] = wys[0] + 1; krs[1] = 0; ny = 2; }
-    wxs[0] = x >> 3; kcs[0] = (x & 7) + 1;
-    if ((x & 7) == 0 && wxs[0] > 0) { wxs[1] = wxs[0] - 1; kcs[1] = 9; nx = 2; }
-    else if ((x & 7) == 7 && wxs[0] < nw - 1) { wxs[1] = wxs[0] + 1; kcs[1] = 0; nx = 2; }
+    wys[0] = wy0; krs[0] = py + 1;
+    if (py == 0 && wy0 > 0) { wys[1] = wy0 - 1; krs[1] = 9; ny = 2; }
+    else if (py == 7 && wy0 < nh - 1) { wys[1] = wy0 + 1; krs[1] = 0; ny = 2; }
+    wxs[0] = wx0; kcs[0] = px + 1;
+    if (px == 0 && wx0 > 0) { wxs[1] = wx0 - 1; kcs[1] = 9; nx = 2; }
+    else if (px == 7 && wx0 < nw - 1) { wxs[1] = wx0 + 1; kcs[1] = 0; nx = 2; }
+    if (ny * nx == 1) continue;                                   // image corner / edge with no neighbour
+    T* dst = gqkv + (((long long)b * h + y) * w + x) * (3 * C) + C + cv * 8;
     float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    load8f(dst, acc);
     for (int a = 0; a < ny; ++a)
       for (int c = 0; c < nx; ++c) {
+        if (a == 0 && c == 0) continue;                           // the own window wrote straight to gqkv
         const long long wi = ((long long)b * nh + wys[a]) * nw + wxs[c];
-        const int key = krs[a] * 10 + kcs[c];
         float v[8];
-        load8f(win + (wi * WA_NK + key) * (2 * C) + cv * 8, v);
+        load8f(win + (wi * WA_RING + ring_index(krs[a], kcs[c])) * (2 * C) + cv * 8, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += v[e];
       }
-    store8f(gqkv + pix * (3 * C) + C + cv * 8, acc);
+    store8f(dst, acc);
   }
 }
 
@@ -652,7 +660,7 @@ static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const floa
   m2t_prof_end(C == 16 ? M2T_PROF_ATTN_BWD_16 : (C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256), st);
   M2T_LAUNCH_CHECK();
   if (gather) {
-    const long long total = (long long)B * h * w * (2 * C / 8);
+    const long long total = (long long)B * (h / 8) * (w / 8) * 28 * (2 * C / 8);
     const int g = (int)std::min<long long>(ceil_divll(total, 256), 4096);
     hipLaunchKernelGGL(halo_gather_kernel<T>, dim3(g), dim3(256), 0, st, win, gqkv, B, h, w, C);
     M2T_LAUNCH_CHECK();

@@ -206,12 +206,11 @@ __global__ void __launch_bounds__(256, 2) window_attn_bwd_c16_kernel(const bf16_
   }
 
   // ---- dK^ | dV rows of this window: lane holds channels 4g .. 4g+3 of key 16 t + lr ----
-  const long long wbase = (long long)wi * WA_NK * (2 * C16);
 #pragma unroll
   for (int t = 0; t < WA_KT; ++t) {
     const int key = 16 * t + lr;
     if (key < WA_NK) {
-      bf16_t* wp = win + wbase + (long long)key * (2 * C16) + 4 * g;
+      bf16_t* wp = dkv_row(gqkv, win, (long long)wi, b, wy, wx, h, w, C16, key) + 4 * g;
       st4(wp, pack4(dkT[t][0], dkT[t][1], dkT[t][2], dkT[t][3]));
       st4(wp + C16, pack4(dvT[t][0], dvT[t][1], dvT[t][2], dvT[t][3]));
     }

@@ -295,7 +295,6 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
   T(*VOUT)[LD] = Vs;
   T(*KOUT)[LD] = Kh;
   T(*QOUT)[LD] = DOs;
-  const long long wbase = (long long)blockIdx.x * WA_NK * (2 * C);
   const int mt0 = wv * TPW;
   // dV^T [c][key] = sum_q dO[q][c] P[q][key] ; dK^^T [c][key] = sum_q q[q][c] dS[q][key]; tile 7 of dK^ = the
   // rel-pos sums of this tile's channel half
@@ -395,12 +394,12 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
     }
   for (int idx = tid; idx < WA_NK * VEC; idx += NTHR) {
     const int key = idx / VEC, cv = idx % VEC;
-    store8(win + wbase + (long long)key * (2 * C) + C + cv * 8, load8(&VOUT[key][cv * 8]));
+    store8(dkv_row(gqkv, win, (long long)blockIdx.x, gm.b, gm.wy, gm.wx, h, w, C, key) + C + cv * 8, load8(&VOUT[key][cv * 8]));
   }
   __syncthreads();
   for (int idx = tid; idx < WA_NK * VEC; idx += NTHR) {
     const int key = idx / VEC, cv = idx % VEC;
-    store8(win + wbase + (long long)key * (2 * C) + cv * 8, load8(&KOUT[key][cv * 8]));
+    store8(dkv_row(gqkv, win, (long long)blockIdx.x, gm.b, gm.wy, gm.wx, h, w, C, key) + cv * 8, load8(&KOUT[key][cv * 8]));
   }
   for (int idx = tid; idx < 64 * VEC; idx += NTHR) {
     const int row = idx / VEC, cv = idx % VEC;

@@ -252,7 +252,6 @@ static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStr
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_SHUF) GO(M2T_A_PLAIN, M2T_E_BIAS_SHUF);
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_GELU) GO(M2T_A_PLAIN, M2T_E_BIAS_GELU);
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_RESID) GO(M2T_A_PLAIN, M2T_E_BIAS_RESID);
-  else if (amode == M2T_A_HALO && emode == M2T_E_PLAIN) GO(M2T_A_HALO, M2T_E_PLAIN);
   else if (amode == M2T_A_UNSHUF && emode == M2T_E_PLAIN) GO(M2T_A_UNSHUF, M2T_E_PLAIN);
   else if (amode == M2T_A_UNSHUF && emode == M2T_E_GELU_GRAD) GO(M2T_A_UNSHUF, M2T_E_GELU_GRAD);
   else return m2t_set_error(-2, "gemm_nt: unsupported (A mode, epilogue) combination");
@@ -513,7 +512,6 @@ static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_
   hipLaunchKernelGGL((wgrad_tn_kernel<T, GM, XM>), grid, dim3(256), 0, st, (const T*)a.G, a.ldg, (const T*)a.X, \
                      a.ldx, a.slabs, a.bias_slabs, a.M, a.N, a.K, rps, sg)
   if (a.gmode == M2T_A_PLAIN && a.xmode == M2T_A_PLAIN) GO(M2T_A_PLAIN, M2T_A_PLAIN);
-  else if (a.gmode == M2T_A_HALO && a.xmode == M2T_A_PLAIN) GO(M2T_A_HALO, M2T_A_PLAIN);
   else if (a.gmode == M2T_A_UNSHUF && a.xmode == M2T_A_PLAIN) GO(M2T_A_UNSHUF, M2T_A_PLAIN);
   else return m2t_set_error(-2, "wgrad_tn: unsupported operand modes");
 #undef GO

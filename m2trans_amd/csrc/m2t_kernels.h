@@ -66,7 +66,7 @@ int launch_layout(int dt, const float* nchw, void* nhwc, float* nchw_out, int B,
 // Y[M][N] = A[M][K] * W[N][K]^T  with A-side and epilogue variants
 // leading dimension sentinel: the operand / output is a P64 feature map ([4][M][16], m2t_common.h) with M rows
 #define M2T_LD_P64 (-64)
-enum m2t_gemm_a { M2T_A_PLAIN = 0, M2T_A_GELU = 1, M2T_A_UNSHUF = 2, M2T_A_HALO = 3 };
+enum m2t_gemm_a { M2T_A_PLAIN = 0, M2T_A_GELU = 1, M2T_A_UNSHUF = 2 };
 enum m2t_gemm_epi { M2T_E_PLAIN = 0, M2T_E_BIAS = 1, M2T_E_BIAS_SHUF = 2, M2T_E_GELU_GRAD = 3, M2T_E_BIAS_GELU = 4, M2T_E_BIAS_RESID = 5 };
 struct m2t_gemm_args {
   const void* A; int lda;       // A rows (or, UNSHUF: the [B][H*r][W*r][C] tensor)
@@ -133,12 +133,14 @@ int launch_tail_bwd_fused(const float* gout, const float* wf, const void* act, c
 // epilogue writes xc = IWT^levels(attention) + xin
 int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0,
                            const void* res, int ldr, int B, int h, int w, int C, hipStream_t st, int post_levels = 0);
-// gout [B][h][w][ldg] (channels gc0..gc0+C) -> gqkv [B][h][w][3C]; per-window dK/dV scratch `win` [B*L][100][2C] (T);
+// gout [B][h][w][ldg] (channels gc0..gc0+C) -> gqkv [B][h][w][3C]; `win` [windows][36][2C] (T): the dK|dV rows of each
+// window's 36 ring keys (its own 64 pixels are written straight to gqkv; halo_gather adds the ring rows to the
+// border pixels of the neighbouring windows);
 // rel-pos gradient slabs
 int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg,
                            int gc0, void* gqkv, void* win, float* relw, int B, int h, int w, int C, hipStream_t st,
                            int dwt_levels = 0,    // 1, 2: gout is the FULL-RES g_xc tensor; DWT^levels applied on load
-                           bool gather = true,    // false: leave dK|dV in `win` (consumers gather with M2T_A_HALO)
+                           bool gather = true,    // false: skip the halo gather (border pixels then lack their neighbours' ring rows)
                            bool resident = true); // bf16, C = 64 / 256: whole-window-resident kernel (k_attn_res.hip)
 // C = 16, bf16, no fused DWT: one wave per window (k_attn_c16.hip)
 int launch_window_attn_fwd_c16(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0, const void* res,

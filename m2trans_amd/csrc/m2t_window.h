@@ -21,6 +21,23 @@ struct WinGeom {
     return ((long long)b * h + 8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
   }
 };
+// dK|dV rows of a window's backward: the 64 keys that are the window's OWN pixels (kr, kc in 1..8) go straight to
+// their row of gqkv ([pixel][3C], columns C..3C); the 36 ring keys go to the per-window scratch `win`
+// [window][36][2C] and are added by halo_gather to the border pixels of the neighbouring windows.
+#define WA_RING 36
+__device__ __forceinline__ int ring_index(int kr, int kc) {      // kr or kc in {0, 9}
+  return (kr == 0) ? kc : ((kr == 9) ? 10 + kc : ((kc == 0) ? 19 + kr : 27 + kr));
+}
+// destination row (element offset of its dK|dV part) of key (kr,kc) of window (b,wy,wx); false: phantom key outside
+// the image whose dK|dV is dropped (the gradient of zero padding) -- only possible for ring keys
+template <typename T>
+__device__ __forceinline__ T* dkv_row(T* gqkv, T* win, long long wi, int b, int wy, int wx, int h, int w, int C, int key) {
+  const int kr = key / 10, kc = key - kr * 10;
+  if (kr >= 1 && kr <= 8 && kc >= 1 && kc <= 8)
+    return gqkv + (((long long)b * h + 8 * wy + kr - 1) * w + 8 * wx + kc - 1) * (3 * C) + C;
+  return win + (wi * WA_RING + ring_index(kr, kc)) * (2 * C);
+}
+
 __device__ __forceinline__ WinGeom make_geom(int h, int w) {
   WinGeom g;
   g.h = h; g.w = w; g.nw = w / 8; g.nh = h / 8;
