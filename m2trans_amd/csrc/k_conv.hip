@@ -228,27 +228,31 @@ __global__ void __launch_bounds__(256) conv3x3_c64_kernel(const T* __restrict__ 
 // a strip of tiles with the halo tile double-buffered: one barrier per tile instead of eighteen, the next tile's
 // global loads (halo + residuals) in flight under the current tile's 576 MFMAs.  Same tile / wave / lane mapping
 // and the same accumulation order as conv3x3_c64_kernel, so the two produce identical bits.
-// MEASURED (B=16, 128x128): 53 us against 39 us for the tile-per-workgroup kernel -- with 135 KB of LDS only one
-// 4-wave workgroup fits a CU and nothing hides the LDS read latency; kept as option "persistent_conv" (default off).
+// MEASURED (B=16, 128x128): with one 4-wave workgroup per CU 53 us against 39 us for the tile-per-workgroup kernel;
+// with 8 waves (two tiles in lockstep, below) 41 / 33 us (forward / data gradient) -- a tie.  Three designs with
+// very different weight traffic and latency structure all land at 33-40 us for 102 MB of HBM traffic (PMC), i.e.
+// ~3 TB/s on the 18-pixel x 32-byte runs of the P64 halo tiles; kept as option "persistent_conv" (default off).
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) conv3x3_c64_persistent_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+__global__ void __launch_bounds__(512) conv3x3_c64_persistent_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
                                                                      const float* __restrict__ bias, const bf16_t* __restrict__ res1,
                                                                      const bf16_t* __restrict__ res2, bf16_t* __restrict__ y, int B,
                                                                      int H, int W, int tiles_per_block) {
+  // 8 waves = two groups of 4; each group owns one tile of the current pair (its own halo buffer), all share the
+  // weights.  Per pair: stage -> barrier -> (next pair's loads issued) -> 576 MFMAs per group -> epilogue -> barrier.
   using T = bf16_t;
   constexpr int HP = (C3_TH + 2) * (C3_TW + 2);                   // 180 halo pixels
   constexpr int TOT = HP * 8, ITEMS = (TOT + 255) / 256;          // 16-byte vectors of a halo tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T(*Ws)[64][C3_LD] = reinterpret_cast<T(*)[64][C3_LD]>(smem);                                   // [9][64][72]
-  T(*Xs)[HP][C3_LD] = reinterpret_cast<T(*)[HP][C3_LD]>(smem + sizeof(T) * 9 * 64 * C3_LD);      // [2][180][72]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  T(*Xs)[HP][C3_LD] = reinterpret_cast<T(*)[HP][C3_LD]>(smem + sizeof(T) * 9 * 64 * C3_LD);      // [2 groups][180][72]
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const int tw = W / C3_TW, th = H / C3_TH;
   const long long ntiles = (long long)B * th * tw;
   const long long npix = (long long)B * H * W;                    // P64 feature maps
   const long long t0 = (long long)blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
   if (t0 >= t1) return;
-  for (int idx = tid; idx < 9 * 64 * 8; idx += 256) store8(&Ws[0][idx >> 3][(idx & 7) * 8], load8(wp + (long long)(idx >> 3) * 64 + (idx & 7) * 8));
+  for (int idx = threadIdx.x; idx < 9 * 64 * 8; idx += 512) store8(&Ws[0][idx >> 3][(idx & 7) * 8], load8(wp + (long long)(idx >> 3) * 64 + (idx & 7) * 8));
   Frag8<T> f[ITEMS];
   auto fetch = [&](long long t) {
     const int tx = (int)(t % tw);
@@ -266,74 +270,79 @@ __global__ void __launch_bounds__(256) conv3x3_c64_persistent_kernel(const bf16_
       if (idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W) f[it] = load8(x + p64(npix, pb + (long long)gy * W + gx, cv * 8));
     }
   };
-  fetch(t0);
-  int buf = 0;
-  for (long long t = t0; t < t1; ++t, buf ^= 1) {
+  if (t0 + grp < t1) fetch(t0 + grp);
+  for (long long tp = t0; tp < t1; tp += 2) {
+    const long long t = tp + grp;
+    const bool live = t < t1;
+    if (live) {
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = tid + it * 256;
-      if (idx < TOT) store8(&Xs[buf][idx >> 3][(idx & 7) * 8], f[it]);
+      for (int it = 0; it < ITEMS; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < TOT) store8(&Xs[grp][idx >> 3][(idx & 7) * 8], f[it]);
+      }
     }
-    __syncthreads();          // (the other buffer was last read before the previous barrier)
-    if (t + 1 < t1) fetch(t + 1);
-    const int tx = (int)(t % tw);
-    const long long q = t / tw;
-    const int ty = (int)(q % th);
-    const long long pb = (q / th) * H * W;
-    const int x0 = tx * C3_TW, y0 = ty * C3_TH;
-    // residual rows of this lane's two pixels: issued before the products
-    float r1[2][16], r2[2][16];
-    long long off[2];
+    __syncthreads();
+    if (t + 2 < t1) fetch(t + 2);
+    if (live) {
+      const int tx = (int)(t % tw);
+      const long long q = t / tw;
+      const int ty = (int)(q % th);
+      const long long pb = (q / th) * H * W;
+      const int x0 = tx * C3_TW, y0 = ty * C3_TH;
+      float r1[2][16], r2[2][16];
+      long long off[2];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      off[mt] = ((long long)g * npix + pb + (long long)(y0 + 2 * wv + mt) * W + x0 + lr) * 16;
-      if (res1) load16f(res1 + off[mt], r1[mt]);
-      if (res2) load16f(res2 + off[mt], r2[mt]);
-    }
-    f32x4 acc[2][4];
+      for (int mt = 0; mt < 2; ++mt) {
+        off[mt] = ((long long)g * npix + pb + (long long)(y0 + 2 * wv + mt) * W + x0 + lr) * 16;
+        if (res1) load16f(res1 + off[mt], r1[mt]);
+        if (res2) load16f(res2 + off[mt], r2[mt]);
+      }
+      f32x4 acc[2][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-      for (int kc = 0; kc < 2; ++kc) {
-        Frag8<T> xf[2];
+        for (int kc = 0; kc < 2; ++kc) {
+          Frag8<T> xf[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          xf[mt] = load8(&Xs[buf][(2 * wv + mt + ky) * (C3_TW + 2) + lr + kx][kc * 32 + g * 8]);
+          for (int mt = 0; mt < 2; ++mt)
+            xf[mt] = load8(&Xs[grp][(2 * wv + mt + ky) * (C3_TW + 2) + lr + kx][kc * 32 + g * 8]);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int nl = 16 * (lr >> 2) + 4 * nt + (lr & 3);
-          const Frag8<T> wf = load8(&Ws[tap][nl][kc * 32 + g * 8]);
+          for (int nt = 0; nt < 4; ++nt) {
+            const int nl = 16 * (lr >> 2) + 4 * nt + (lr & 3);
+            const Frag8<T> wf = load8(&Ws[tap][nl][kc * 32 + g * 8]);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wf, xf[mt]);
+            for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wf, xf[mt]);
+          }
         }
       }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float v[16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
+        if (bias) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += bias[16 * g + e];
+        }
+        if (res1) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += r1[mt][e];
+        }
+        if (res2) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += r2[mt][e];
+        }
+        store16f(y + off[mt], v);
+      }
     }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float v[16];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
-      if (bias) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += bias[16 * g + e];
-      }
-      if (res1) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += r1[mt][e];
-      }
-      if (res2) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += r2[mt][e];
-      }
-      store16f(y + off[mt], v);
-    }
+    __syncthreads();          // both halo buffers are free for the next pair
   }
 }
 
@@ -342,7 +351,7 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
   if (H % C3_TH || W % C3_TW) return m2t_set_error(-2, "conv3x3_c64: H%8 or W%16");
   const long long ntiles = (long long)B * (H / C3_TH) * (W / C3_TW);
   if (dt != M2T_F32 && persistent && ntiles >= 512) {
-    const size_t sh = sizeof(bf16_t) * C3_LD * (9 * 64 + 2 * (C3_TH + 2) * (C3_TW + 2));
+    const size_t sh = sizeof(bf16_t) * C3_LD * (9 * 64 + 2 * (C3_TH + 2) * (C3_TW + 2));   // weights + one halo tile per wave group
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -352,7 +361,7 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
     int nblk = 256;
     const int tpb = (int)ceil_divll(ntiles, nblk);
     nblk = (int)ceil_divll(ntiles, tpb);
-    hipLaunchKernelGGL(conv3x3_c64_persistent_kernel, dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
+    hipLaunchKernelGGL(conv3x3_c64_persistent_kernel, dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
                        (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, B, H, W, tpb);
     M2T_LAUNCH_CHECK();
     return 0;

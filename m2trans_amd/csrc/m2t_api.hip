@@ -87,8 +87,7 @@ struct m2t_plan {
   bool have_seed = false, have_acts = false;
   bool use_side = true;
   bool debug_skip_side = false;    // timing experiments only: skip every parameter-gradient kernel (results are WRONG)      // halo gather + qkv dgrad GEMM + prep_bwd as one kernel (k_branch.hip)
-  bool use_persistent_conv = false;  // bf16 conv3x3 with LDS-resident weights: bit-identical, but measured SLOWER (53 vs 39 us:
-                                     // one 4-wave workgroup per CU cannot hide the LDS latency that 4 co-resident tiles do)
+  bool use_persistent_conv = false;  // bf16 conv3x3 with LDS-resident weights: bit-identical, measured a tie (see k_conv.hip)
   bool use_fused_tail_bwd = true;  // x4 bf16: k_tail_bwd.hip instead of four HR kernels
   bool tail_wgrad_main = true;     // tail weight gradients on the main stream (see m2t_backward)
   int gate_branch = 2;             // 2: after the two C = 256 attentions; 1: after the C = 64 one too
