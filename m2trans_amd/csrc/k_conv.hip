@@ -567,9 +567,11 @@ __device__ __forceinline__ void final_stage_act(T (*As)[FC_LD], const T* __restr
   }
 }
 
+// Persistent: a workgroup keeps the 27 x 64 weight tile in LDS and sweeps tiles dealt round-robin; the next tile's
+// halo (11 vectors per thread) is in flight while the current one is multiplied and summed.
 template <typename T>
 __global__ void __launch_bounds__(256) final_conv_fwd_kernel(const T* __restrict__ tpre, const float* __restrict__ w,
-                                                             float* __restrict__ out, int H, int W) {
+                                                             float* __restrict__ out, int B, int H, int W) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T(*As)[FC_LD] = reinterpret_cast<T(*)[FC_LD]>(smem);                                   // [336][72] (21 pixel tiles)
   constexpr size_t szAY = (sizeof(T) * 336 * FC_LD > sizeof(float) * 336 * 33) ? sizeof(T) * 336 * FC_LD : sizeof(float) * 336 * 33;
@@ -577,59 +579,93 @@ __global__ void __launch_bounds__(256) final_conv_fwd_kernel(const T* __restrict
   float(*Ys)[33] = reinterpret_cast<float(*)[33]>(smem);   // [336][33] fp32, ALIASES As once the products are done
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
-  const int x0 = blockIdx.x * FC_T, y0 = blockIdx.y * FC_T, b = blockIdx.z;
-  final_stage_act<T, 336>(As, tpre + (long long)b * H * W * 64, y0, x0, H, W, tid);
+  const int tw = W / FC_T, th = H / FC_T;
+  const long long ntiles = (long long)B * th * tw;
+  const long long hw = (long long)H * W;
   for (int i = tid; i < 32 * 64; i += 256) {
     const int n = i >> 6, ic = i & 63;              // n = tap*3 + oc
     float v = 0.f;
     if (n < 27) v = w[((n % 3) * 64 + ic) * 9 + n / 3];
     Ws[n][ic] = from_f<T>(v);
   }
-  __syncthreads();
-  // Y^T tile products: rows n (2 tiles), cols = halo pixels (21 tiles of 16: wave wv takes wv, wv+4, ...)
-  f32x4 acc[6][2];
+  constexpr int ITEMS = (336 * 8 + 255) / 256;      // 11
+  Frag8<T> f[ITEMS];
+  auto fetch = [&](long long t) {
+    const int x0 = (int)(t % tw) * FC_T;
+    const long long q = t / tw;
+    const int y0 = (int)(q % th) * FC_T;
+    const T* tb = tpre + (q / th) * hw * 64;
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int mt = wv + 4 * j;
-    if (mt < 21) {
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * 256;
+      const int cv = idx & 7, p = idx >> 3;
+      f[it] = frag_zero<T>();
+      if (p < FC_HP) {
+        const int py = p / (FC_T + 2), px = p - py * (FC_T + 2);
+        const int gy = reflect_idx(y0 + py - 1, H), gx = reflect_idx(x0 + px - 1, W);
+        f[it] = load8(tb + ((long long)gy * W + gx) * 64 + cv * 8);
+      }
+    }
+  };
+  if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int x0 = (int)(t % tw) * FC_T;
+    const long long q = t / tw;
+    const int y0 = (int)(q % th) * FC_T;
+    const long long b = q / th;
+    __syncthreads();      // the previous tile's Ys reads are done (first trip: Ws staged)
 #pragma unroll
-      for (int kc = 0; kc < 2; ++kc) {
-        const Frag8<T> xf = load8(&As[16 * mt + lr][32 * kc + 8 * g]);
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * 256;
+      const int cv = idx & 7, p = idx >> 3;
+      if (p < 336) store8(&As[p][cv * 8], f[it]);
+    }
+    __syncthreads();
+    if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
+    // Y^T tile products: rows n (2 tiles), cols = halo pixels (21 tiles of 16: wave wv takes wv, wv+4, ...)
+    f32x4 acc[6][2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const Frag8<T> wf = load8(&Ws[16 * nt + lr][32 * kc + 8 * g]);
-          mma16(acc[j][nt], wf, xf);
+    for (int j = 0; j < 6; ++j) {
+      acc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[j][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int mt = wv + 4 * j;
+      if (mt < 21) {
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          const Frag8<T> xf = load8(&As[16 * mt + lr][32 * kc + 8 * g]);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const Frag8<T> wf = load8(&Ws[16 * nt + lr][32 * kc + 8 * g]);
+            mma16(acc[j][nt], wf, xf);
+          }
         }
       }
     }
-  }
-  __syncthreads();      // every wave is done reading As: its memory becomes the Y tile
+    __syncthreads();      // every wave is done reading As: its memory becomes the Y tile
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int mt = wv + 4 * j;
-    if (mt < 21) {
+    for (int j = 0; j < 6; ++j) {
+      const int mt = wv + 4 * j;
+      if (mt < 21) {
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Ys[16 * mt + lr][16 * nt + 4 * g + r] = acc[j][nt][r];
+          for (int r = 0; r < 4; ++r) Ys[16 * mt + lr][16 * nt + 4 * g + r] = acc[j][nt][r];
+      }
     }
-  }
-  __syncthreads();
-  const int ty = tid >> 4, tx = tid & 15;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int ky = tap / 3, kx = tap - ky * 3;
-    const float* yp = &Ys[(ty + ky) * (FC_T + 2) + tx + kx][tap * 3];
-    a0 += yp[0]; a1 += yp[1]; a2 += yp[2];
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const float* yp = &Ys[(ty + ky) * (FC_T + 2) + tx + kx][tap * 3];
+      a0 += yp[0]; a1 += yp[1]; a2 += yp[2];
+    }
+    const long long o = b * 3 * hw + (long long)(y0 + ty) * W + x0 + tx;
+    out[o] = a0;
+    out[o + hw] = a1;
+    out[o + 2 * hw] = a2;
   }
-  const long long hw = (long long)H * W;
-  const long long o = (long long)b * 3 * hw + (long long)(y0 + ty) * W + x0 + tx;
-  out[o] = a0;
-  out[o + hw] = a1;
-  out[o + 2 * hw] = a2;
 }
 template <typename T> static size_t final_fwd_smem() {
   const size_t a = sizeof(T) * 336 * FC_LD, y = sizeof(float) * 336 * 33;   // Ys aliases As; Ws sits behind the larger of the two
@@ -638,15 +674,17 @@ template <typename T> static size_t final_fwd_smem() {
 }
 int launch_final_conv_fwd(int dt, const void* tpre, const float* w, float* out, int B, int H, int W, hipStream_t st) {
   if (H % FC_T || W % FC_T) return m2t_set_error(-2, "final_conv: H,W must be multiples of 16");
-  dim3 grid(W / FC_T, H / FC_T, B);
+  const long long ntiles = (long long)B * (H / FC_T) * (W / FC_T);
   if (dt == M2T_F32) {
     const size_t sh = final_fwd_smem<float>();
     (void)hipFuncSetAttribute((const void*)final_conv_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(final_conv_fwd_kernel<float>, grid, dim3(256), sh, st, (const float*)tpre, w, out, H, W);
+    const int grid = (int)std::min<long long>(ntiles, 256);        // fp32: 101 KB of LDS, one workgroup per CU
+    hipLaunchKernelGGL(final_conv_fwd_kernel<float>, dim3(grid), dim3(256), sh, st, (const float*)tpre, w, out, B, H, W);
   } else {
     const size_t sh = final_fwd_smem<bf16_t>();
     (void)hipFuncSetAttribute((const void*)final_conv_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(final_conv_fwd_kernel<bf16_t>, grid, dim3(256), sh, st, (const bf16_t*)tpre, w, out, H, W);
+    const int grid = (int)std::min<long long>(ntiles, 768);        // bf16: 53 KB of LDS, three workgroups per CU
+    hipLaunchKernelGGL(final_conv_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, st, (const bf16_t*)tpre, w, out, B, H, W);
   }
   M2T_LAUNCH_CHECK();
   return 0;
