@@ -174,6 +174,26 @@ def test_bf16_forward_and_grads_close_to_fp32_oracle():
     assert not bad, (bad, table)
 
 
+@pytest.mark.parametrize("scale", [2, 3])
+def test_bf16_other_scales_close_to_fp32_oracle(scale):
+    """The x2 / x3 tails (one expansion with r = 2 / 3, unfused tail backward) in bf16 mode against the fp32 oracle,
+    same stated tolerance as the x4 test: output rel-rms <= 5e-2, whole-gradient cosine >= 0.99."""
+    nb, B, H, W = 2, 2, 32, 32
+    model, p = build_model(scale, nb, "bf16")
+    x = O.closed_form_image(B, 3, H, W)
+    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7)
+    loss_o, sr_o, g_o = O.l1_loss_and_grads(x, hr, p, scale, nb)
+    sr = model(x.cuda())
+    loss = torch.nn.L1Loss()(sr, hr.cuda())
+    loss.backward()
+    assert rms_rel(sr, sr_o) < 5e-2
+    names = [n for n, q in model.named_parameters() if q.requires_grad]
+    got = torch.cat([dict(model.named_parameters())[n].grad.reshape(-1).double().cpu() for n in names])
+    want = torch.cat([g_o[n].reshape(-1).double() for n in names])
+    cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
+    assert cos > 0.99, cos
+
+
 def test_bf16_fast_kernels_match_plain_kernels():
     """A/B inside bf16 mode, at a size where every specialised kernel is live (512 conv tiles, 1024 C=16
     windows): weights-resident persistent conv3x3, whole-window-resident / wave-per-window attention backward and
