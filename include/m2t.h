@@ -149,6 +149,29 @@ int m2t_semantic_loss(const float* emb, const float* text, int B, int n_patches,
 /* F.interpolate(mode='bicubic', align_corners=True) (losses.py:53-54): src [NC,Hin,Win] -> dst [NC,Hout,Wout]. */
 int m2t_bicubic_resize(const float* src, float* dst, int NC, int Hin, int Win, int Hout, int Wout, void* stream);
 
+/* ---- evaluation metrics of the reference's test loop ------------------------------------------
+ * test.py:101-113 / train.py:299-312: Y channel of utils.rgb_to_ycbcr (utils.py:121-146), `crop` (= scale) border
+ * pixels removed, x255 when rgb_range == 1; then utils.calc_psnr (utils.py:179-184) and utils.calc_ssim
+ * (utils.py:232-234 -> pytorch_msssim.ssim defaults).  sr, hr: float32 NCHW [B,3,H,W] on the device.
+ * out: double[B][2] on the device = { mean(((Ysr-Yhr)/255)^2), mean SSIM } per image (PSNR = -10 log10 out[b][0]).
+ * Y is bit-identical to the reference's fp32 Y; the reductions and the SSIM filtering are fp64.
+ * window_host: the 11 fp32 taps of the SSIM window in HOST memory (the dependency computes them with torch.exp in
+ * fp32, whose last bit a caller may want to reproduce), or NULL for the built-in exp(-(i-5)^2/4.5) normalised in fp32. */
+size_t m2t_eval_metrics_scratch_bytes(int B, int H, int W, int crop);
+int m2t_eval_metrics(const float* sr, const float* hr, int B, int H, int W, int crop, float rgb_range,
+                     const float* window_host, void* scratch, double* out, void* stream);
+
+/* ---- training input pipeline --------------------------------------------------------------------
+ * datas/us1k.py:16-36 crop_patch + utils.py ndarray2tensor + the /255 of datas/us1k.py:169, for n samples at once,
+ * cut out of uint8 HWC images that stay resident in device memory (lr_pool / hr_pool: the npy cache, back to back).
+ * desc_host: long long[n][8] in HOST memory = { byte offset of the LR image in lr_pool, of the HR image in hr_pool,
+ * LR row length in pixels, HR row length in pixels, lx, ly (LR corner; HR corner = scale x), flags (bit0 [:, ::-1],
+ * bit1 [::-1, :], bit2 transpose(1,0,2), applied in that order like the reference), LR image height }.
+ * lr_out [n,channels,patch/scale,patch/scale], hr_out [n,channels,patch,patch]: float32 NCHW, bit-identical to the
+ * reference's tensors.  The random draws themselves stay with the caller (reference order: lx, ly, hflip, vflip, rot). */
+int m2t_crop_patches(const unsigned char* lr_pool, const unsigned char* hr_pool, const long long* desc_host, int n,
+                     int channels, int patch_size, int scale, float* lr_out, float* hr_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,3 +27,61 @@ def psnr_y(sr: torch.Tensor, hr: torch.Tensor, scale: int, rgb_range: float = 1.
     if rgb_range == 1:
         s, h = s * 255.0, h * 255.0
     return calc_psnr(s, h)
+
+
+_WINDOW = None
+
+
+def _ssim_window() -> torch.Tensor:
+    """11-tap Gaussian, sigma 1.5, evaluated and normalised in fp32 with torch ops exactly as `pytorch_msssim`
+    builds its window (host tensor, read by m2t_eval_metrics during the call)."""
+    global _WINDOW
+    if _WINDOW is None:
+        c = torch.arange(11, dtype=torch.float32) - 11 // 2
+        g = torch.exp(-(c ** 2) / (2 * 1.5 ** 2))
+        _WINDOW = (g / g.sum()).contiguous()
+    return _WINDOW
+
+
+def y_metrics_device(sr: torch.Tensor, hr: torch.Tensor, scale: int, rgb_range: float = 1.0) -> torch.Tensor:
+    """PSNR input and SSIM of the eval loop (test.py:101-113, utils.py:179-184,232-234) on the device:
+    [B,3,H,W] float32 pairs -> float64 [B,2] = (mean squared Y error, mean SSIM) per image.  HIP kernels
+    behind `m2t_eval_metrics` (k_metrics.hip); no host fallback for device tensors."""
+    from . import _lib
+    if sr.shape != hr.shape or sr.dim() != 4 or sr.shape[1] != 3:
+        raise _lib.M2TError(f"expected two [B,3,H,W] tensors of equal shape, got {tuple(sr.shape)} and {tuple(hr.shape)}")
+    if not (sr.is_cuda and hr.is_cuda):
+        raise _lib.M2TError("y_metrics_device needs HIP device tensors (use psnr_y for host tensors)")
+    lib = _lib.load()
+    sr, hr = sr.contiguous().float(), hr.contiguous().float()
+    B, _, H, W = sr.shape
+    nbytes = lib.m2t_eval_metrics_scratch_bytes(B, H, W, scale)
+    if nbytes == 0:
+        raise _lib.M2TError(f"image {H}x{W} is too small for a border crop of {scale}")
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=sr.device)
+    out = torch.empty(B, 2, dtype=torch.float64, device=sr.device)
+    with torch.cuda.device(sr.device):
+        _lib.check(lib.m2t_eval_metrics(_lib.ptr(sr), _lib.ptr(hr), B, H, W, scale, float(rgb_range), _ssim_window().data_ptr(),
+                                        _lib.ptr(scratch), _lib.ptr(out), _lib.stream_ptr()), "m2t_eval_metrics")
+    return out
+
+
+def evaluate(model, pairs, scale: int, rgb_range: float = 1.0):
+    """The reference's test loop (test.py:77-122) for PSNR / SSIM: `pairs` yields (lr, hr) device tensors
+    [1,3,h,w] / [1,3,h*scale,w*scale]; returns (avg_psnr, avg_ssim) rounded as the reference prints them.
+    One host synchronisation at the end (the reference synchronises per image).  FSIM / GMSD (`piq`) are not
+    built: that dependency is absent from the reference tree and this image, so there is nothing to pin against."""
+    rows = []
+    with torch.no_grad():
+        for lr, hr in pairs:
+            sr = model(lr)
+            if sr.shape != hr.shape:
+                raise ValueError(f"hr {tuple(hr.shape)} does not match sr {tuple(sr.shape)}")
+            rows.append(y_metrics_device(sr, hr, scale, rgb_range))
+    if not rows:
+        raise ValueError("no evaluation pairs")
+    m = torch.cat(rows).cpu()
+    psnr = [-10.0 * math.log10(float(v)) for v in m[:, 0]]
+    avg_psnr = round(sum(psnr) / len(psnr) + 5e-3, 2)
+    avg_ssim = round(float(m[:, 1].sum()) / len(psnr) + 5e-5, 4)
+    return avg_psnr, avg_ssim

@@ -357,3 +357,106 @@ def psnr_y(sr: Tensor, hr: Tensor, scale: int, rgb_range: float = 1.0) -> float:
     diff = (s.double() - h.double()) / 255.0
     mse = diff.pow(2).mean()
     return float(-10.0 * math.log10(float(mse)))
+
+
+def y_channel_eval(img: Tensor, scale: int, rgb_range: float = 1.0) -> Tensor:
+    """The tensor both eval metrics are computed on: Y of utils.rgb_to_ycbcr (utils.py:121-146, with its
+    /255 on [0,1] inputs), border crop of `scale` pixels and x255 (test.py:101-111).  [B,3,H,W] -> [B,1,H-2s,W-2s]."""
+    img = img / 255.0
+    y = (65.481 * img[..., 0, :, :] + 128.553 * img[..., 1, :, :] + 24.966 * img[..., 2, :, :] + 16.0).unsqueeze(-3)
+    y = y[..., scale:-scale, scale:-scale]
+    return y * 255.0 if rgb_range == 1 else y
+
+
+def mse_y(sr: Tensor, hr: Tensor, scale: int, rgb_range: float = 1.0) -> Tensor:
+    """Per-image mean of ((Y_sr - Y_hr)/255)^2 in fp64 (utils.py:179-184: calc_psnr = -10 log10 of it)."""
+    d = (y_channel_eval(sr, scale, rgb_range).double() - y_channel_eval(hr, scale, rgb_range).double()) / 255.0
+    return d.pow(2).flatten(1).mean(1)
+
+
+SSIM_WIN, SSIM_SIGMA, SSIM_K1, SSIM_K2, SSIM_RANGE = 11, 1.5, 0.01, 0.03, 255.0
+
+
+def ssim_window(dtype=torch.float32) -> Tensor:
+    """Normalised 1-D Gaussian, 11 taps, sigma 1.5, computed in fp32 like the dependency does."""
+    c = torch.arange(SSIM_WIN, dtype=torch.float32) - SSIM_WIN // 2
+    g = torch.exp(-(c ** 2) / (2 * SSIM_SIGMA ** 2))
+    return (g / g.sum()).to(dtype)
+
+
+def ssim_y(sr: Tensor, hr: Tensor, scale: int, rgb_range: float = 1.0, dtype=torch.float32) -> Tensor:
+    """utils.calc_ssim (utils.py:232-234) on the tensors test.py:101-113 hands it: `pytorch_msssim.ssim(X, Y,
+    size_average=True)` with that package's defaults (data_range 255, 11-tap Gaussian sigma 1.5, K = (0.01, 0.03),
+    no non-negativity clamp).  Returned per image (the reference evaluates with batch 1, so size_average is a no-op).
+
+    PARITY UNPINNED: `pytorch_msssim` (pip, no version pin in the reference's README/environment) is not
+    vendored under /root/reference and is not installed here; this restates its published algorithm (Wang et al.
+    2004 as implemented by that package): separable VALID Gaussian filtering, first along H then along W, of
+    X, Y, X*X, Y*Y, X*Y; sigma = filtered square minus squared mean; ssim_map = (2 mu1 mu2 + C1)/(mu1^2 + mu2^2 + C1)
+    * (2 sigma12 + C2)/(sigma1^2 + sigma2^2 + C2); mean over the map.  Anchors used by the tests instead:
+    SSIM(x, x) = 1, the closed form for constant images, symmetry, and an independent float64 scipy evaluation."""
+    X = y_channel_eval(sr, scale, rgb_range).to(dtype)
+    Y = y_channel_eval(hr, scale, rgb_range).to(dtype)
+    g = ssim_window(dtype)
+    C1, C2 = (SSIM_K1 * SSIM_RANGE) ** 2, (SSIM_K2 * SSIM_RANGE) ** 2
+
+    def filt(t):
+        if t.shape[-2] >= SSIM_WIN:        # the dependency skips (with a warning) an axis shorter than the window
+            t = F.conv2d(t, g.view(1, 1, -1, 1))
+        if t.shape[-1] >= SSIM_WIN:
+            t = F.conv2d(t, g.view(1, 1, 1, -1))
+        return t
+
+    mu1, mu2 = filt(X), filt(Y)
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = filt(X * X) - mu1_sq
+    s2 = filt(Y * Y) - mu2_sq
+    s12 = filt(X * Y) - mu12
+    cs = (2 * s12 + C2) / (s1 + s2 + C2)
+    m = ((2 * mu12 + C1) / (mu1_sq + mu2_sq + C1)) * cs
+    return m.flatten(1).mean(1)
+
+
+# --------------------------------------------------------------------------------------
+# training input pipeline   (datas/us1k.py:16-36,146-170; utils.py ndarray2tensor:237-240)
+# --------------------------------------------------------------------------------------
+def crop_patch_draw(rng, lr_h: int, lr_w: int, patch_size: int, scale: int, augment: bool = True):
+    """The random draws of datas/us1k.py:21,27-29 in the reference's order on a `random.Random`-like `rng`:
+    column then row of the LR corner, then hflip, vflip, rot90 (each `random() > 0.5`)."""
+    lp = patch_size // scale
+    lx = rng.randrange(0, lr_w - lp + 1)
+    ly = rng.randrange(0, lr_h - lp + 1)
+    hflip = vflip = rot90 = False
+    if augment:
+        hflip = rng.random() > 0.5
+        vflip = rng.random() > 0.5
+        rot90 = rng.random() > 0.5
+    return lx, ly, hflip, vflip, rot90
+
+
+def crop_patch_apply(lr, hr, draw, patch_size: int, scale: int):
+    """datas/us1k.py:22-35 + :169 for given draws: lr / hr are HWC arrays (the npy cache holds uint8);
+    returns float32 CHW tensors already divided by 255 (what `US1K.__getitem__` hands to the DataLoader)."""
+    import numpy as np
+    lx, ly, hflip, vflip, rot90 = draw
+    hp, lp = patch_size, patch_size // scale
+    hx, hy = lx * scale, ly * scale
+    lp_, hp_ = lr[ly:ly + lp, lx:lx + lp, :], hr[hy:hy + hp, hx:hx + hp, :]
+    if hflip:
+        lp_, hp_ = lp_[:, ::-1, :], hp_[:, ::-1, :]
+    if vflip:
+        lp_, hp_ = lp_[::-1, :, :], hp_[::-1, :, :]
+    if rot90:
+        lp_, hp_ = lp_.transpose(1, 0, 2), hp_.transpose(1, 0, 2)
+
+    def to_tensor(a):
+        return torch.from_numpy(np.ascontiguousarray(a.transpose((2, 0, 1)))).float() / 255.0
+
+    return to_tensor(lp_), to_tensor(hp_)
+
+
+def closed_form_u8_image(h: int, w: int, c: int = 3, phase: float = 0.0):
+    """Deterministic uint8 HWC image (stand-in for one entry of the us1k npy cache)."""
+    import numpy as np
+    v = closed_form_image(1, c, h, w, phase=phase, dtype=torch.float64)[0]
+    return np.ascontiguousarray((v * 255.0).round().clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy())

@@ -214,9 +214,38 @@ def main():
                         body3_attn2_rel_w=sd0["body.3.attn2.rel_w"].numpy())
     report.append("seed-33 init checksums of the reference written (init_seed33_x4.npz)")
 
+    # ---- 8. input pipeline: crop / flip / transpose / to-tensor / 255 (datas/us1k.py:16-36,169) ---------
+    # datas/us1k.py imports imageio, skimage.color and cv2 at module level (none installed here); the functions
+    # exercised below (crop_patch, utils.ndarray2tensor) never touch them, so empty stand-in modules suffice.
+    for name in ("imageio", "skimage", "skimage.color"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    import importlib
+    import random
+    us1k = importlib.import_module("datas.us1k")
+    scale_p, patch_p = 4, 48
+    lr_img = O.closed_form_u8_image(37, 53, phase=0.4)
+    hr_img = O.closed_form_u8_image(37 * scale_p, 53 * scale_p, phase=0.4)
+    random.seed(33)
+    ref_out = [us1k.crop_patch(lr_img, hr_img, patch_p, scale_p, True) for _ in range(16)]
+    ref_out = [(a / 255.0, b / 255.0) for a, b in ref_out]                  # US1K.__getitem__ :169
+    rng = random.Random(33)
+    draws, seen = [], set()
+    for k in range(16):
+        d = O.crop_patch_draw(rng, 37, 53, patch_p, scale_p, True)
+        a, b = O.crop_patch_apply(lr_img, hr_img, d, patch_p, scale_p)
+        assert torch.equal(a, ref_out[k][0]) and torch.equal(b, ref_out[k][1]), k
+        draws.append([int(v) for v in d]); seen.add(tuple(d[2:]))
+    assert len(seen) >= 6, "the 16 draws should cover most flip/transpose combinations"
+    np.savez_compressed(os.path.join(out_dir, "crop_patch_seed33.npz"), draws=np.array(draws),
+                        lr_sums=np.array([float(a.double().sum()) for a, _ in ref_out]),
+                        hr_sums=np.array([float(b.double().sum()) for _, b in ref_out]),
+                        lr_first=ref_out[0][0].numpy(), hr_corner=ref_out[5][1][:, :8, :8].numpy())
+    report.append(f"crop_patch: 16 seeded draws bit-equal to datas/us1k.py ({len(seen)} of 8 flip/rot combinations)")
+
     with open(os.path.join(HERE, "PINNING.txt"), "w") as f:
         f.write("oracle/m2trans_oracle.py checked against /root/reference "
-                "(models/M2Trans_network.py, utils.py) by oracle/pin_against_reference.py\n")
+                "(models/M2Trans_network.py, utils.py, datas/us1k.py) by oracle/pin_against_reference.py\n")
         f.write("\n".join(report) + "\n")
     print("\n".join(report))
 
