@@ -295,3 +295,44 @@ def test_no_cpu_fallback():
     model = create_model(make_args(4, 1))
     with pytest.raises(M2TError):
         model(torch.zeros(1, 3, 32, 32))
+
+
+def test_training_drift_psnr_vs_oracle():
+    """N identical Adam steps (same weights, same synthetic data, fp32 master weights) in the oracle on
+    the CPU and in the build (fp32 and bf16 compute); PSNR-Y of a held-out pair through the eval formula.
+    Target |dPSNR| <= 0.02 dB; the loss curves must agree step by step."""
+    import torch.nn.functional as F
+    from m2trans_amd.train_step import TrainStep
+    scale, nb, B, H, W, N = 4, 2, 2, 32, 32, 24
+
+    def pair(phase):
+        hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=phase)
+        return F.avg_pool2d(hr, scale).contiguous(), hr
+
+    p = {k: v.clone() for k, v in O.closed_form_params(64, scale, nb).items()}
+    names = O.trainable_names(p)
+    m = {k: torch.zeros_like(p[k]) for k in names}
+    v = {k: torch.zeros_like(p[k]) for k in names}
+    losses_o = []
+    for s in range(1, N + 1):
+        lr_img, hr_img = pair(0.3 * s)
+        loss, _, g = O.l1_loss_and_grads(lr_img, hr_img, p, scale, nb)
+        losses_o.append(float(loss))
+        for k in names:
+            p[k], m[k], v[k] = O.adam_update(p[k], g[k], m[k], v[k], s, 1e-4)
+    lr_v, hr_v = pair(9.1)
+    with torch.no_grad():
+        ps_o = O.psnr_y(O.forward(lr_v, p, scale, nb), hr_v, scale)
+        ps_0 = O.psnr_y(O.forward(lr_v, O.closed_form_params(64, scale, nb), scale, nb), hr_v, scale)
+    assert abs(ps_o - ps_0) > 0.05, "the N steps must move the held-out PSNR for the comparison to mean anything"
+    for dt, loss_tol, tol in (("fp32", 2e-5, 2e-3), ("bf16", 5e-3, 0.02)):
+        model, _ = build_model(scale, nb, dt)
+        ts = TrainStep(model, lr=1e-4, lambda_l1=1.0, world_size=1)
+        for s in range(1, N + 1):
+            lr_img, hr_img = pair(0.3 * s)
+            loss = float(ts.step(lr_img.cuda(), hr_img.cuda()))
+            assert abs(loss - losses_o[s - 1]) <= loss_tol * max(1.0, abs(losses_o[s - 1])), (dt, s, loss, losses_o[s - 1])
+        with torch.no_grad():
+            ps = O.psnr_y(model(lr_v.cuda()).cpu(), hr_v, scale)
+        print(f"training drift {dt}: PSNR {ps:.4f} dB vs oracle {ps_o:.4f} dB (untrained {ps_0:.4f})")
+        assert abs(ps - ps_o) <= tol, (dt, ps, ps_o)
