@@ -181,9 +181,7 @@ def main():
     torch.cuda.synchronize()
     if rank == 0 and not args.no_kernel_events and args.warmup > 0:
         tt = m2t_profile.read_all()
-        single = [i for i, n in enumerate(m2t_profile.CATS) if n.startswith(("attn_", "conv3x3_", "final_conv_"))]
-        top = max(single, key=lambda i: tt[m2t_profile.CATS[i]][0])      # dominant single-shape kernel
-        dominant_mask = 1 << top
+        dominant_mask = m2t_profile.dominant_mask(tt)                    # dominant single-shape kernel
         m2t_profile.enable(0)
     if world > 1:
         torch.distributed.barrier()

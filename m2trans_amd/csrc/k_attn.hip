@@ -260,7 +260,7 @@ int launch_window_attn_fwd(int dt, const void* qkv, const float* rel_h, const fl
     const int rc = launch_window_attn_fwd_resident(qkv, rel_h, rel_w, out, ldo, oc0, res, ldr, B, h, w, C, post_levels, st);
     if (rc != M2T_UNSUPPORTED) return rc;
   }
-#define GO(T_, C_, L_) hipLaunchKernelGGL((window_attn_fwd_kernel<T_, C_, L_>), dim3(nwin), dim3(256), 0, st, (const T_*)qkv, rel_h, rel_w, (T_*)out, ldo, oc0, (const T_*)res, ldr, h, w)
+#define GO(T_, C_, L_) M2T_LAUNCH_TIMED((window_attn_fwd_kernel<T_, C_, L_>), dim3(nwin), dim3(256), 0, st, (const T_*)qkv, rel_h, rel_w, (T_*)out, ldo, oc0, (const T_*)res, ldr, h, w)
 #define GOT(T_)                                                                                   \
   if (post_levels == 1) GO(T_, 64, 1); else if (post_levels == 2) GO(T_, 256, 2);                   \
   else if (C == 16) GO(T_, 16, 0); else if (C == 64) GO(T_, 64, 0); else if (C == 256) GO(T_, 256, 0); \
@@ -598,21 +598,33 @@ __global__ void __launch_bounds__(256) halo_gather_kernel(const T* __restrict__ 
 
 // relative-position gradients: sum the per-window partials relw [nwin][10*C] over the windows
 // (two deterministic stages), then scatter to the torch layouts rel_h [1][10][1][C/2], rel_w [1][1][10][C/2]
+// stage 1: workgroup = 32 columns x 8 window lanes of one split; every thread keeps 4 independent partial sums, so a
+// split of 128 windows (C = 16: 4096 windows) costs 4 rounds of loads instead of 32 (30 us -> 5 us per launch)
 __global__ void __launch_bounds__(256) rel_reduce1_kernel(const float* __restrict__ relw, float* __restrict__ part, int nwin,
                                                           int ncol, int win_per_split) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= ncol) return;
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, l = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
   const int w0 = blockIdx.y * win_per_split, w1 = min(nwin, w0 + win_per_split);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int wi = w0;
-  for (; wi + 3 < w1; wi += 4) {
-    a0 += relw[(long long)wi * ncol + col];
-    a1 += relw[(long long)(wi + 1) * ncol + col];
-    a2 += relw[(long long)(wi + 2) * ncol + col];
-    a3 += relw[(long long)(wi + 3) * ncol + col];
+  if (col < ncol) {
+    int wi = w0 + l;
+    for (; wi + 24 < w1; wi += 32) {
+      a0 += relw[(long long)wi * ncol + col];
+      a1 += relw[(long long)(wi + 8) * ncol + col];
+      a2 += relw[(long long)(wi + 16) * ncol + col];
+      a3 += relw[(long long)(wi + 24) * ncol + col];
+    }
+    for (; wi < w1; wi += 8) a0 += relw[(long long)wi * ncol + col];
   }
-  for (; wi < w1; ++wi) a0 += relw[(long long)wi * ncol + col];
-  part[(long long)blockIdx.y * ncol + col] = (a0 + a1) + (a2 + a3);
+  red[l][c] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (l == 0 && col < ncol) {
+    float t = red[0][c];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) t += red[j][c];
+    part[(long long)blockIdx.y * ncol + col] = t;
+  }
 }
 __global__ void __launch_bounds__(256) rel_reduce2_kernel(const float* __restrict__ part, float* __restrict__ grel_h,
                                                           float* __restrict__ grel_w, int nsplit, int C) {
@@ -641,7 +653,7 @@ static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const floa
   {                                                                                                                \
     const size_t sh = attn_bwd_smem<T, C_>();                                                                      \
     (void)hipFuncSetAttribute((const void*)window_attn_bwd_kernel<T, C_, L_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-    hipLaunchKernelGGL((window_attn_bwd_kernel<T, C_, L_>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, h, w); \
+    M2T_LAUNCH_TIMED((window_attn_bwd_kernel<T, C_, L_>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, h, w); \
   }
   m2t_prof_begin(C == 16 ? M2T_PROF_ATTN_BWD_16 : (C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256), st);
   int res_rc = M2T_UNSUPPORTED;
@@ -671,7 +683,7 @@ int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int*
   int nsplit = std::min(nwin, 32);
   const int wps = ceil_div(nwin, nsplit);
   nsplit = ceil_div(nwin, wps);
-  hipLaunchKernelGGL(rel_reduce1_kernel, dim3(ceil_div(10 * C, 256), nsplit), dim3(256), 0, st, relw, rel_part, nwin, 10 * C, wps);
+  hipLaunchKernelGGL(rel_reduce1_kernel, dim3(ceil_div(10 * C, 32), nsplit), dim3(256), 0, st, relw, rel_part, nwin, 10 * C, wps);
   M2T_LAUNCH_CHECK();
   *nsplit_out = nsplit;
   return 0;
@@ -680,7 +692,7 @@ int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* 
   int nsplit = std::min(nwin, 32);
   const int wps = ceil_div(nwin, nsplit);
   nsplit = ceil_div(nwin, wps);
-  hipLaunchKernelGGL(rel_reduce1_kernel, dim3(ceil_div(10 * C, 256), nsplit), dim3(256), 0, st, relw, rel_part, nwin, 10 * C, wps);
+  hipLaunchKernelGGL(rel_reduce1_kernel, dim3(ceil_div(10 * C, 32), nsplit), dim3(256), 0, st, relw, rel_part, nwin, 10 * C, wps);
   M2T_LAUNCH_CHECK();
   hipLaunchKernelGGL(rel_reduce2_kernel, dim3(ceil_div(10 * C, 256)), dim3(256), 0, st, rel_part, grel_h, grel_w, nsplit, C);
   M2T_LAUNCH_CHECK();

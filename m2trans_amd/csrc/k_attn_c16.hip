@@ -350,7 +350,7 @@ int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float*
     if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
     attr_set = true;
   }
-  hipLaunchKernelGGL(window_attn_bwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), sh, st, (const bf16_t*)qkv, rel_h, rel_w,
+  M2T_LAUNCH_TIMED(window_attn_bwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), sh, st, (const bf16_t*)qkv, rel_h, rel_w,
                      (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, h, w, nwin);
   M2T_LAUNCH_CHECK();
   return 0;
@@ -359,7 +359,7 @@ int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float*
 int launch_window_attn_fwd_c16(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0, const void* res,
                                int ldr, int B, int h, int w, hipStream_t st) {
   const int nwin = B * (h / 8) * (w / 8);
-  hipLaunchKernelGGL(window_attn_fwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), 0, st, (const bf16_t*)qkv, rel_h, rel_w,
+  M2T_LAUNCH_TIMED(window_attn_fwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), 0, st, (const bf16_t*)qkv, rel_h, rel_w,
                      (bf16_t*)out, ldo, oc0, (const bf16_t*)res, ldr, h, w, nwin);
   M2T_LAUNCH_CHECK();
   return 0;

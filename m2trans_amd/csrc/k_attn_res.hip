@@ -575,7 +575,7 @@ int go_fwd_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, bf16_t
     if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
     attr_set = true;
   }
-  hipLaunchKernelGGL((window_attn_fwd_res_kernel<C, L>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, out, ldo, oc0, res, ldr, h, w);
+  M2T_LAUNCH_TIMED((window_attn_fwd_res_kernel<C, L>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, out, ldo, oc0, res, ldr, h, w);
   return 0;
 }
 
@@ -589,7 +589,7 @@ int go_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, const bf16
     if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
     attr_set = true;
   }
-  hipLaunchKernelGGL((window_attn_bwd_res_kernel<C, L, NW>), dim3(nwin), dim3(NW * 64), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0,
+  M2T_LAUNCH_TIMED((window_attn_bwd_res_kernel<C, L, NW>), dim3(nwin), dim3(NW * 64), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0,
                      gqkv, win, relw, h, w);
   return 0;
 }

@@ -361,14 +361,14 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
     int nblk = 256;
     const int tpb = (int)ceil_divll(ntiles, nblk);
     nblk = (int)ceil_divll(ntiles, tpb);
-    hipLaunchKernelGGL(conv3x3_c64_persistent_kernel, dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
+    M2T_LAUNCH_TIMED(conv3x3_c64_persistent_kernel, dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
                        (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, B, H, W, tpb);
     M2T_LAUNCH_CHECK();
     return 0;
   }
   dim3 grid(W / C3_TW, H / C3_TH, B);
-  if (dt == M2T_F32) hipLaunchKernelGGL(conv3x3_c64_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)wp, bias, (const float*)res1, (const float*)res2, (float*)y, H, W);
-  else hipLaunchKernelGGL(conv3x3_c64_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, H, W);
+  if (dt == M2T_F32) M2T_LAUNCH_TIMED(conv3x3_c64_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)wp, bias, (const float*)res1, (const float*)res2, (float*)y, H, W);
+  else M2T_LAUNCH_TIMED(conv3x3_c64_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wp, bias, (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, H, W);
   M2T_LAUNCH_CHECK();
   return 0;
 }
@@ -517,11 +517,11 @@ int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs
   if (dt == M2T_F32) {
     const size_t sh = sizeof(float) * 72 * (4 * 16 + 6 * 18);
     (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<float, 4>), dim3(nblk), dim3(512), sh, st, (const float*)x, (const float*)gy, slabs, bias_slabs, B, H, W, tpb);
+    M2T_LAUNCH_TIMED((conv3x3_c64_wgrad_kernel<float, 4>), dim3(nblk), dim3(512), sh, st, (const float*)x, (const float*)gy, slabs, bias_slabs, B, H, W, tpb);
   } else {
     const size_t sh = sizeof(bf16_t) * 72 * (8 * 16 + 10 * 18);
     (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL((conv3x3_c64_wgrad_kernel<bf16_t, 8>), dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)gy, slabs, bias_slabs, B, H, W, tpb);
+    M2T_LAUNCH_TIMED((conv3x3_c64_wgrad_kernel<bf16_t, 8>), dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)gy, slabs, bias_slabs, B, H, W, tpb);
   }
   M2T_LAUNCH_CHECK();
   *nslab = nblk;
@@ -679,12 +679,12 @@ int launch_final_conv_fwd(int dt, const void* tpre, const float* w, float* out, 
     const size_t sh = final_fwd_smem<float>();
     (void)hipFuncSetAttribute((const void*)final_conv_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int grid = (int)std::min<long long>(ntiles, 256);        // fp32: 101 KB of LDS, one workgroup per CU
-    hipLaunchKernelGGL(final_conv_fwd_kernel<float>, dim3(grid), dim3(256), sh, st, (const float*)tpre, w, out, B, H, W);
+    M2T_LAUNCH_TIMED(final_conv_fwd_kernel<float>, dim3(grid), dim3(256), sh, st, (const float*)tpre, w, out, B, H, W);
   } else {
     const size_t sh = final_fwd_smem<bf16_t>();
     (void)hipFuncSetAttribute((const void*)final_conv_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     const int grid = (int)std::min<long long>(ntiles, 768);        // bf16: 53 KB of LDS, three workgroups per CU
-    hipLaunchKernelGGL(final_conv_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, st, (const bf16_t*)tpre, w, out, B, H, W);
+    M2T_LAUNCH_TIMED(final_conv_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, st, (const bf16_t*)tpre, w, out, B, H, W);
   }
   M2T_LAUNCH_CHECK();
   return 0;
@@ -788,8 +788,8 @@ int launch_final_conv_dgrad(int dt, const float* gout, const float* w, const voi
                             hipStream_t st) {
   if (H % FC_T || W % FC_T) return m2t_set_error(-2, "final_conv: H,W must be multiples of 16");
   dim3 grid(W / FC_T, H / FC_T, B);
-  if (dt == M2T_F32) hipLaunchKernelGGL(final_conv_dgrad_kernel<float>, grid, dim3(256), 0, st, gout, w, (const float*)tpre, (float*)gtpre, H, W);
-  else hipLaunchKernelGGL(final_conv_dgrad_kernel<bf16_t>, grid, dim3(256), 0, st, gout, w, (const bf16_t*)tpre, (bf16_t*)gtpre, H, W);
+  if (dt == M2T_F32) M2T_LAUNCH_TIMED(final_conv_dgrad_kernel<float>, grid, dim3(256), 0, st, gout, w, (const float*)tpre, (float*)gtpre, H, W);
+  else M2T_LAUNCH_TIMED(final_conv_dgrad_kernel<bf16_t>, grid, dim3(256), 0, st, gout, w, (const bf16_t*)tpre, (bf16_t*)gtpre, H, W);
   M2T_LAUNCH_CHECK();
   return 0;
 }
@@ -868,11 +868,11 @@ int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* 
   if (dt == M2T_F32) {
     const size_t sh = final_wgrad_smem<float>();
     (void)hipFuncSetAttribute((const void*)final_conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(final_conv_wgrad_kernel<float>, dim3(nblk), dim3(256), sh, st, gout, (const float*)tpre, slabs, B, H, W, tpb);
+    M2T_LAUNCH_TIMED(final_conv_wgrad_kernel<float>, dim3(nblk), dim3(256), sh, st, gout, (const float*)tpre, slabs, B, H, W, tpb);
   } else {
     const size_t sh = final_wgrad_smem<bf16_t>();
     (void)hipFuncSetAttribute((const void*)final_conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    hipLaunchKernelGGL(final_conv_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), sh, st, gout, (const bf16_t*)tpre, slabs, B, H, W, tpb);
+    M2T_LAUNCH_TIMED(final_conv_wgrad_kernel<bf16_t>, dim3(nblk), dim3(256), sh, st, gout, (const bf16_t*)tpre, slabs, B, H, W, tpb);
   }
   M2T_LAUNCH_CHECK();
   *nslab = nblk;

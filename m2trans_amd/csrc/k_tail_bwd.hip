@@ -344,7 +344,7 @@ int launch_tail_bwd_fused(const float* gout, const float* wf, const void* act, c
   }
   TailBwdArgs a{gout, wf, (const bf16_t*)act, (const bf16_t*)der, (const bf16_t*)a1, (const bf16_t*)d1, (const bf16_t*)w3t,
                 (bf16_t*)gt1, slab_wf, slab_w3, slab_b3, B, H, W};
-  hipLaunchKernelGGL(tail_bwd_fused_kernel, dim3(nblk), dim3(512), sh, st, a);
+  M2T_LAUNCH_TIMED(tail_bwd_fused_kernel, dim3(nblk), dim3(512), sh, st, a);
   M2T_LAUNCH_CHECK();
   *nslab_out = nblk;
   return 0;

@@ -27,17 +27,29 @@ struct ProfState {
   unsigned long long mask = 0;
   std::vector<ProfRec> pool;
   size_t used = 0;
-  hipEvent_t pending = nullptr;
+  bool open = false, taken = false;      // a dispatch-timed scope is open / its events went out with a launch
 } g_prof;
 }
 void m2t_prof_begin(int cat, hipStream_t st) {
   if (!((g_prof.mask >> cat) & 1ull) || g_prof.used >= g_prof.pool.size()) return;
   ProfRec& r = g_prof.pool[g_prof.used];
   r.cat = cat;
+  if ((M2T_PROF_DISPATCH_CATS >> cat) & 1ull) { g_prof.open = true; g_prof.taken = false; return; }
   (void)hipEventRecord(r.a, st);
+}
+bool m2t_prof_take(hipEvent_t* a, hipEvent_t* b) {
+  if (!g_prof.open || g_prof.taken) return false;
+  g_prof.taken = true;
+  *a = g_prof.pool[g_prof.used].a; *b = g_prof.pool[g_prof.used].b;
+  return true;
 }
 void m2t_prof_end(int cat, hipStream_t st) {
   if (!((g_prof.mask >> cat) & 1ull) || g_prof.used >= g_prof.pool.size()) return;
+  if ((M2T_PROF_DISPATCH_CATS >> cat) & 1ull) {
+    if (g_prof.open && g_prof.taken) ++g_prof.used;     // a scope whose launcher did not take the events is dropped
+    g_prof.open = g_prof.taken = false;
+    return;
+  }
   (void)hipEventRecord(g_prof.pool[g_prof.used].b, st);
   ++g_prof.used;
 }

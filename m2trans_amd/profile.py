@@ -43,6 +43,8 @@ KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these cate
     "tail_gemm": "tail_expand_kernel (fwd) + gemm_nt_kernel (data gradients)",
     "final_conv_dgrad": "tail_bwd_fused_kernel (tail conv dgrad+wgrad, GELU', tail.3 dgrad+wgrad)",
 }
+MERGED = {"conv3x3_fwd+dgrad": ("conv3x3_fwd", "conv3x3_dgrad")}
+MERGED_KERNEL = {"conv3x3_fwd+dgrad": "conv3x3_c64_kernel (64->64 3x3 conv: forward and data gradient are the same kernel and tile shape)"}
 HBM_PEAK_GBS = 8000.0
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
 ALL_MASK = (1 << len(CATS)) - 1
@@ -144,19 +146,53 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
                      "hbm_GBs": round(by_l / avg_s / 1e9, 1), "mfma_TFs": round(fl_l / avg_s / 1e12, 2)})
     if not rows:
         return None
-    rows.sort(key=lambda r: -r["total_ms"])
-    # the headline object is the dominant SINGLE kernel (one shape per launch); the qkv / tail GEMM
-    # categories aggregate four different shapes each and are listed under "others"
-    single = [r for r in rows if r["category"].startswith(("attn_", "conv3x3_", "final_conv_"))]
-    first = single[0] if single else rows[0]
-    rows.remove(first)
-    rows.insert(0, first)
     for r in rows:
         if r["traffic"] is None:
             alias = {"conv3x3_fwd": "conv3x3_fwd+dgrad", "conv3x3_dgrad": "conv3x3_fwd+dgrad"}.get(r["category"])
             if alias:
                 r["traffic"] = traffic.get(alias)
+    # one kernel, one tile shape, launched under two categories: rocprofv3 lists it as ONE row, so does the headline
+    for merged, parts in MERGED.items():
+        sub = [r for r in rows if r["category"] in parts]
+        if len(sub) != len(parts):
+            continue
+        n = sum(r["launches"] for r in sub)
+        ms = sum(r["total_ms"] for r in sub)
+        by = sum(work[r["category"]][1] / work[r["category"]][2] * r["launches"] for r in sub)
+        fl = sum(work[r["category"]][0] / work[r["category"]][2] * r["launches"] for r in sub)
+        sec = ms * 1e-3
+        bound = "hbm" if by / (HBM_PEAK_GBS * 1e9) >= fl / (MFMA_PEAK_TF[dtype] * 1e12) else "mfma"
+        ach, peak, unit = (by / sec / 1e9, HBM_PEAK_GBS, "GB/s") if bound == "hbm" else (fl / sec / 1e12, MFMA_PEAK_TF[dtype], "TFLOP/s")
+        rows.append({"kernel": MERGED_KERNEL[merged], "category": merged, "bound": bound, "achieved": round(ach, 2), "peak": peak,
+                     "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic.get(merged),
+                     "avg_launch_us": round(ms / n * 1e3, 2), "launches": n, "total_ms": round(ms, 3),
+                     "hbm_GBs": round(by / sec / 1e9, 1), "mfma_TFs": round(fl / sec / 1e12, 2)})
+    rows.sort(key=lambda r: -r["total_ms"])
+    # the headline object is the dominant SINGLE kernel (one shape per launch); the qkv / tail GEMM
+    # categories aggregate four different shapes each and are listed under "others"
+    parts_of_merged = {c for m, parts in MERGED.items() if any(r["category"] == m for r in rows) for c in parts}
+    single = [r for r in rows if r["category"].startswith(("attn_", "conv3x3_", "final_conv_")) and r["category"] not in parts_of_merged]
+    first = single[0] if single else rows[0]
+    rows.remove(first)
+    rows.insert(0, first)
     top = dict(rows[0])
     top["others"] = [{k: r[k] for k in ("category", "bound", "frac", "avg_launch_us", "total_ms", "hbm_GBs", "mfma_TFs")}
-                     for r in rows[1:]]
+                     for r in rows[1:] if r["category"] not in MERGED]
     return top
+
+
+def dominant_mask(totals) -> int:
+    """Bit mask of the categories of the dominant single-shape kernel, from `read_all()` totals (forward and data
+    gradient of the 3x3 conv are one kernel)."""
+    cand = {}
+    merged_parts = set()
+    for m, parts in MERGED.items():
+        if all(totals.get(c, (0.0, 0))[1] > 0 for c in parts):
+            cand[m] = (sum(totals[c][0] for c in parts), sum(1 << CATS.index(c) for c in parts))
+            merged_parts.update(parts)
+    for i, c in enumerate(CATS):
+        if c.startswith(("attn_", "conv3x3_", "final_conv_")) and c not in merged_parts and totals.get(c, (0.0, 0))[1] > 0:
+            cand[c] = (totals[c][0], 1 << i)
+    if not cand:
+        return 0
+    return max(cand.values(), key=lambda v: v[0])[1]
