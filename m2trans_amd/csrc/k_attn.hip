@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restric
         }
         const int key = 16 * t + lr;
         if (key < WA_NK) {
-          T* wp = dkv_row(gqkv, win, (long long)blockIdx.x, gm.b, gm.wy, gm.wx, h, w, C, key);
+          T* wp = dkv_row(gqkv, win, (long long)gm.wi, gm.b, gm.wy, gm.wx, h, w, C, key);
 #pragma unroll
           for (int mt = 0; mt < NT; ++mt) {
             float v[4] = {akk[tt][mt][0], akk[tt][mt][1], akk[tt][mt][2], akk[tt][mt][3]};
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restric
 #pragma unroll
         for (int j = 0; j < 10; ++j) a += KA[j * 10 + i][c];      // column embedding: sum over rows
       }
-      relw[((long long)blockIdx.x * 10 + i) * C + cc] = a;
+      relw[((long long)gm.wi * 10 + i) * C + cc] = a;
     }
   }
 }

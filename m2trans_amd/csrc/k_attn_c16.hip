@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256, 2) window_attn_bwd_c16_kernel(const bf16_
                                                                   float* __restrict__ relw, int h, int w, int nwin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wi = blockIdx.x * 4 + wv;
+  const int wi = xcd_block_index() * 4 + wv;
   if (wi >= nwin) return;                         // no workgroup barrier anywhere: a wave may leave alone
   C16WaveLds& L = reinterpret_cast<C16WaveLds*>(smem)[wv];
   const int lr = lane & 15, g = lane >> 4;
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256, 4) window_attn_fwd_c16_kernel(const bf16_
                                                                      int nwin) {
   __shared__ __attribute__((aligned(16))) bf16_t VsAll[4][112][16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int wi = blockIdx.x * 4 + wv;
+  const int wi = xcd_block_index() * 4 + wv;
   if (wi >= nwin) return;
   bf16_t(*Vs)[16] = VsAll[wv];
   const int lr = lane & 15, g = lane >> 4;

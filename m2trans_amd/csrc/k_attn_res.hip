@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
 #pragma unroll
     for (int m = 0; m < TPW; ++m) {
       float v[4] = {ak[m][WA_KT][0], ak[m][WA_KT][1], ak[m][WA_KT][2], ak[m][WA_KT][3]};
-      store4(relw + ((long long)blockIdx.x * 10 + lr) * C + 16 * (mt0 + m) + 4 * g, v);
+      store4(relw + ((long long)gm.wi * 10 + lr) * C + 16 * (mt0 + m) + 4 * g, v);
     }
   }
   __syncthreads();                      // every wave is done with dO, q and P
@@ -394,12 +394,12 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
     }
   for (int idx = tid; idx < WA_NK * VEC; idx += NTHR) {
     const int key = idx / VEC, cv = idx % VEC;
-    store8(dkv_row(gqkv, win, (long long)blockIdx.x, gm.b, gm.wy, gm.wx, h, w, C, key) + C + cv * 8, load8(&VOUT[key][cv * 8]));
+    store8(dkv_row(gqkv, win, (long long)gm.wi, gm.b, gm.wy, gm.wx, h, w, C, key) + C + cv * 8, load8(&VOUT[key][cv * 8]));
   }
   __syncthreads();
   for (int idx = tid; idx < WA_NK * VEC; idx += NTHR) {
     const int key = idx / VEC, cv = idx % VEC;
-    store8(dkv_row(gqkv, win, (long long)blockIdx.x, gm.b, gm.wy, gm.wx, h, w, C, key) + cv * 8, load8(&KOUT[key][cv * 8]));
+    store8(dkv_row(gqkv, win, (long long)gm.wi, gm.b, gm.wy, gm.wx, h, w, C, key) + cv * 8, load8(&KOUT[key][cv * 8]));
   }
   for (int idx = tid; idx < 64 * VEC; idx += NTHR) {
     const int row = idx / VEC, cv = idx % VEC;

@@ -215,6 +215,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Workgroup i of a 1-D grid is dispatched to XCD i % 8 (round-robin).  Returns a LOGICAL index such that each XCD
+// owns one contiguous run of logical indices, so spatial neighbours (tiles / windows of the same image, which share
+// halo rows) sit behind ONE L2.  Identity when the grid is not a multiple of 8.
+__device__ __forceinline__ int xcd_block_index() {
+  const int n = gridDim.x, i = blockIdx.x;
+  return (n & 7) ? i : (i & 7) * (n >> 3) + (i >> 3);
+}
+
 // host-side launch check
 #define M2T_LAUNCH_CHECK()                                  \
   do {                                                      \

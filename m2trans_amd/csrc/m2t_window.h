@@ -11,6 +11,7 @@
 struct WinGeom {
   int h, w, nw, nh;
   int b, wy, wx;
+  int wi;                 // logical window index (XCD-aware, see xcd_block_index)
   __device__ __forceinline__ bool key_pixel(int key, long long& pix) const {
     const int kr = key / 10, kc = key - kr * 10;
     const int y = 8 * wy + kr - 1, x = 8 * wx + kc - 1;
@@ -41,7 +42,8 @@ __device__ __forceinline__ T* dkv_row(T* gqkv, T* win, long long wi, int b, int 
 __device__ __forceinline__ WinGeom make_geom(int h, int w) {
   WinGeom g;
   g.h = h; g.w = w; g.nw = w / 8; g.nh = h / 8;
-  const int wi = blockIdx.x;
+  const int wi = xcd_block_index();
+  g.wi = wi;
   g.wx = wi % g.nw;
   const int q = wi / g.nw;
   g.wy = q % g.nh;

@@ -44,7 +44,7 @@ KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these cate
     "final_conv_dgrad": "tail_bwd_fused_kernel (tail conv dgrad+wgrad, GELU', tail.3 dgrad+wgrad)",
 }
 MERGED = {"conv3x3_fwd+dgrad": ("conv3x3_fwd", "conv3x3_dgrad")}
-MERGED_KERNEL = {"conv3x3_fwd+dgrad": "conv3x3_c64_kernel (64->64 3x3 conv: forward and data gradient are the same kernel and tile shape)"}
+MERGED_KERNEL = {"conv3x3_fwd+dgrad": "conv3x3_c64_pipe_kernel (64->64 3x3 conv: forward and data gradient are the same kernel and tile shape)"}
 HBM_PEAK_GBS = 8000.0
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
 ALL_MASK = (1 << len(CATS)) - 1
