@@ -172,6 +172,10 @@ int m2t_eval_metrics(const float* sr, const float* hr, int B, int H, int W, int 
 int m2t_crop_patches(const unsigned char* lr_pool, const unsigned char* hr_pool, const long long* desc_host, int n,
                      int channels, int patch_size, int scale, float* lr_out, float* hr_out, void* stream);
 
+/* datas/benchmark.py:62-72 (`Benchmark.__getitem__`): top-left h x w crop of a uint8 HWC image [img_h,img_w,channels]
+ * resident in device memory -> float32 [channels,h,w] / 255, bit-identical to ndarray2tensor(...)/255. */
+int m2t_image_to_tensor(const unsigned char* img, int img_h, int img_w, int channels, int h, int w, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

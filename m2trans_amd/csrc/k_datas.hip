@@ -45,6 +45,17 @@ __global__ __launch_bounds__(256) void crop_patches_kernel(const uint8_t* __rest
   for (int c = 0; c < C; ++c) dst[(long long)c * (is_hr ? nh : nl)] = __fdiv_rn((float)src[c], 255.f);
 }
 
+// whole image (datas/benchmark.py:62-72): top-left h x w crop of a uint8 HWC image -> float32 CHW / 255
+__global__ __launch_bounds__(256) void image_to_tensor_kernel(const uint8_t* __restrict__ img, int img_w, int C, int h, int w,
+                                                              float* __restrict__ out) {
+  const long long n = (long long)h * w;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int y = (int)(i / w), x = (int)(i - (long long)y * w);
+    const uint8_t* src = img + ((long long)y * img_w + x) * C;
+    for (int c = 0; c < C; ++c) out[(long long)c * n + i] = __fdiv_rn((float)src[c], 255.f);
+  }
+}
+
 }  // namespace
 
 extern "C" int m2t_crop_patches(const unsigned char* lr_pool, const unsigned char* hr_pool, const long long* desc_host, int n,
@@ -71,5 +82,15 @@ extern "C" int m2t_crop_patches(const unsigned char* lr_pool, const unsigned cha
                                                                                       lr_out, hr_out);
     M2T_LAUNCH_CHECK();
   }
+  return 0;
+}
+
+extern "C" int m2t_image_to_tensor(const unsigned char* img, int img_h, int img_w, int channels, int h, int w, float* out, void* stream) {
+  if (!img || !out || channels < 1 || h < 1 || w < 1 || h > img_h || w > img_w)
+    return m2t_set_error(M2T_ERR_ARG, "m2t_image_to_tensor: bad argument (crop must fit the image)");
+  const long long n = (long long)h * w;
+  const int g = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  image_to_tensor_kernel<<<g, 256, 0, (hipStream_t)stream>>>(img, img_w, channels, h, w, out);
+  M2T_LAUNCH_CHECK();
   return 0;
 }

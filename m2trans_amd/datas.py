@@ -124,3 +124,55 @@ class US1K:
         order = torch.randperm(len(self), generator=generator).tolist() if shuffle else list(range(len(self)))
         for i in range(0, len(order), batch_size):
             yield self.batch(order[i:i + batch_size], rng)
+
+
+class Benchmark:
+    """datas/benchmark.py:17-72 with the images resident in HBM: `len()`, `ds[i] -> (lr [1,3,h,w], hr [1,3,h*s,w*s],
+    name)` float32 in [0,1] on the device (the reference's DataLoader adds the batch dimension of 1), HR cropped to the
+    LR size x scale, bit-identical to the reference's tensors.  `images`: optional list of (hr, lr, name) uint8 HWC
+    arrays instead of the folders."""
+
+    def __init__(self, HR_folder: Optional[str] = None, LR_folder: Optional[str] = None, scale: int = 2, colors: int = 3,
+                 device="cuda", images=None):
+        if colors != 3:
+            raise _lib.M2TError("Benchmark (MI355X build): only colors=3 is built (configs/M2Trans_x4.yml:5)")
+        self.scale, self.colors, self.device = scale, colors, torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.M2TError("Benchmark (MI355X build) keeps its images in HBM: a HIP device is required")
+        if images is None:
+            from PIL import Image                                             # imageio pilmode="RGB" == PIL convert("RGB")
+            images = []
+            for tag in os.listdir(HR_folder):                                 # datas/benchmark.py:33-43
+                ext = ".png" if "US1K_23" in HR_folder else ".jpg"
+                lr_name = os.path.join(LR_folder, f"X{scale}", tag.replace(ext, f"x{scale}{ext}"))
+                hr = np.asarray(Image.open(os.path.join(HR_folder, tag)).convert("RGB"))
+                lr = np.asarray(Image.open(lr_name).convert("RGB"))
+                images.append((hr, lr, tag))
+        self.img_name = [n for _, _, n in images]
+        self._items = []
+        for hr, lr, _ in images:
+            for a in (hr, lr):
+                if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != colors:
+                    raise _lib.M2TError(f"images must be uint8 [H,W,{colors}], got {a.dtype} {a.shape}")
+            if hr.shape[0] < lr.shape[0] * scale or hr.shape[1] < lr.shape[1] * scale:
+                raise _lib.M2TError(f"HR image {hr.shape} is smaller than LR {lr.shape} x {scale}")
+            self._items.append((torch.from_numpy(np.ascontiguousarray(hr)).to(self.device), torch.from_numpy(np.ascontiguousarray(lr)).to(self.device)))
+
+    def __len__(self) -> int:
+        return len(self._items)
+
+    def __getitem__(self, idx: int):
+        hr_u8, lr_u8 = self._items[idx]
+        lib = _lib.load()
+        lh, lw = lr_u8.shape[0], lr_u8.shape[1]
+        lr = torch.empty(1, self.colors, lh, lw, dtype=torch.float32, device=self.device)
+        hr = torch.empty(1, self.colors, lh * self.scale, lw * self.scale, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.m2t_image_to_tensor(_lib.ptr(lr_u8), lh, lw, self.colors, lh, lw, _lib.ptr(lr), _lib.stream_ptr()), "m2t_image_to_tensor")
+            _lib.check(lib.m2t_image_to_tensor(_lib.ptr(hr_u8), hr_u8.shape[0], hr_u8.shape[1], self.colors, lh * self.scale, lw * self.scale,
+                                               _lib.ptr(hr), _lib.stream_ptr()), "m2t_image_to_tensor")
+        return lr, hr, self.img_name[idx]
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]

@@ -460,3 +460,16 @@ def closed_form_u8_image(h: int, w: int, c: int = 3, phase: float = 0.0):
     import numpy as np
     v = closed_form_image(1, c, h, w, phase=phase, dtype=torch.float64)[0]
     return np.ascontiguousarray((v * 255.0).round().clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy())
+
+
+def benchmark_item(lr, hr, scale: int):
+    """datas/benchmark.py:62-72 `Benchmark.__getitem__` for one uint8 HWC pair: HR cropped to the LR size x scale,
+    HWC -> CHW float32, / 255."""
+    import numpy as np
+    lr_h, lr_w, _ = lr.shape
+    hr = hr[0:lr_h * scale, 0:lr_w * scale, :]
+
+    def to_tensor(a):
+        return torch.from_numpy(np.ascontiguousarray(a.transpose((2, 0, 1)))).float() / 255.0
+
+    return to_tensor(lr), to_tensor(hr)

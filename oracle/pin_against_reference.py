@@ -243,9 +243,23 @@ def main():
                         lr_first=ref_out[0][0].numpy(), hr_corner=ref_out[5][1][:, :8, :8].numpy())
     report.append(f"crop_patch: 16 seeded draws bit-equal to datas/us1k.py ({len(seen)} of 8 flip/rot combinations)")
 
+    # ---- 9. evaluation items (datas/benchmark.py:62-72); the object is built without __init__ (which reads files
+    # through imageio), only __getitem__ runs ------------------------------------------------------------------
+    bm = importlib.import_module("datas.benchmark")
+    ds = object.__new__(bm.Benchmark)
+    lr_b = O.closed_form_u8_image(21, 35, phase=1.1)
+    hr_b = O.closed_form_u8_image(21 * 3 + 2, 35 * 3 + 1, phase=1.1)       # HR slightly larger: the crop matters
+    ds.lr_images, ds.hr_images, ds.img_name, ds.scale = [lr_b], [hr_b], ["a.jpg"], 3
+    r_lr, r_hr, r_name = ds[0]
+    o_lr, o_hr = O.benchmark_item(lr_b, hr_b, 3)
+    assert torch.equal(r_lr, o_lr) and torch.equal(r_hr, o_hr) and r_name == "a.jpg"
+    np.savez_compressed(os.path.join(out_dir, "benchmark_item.npz"), lr_sum=float(r_lr.double().sum()),
+                        hr_sum=float(r_hr.double().sum()), hr_shape=np.array(r_hr.shape), hr_corner=r_hr[:, -4:, -4:].numpy())
+    report.append("Benchmark.__getitem__ bit-equal to datas/benchmark.py (HR crop to LR x scale)")
+
     with open(os.path.join(HERE, "PINNING.txt"), "w") as f:
         f.write("oracle/m2trans_oracle.py checked against /root/reference "
-                "(models/M2Trans_network.py, utils.py, datas/us1k.py) by oracle/pin_against_reference.py\n")
+                "(models/M2Trans_network.py, utils.py, datas/us1k.py, datas/benchmark.py) by oracle/pin_against_reference.py\n")
         f.write("\n".join(report) + "\n")
     print("\n".join(report))
 

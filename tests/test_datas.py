@@ -94,3 +94,39 @@ def test_train_step_runs_on_device_batches():
     for lr, hr in ds.loader(2, generator=torch.Generator().manual_seed(0), rng=random.Random(0)):
         losses.append(float(ts.step(lr, hr)))
     assert len(losses) == 2 and all(np.isfinite(losses))
+
+
+def test_benchmark_item_oracle_reproduces_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "benchmark_item.npz"))
+    lr_b = O.closed_form_u8_image(21, 35, phase=1.1)
+    hr_b = O.closed_form_u8_image(21 * 3 + 2, 35 * 3 + 1, phase=1.1)
+    lr, hr = O.benchmark_item(lr_b, hr_b, 3)
+    assert tuple(hr.shape) == tuple(g["hr_shape"]) == (3, 63, 105)
+    assert float(lr.double().sum()) == float(g["lr_sum"]) and float(hr.double().sum()) == float(g["hr_sum"])
+    assert np.array_equal(hr[:, -4:, -4:].numpy(), g["hr_corner"])
+
+
+@pytest.mark.gpu
+def test_device_benchmark_items_bit_identical_and_eval_loop():
+    """datas/benchmark.py items on the device, then the whole test.py:77-122 loop (model + PSNR / SSIM) fed by them."""
+    import types
+    from m2trans_amd import _lib
+    from m2trans_amd.M2Trans_network import create_model
+    from m2trans_amd.datas import Benchmark
+    from m2trans_amd.metrics import evaluate
+    scale = 3
+    imgs = [(O.closed_form_u8_image(h * scale + dh, w * scale + dw, phase=0.3 * i), O.closed_form_u8_image(h, w, phase=0.3 * i), f"{i}.jpg")
+            for i, (h, w, dh, dw) in enumerate([(21, 35, 2, 1), (40, 33, 0, 0), (34, 34, 1, 2)])]
+    ds = Benchmark(scale=scale, images=imgs)
+    assert len(ds) == 3
+    for i, (hr_u8, lr_u8, name) in enumerate(imgs):
+        lr, hr, nm = ds[i]
+        a, b = O.benchmark_item(lr_u8, hr_u8, scale)
+        assert nm == name and torch.equal(lr[0].cpu(), a) and torch.equal(hr[0].cpu(), b)
+    args = types.SimpleNamespace(n_feats=64, scale=scale, rgb_range=1.0, n_blocks=1, colors=3, compute_dtype="bf16")
+    torch.manual_seed(11)
+    model = create_model(args).cuda().eval()
+    psnr, ssim = evaluate(model, ((lr, hr) for lr, hr, _ in ds), scale)
+    assert np.isfinite(psnr) and 0.0 < ssim <= 1.0
+    with pytest.raises(_lib.M2TError):
+        Benchmark(scale=scale, images=[(imgs[0][1], imgs[0][0], "swapped.jpg")])      # HR smaller than LR x scale
