@@ -55,8 +55,8 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  * tests/test_gpu_model.py).  Defaults in brackets.
  *   "side_stream"       [1] parameter-gradient kernels of m2t_backward on a plan-owned second stream
  *   "gated_side"        [1] release a block's side-stream work only after its LDS-hungry attention launches
- *   "gate_branch"       [0] branch index (3..0) after whose attention launch the gate opens (2: 0.5 % faster, but the
- *                           C = 64 / C = 16 attention kernels then share the CUs with weight-gradient GEMMs)
+ *   "gate_branch"       [2] branch index (3..0) after whose attention launch the gate opens (2 = behind the two
+ *                           C = 256 launches: measured 1.2 % faster than 0 = behind all four, 2.7 % faster than 3)
  *   "tail_wgrad_main"   [1] tail weight gradients on the caller's stream (they are HBM-bound like their neighbours)
  *   "fused_tail_bwd"    [1] bf16 x4: one fused kernel for the high-resolution half of the tail backward
  *   "resident_attn_bwd" [1] bf16: whole-window-resident / wave-per-window attention backward kernels

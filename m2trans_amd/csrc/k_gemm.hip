@@ -506,8 +506,12 @@ wgrad_tn_fast_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ X, 
   __shared__ __attribute__((aligned(16))) T Xs[WG_BM][WG_LD];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
-  const long long mb = (long long)blockIdx.z * rows_per_slab;
+  // 1-D grid, XCD-aware: the tn x tk tiles of one slab read the same rows of G and X -- keep them behind one L2
+  const int tn = N / 64, tk = K / 64;
+  const int L = xcd_block_index();
+  const int slab = L / (tn * tk), rem = L - slab * (tn * tk);
+  const int n0 = (rem % tn) * 64, k0 = (rem / tn) * 64;
+  const long long mb = (long long)slab * rows_per_slab;
   const int nst = (int)((min(M, mb + rows_per_slab) - mb) / WG_BM);       // M and rows_per_slab are multiples of 128
   f32x4 acc[4];
 #pragma unroll
@@ -551,7 +555,7 @@ wgrad_tn_fast_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ X, 
       }
     }
   }
-  float* out = slabs + (long long)blockIdx.z * N * K;
+  float* out = slabs + (long long)slab * N * K;
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -574,7 +578,7 @@ static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_
   nslab = (int)ceil_divll(a.M, rps);
   if (sizeof(T) == 2 && a.gmode == M2T_A_PLAIN && a.xmode == M2T_A_PLAIN && !a.bias_slabs && a.ldg > 0 && a.ldx > 0 &&
       a.N % 64 == 0 && a.K % 64 == 0 && a.M % WG_BM == 0) {
-    hipLaunchKernelGGL((wgrad_tn_fast_kernel<T>), dim3(tn, tk, nslab), dim3(256), 0, st, (const T*)a.G, a.ldg, (const T*)a.X, a.ldx,
+    hipLaunchKernelGGL((wgrad_tn_fast_kernel<T>), dim3(tn * tk * nslab), dim3(256), 0, st, (const T*)a.G, a.ldg, (const T*)a.X, a.ldx,
                        a.slabs, a.M, a.N, a.K, rps);
     M2T_LAUNCH_CHECK();
     *nslab_out = nslab;

@@ -102,8 +102,8 @@ struct m2t_plan {
   bool use_persistent_conv = false;  // bf16 conv3x3 with LDS-resident weights: bit-identical, measured a tie (see k_conv.hip)
   bool use_fused_tail_bwd = true;  // x4 bf16: k_tail_bwd.hip instead of four HR kernels
   bool tail_wgrad_main = true;     // tail weight gradients on the main stream (see m2t_backward)
-  int gate_branch = 0;             // 0: after ALL four attention launches of the block (2: after the two C = 256 ones only --
-                                   // 0.5 % faster, but the C = 64 / C = 16 attention kernels then run 2x slower under the side work)
+  int gate_branch = 2;             // 2: after the two C = 256 attention launches of the block (same-box A/B, 6 alternating
+                                   // runs: 6.17 ms against 6.24 for 0 = after all four, 6.34 for 3, 6.23 ungated)
   bool use_gated_side = true;      // see the side-stream schedule in m2t_backward
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
@@ -613,8 +613,8 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   // (k_attn_res.hip): any concurrent parameter-gradient kernel starves them until it has drained (measured:
   // 70 us instead of 25 us per launch); the C = 64 / C = 16 attention kernels run 2x slower next to a weight-
   // gradient GEMM.  So the block's side work is GATED behind the attention launch of branch `gate_branch`
-  // (default 0 = the last one): the conv / qkv weight gradients then run under the halo gather, the data-gradient
-  // GEMM, the norm backward and the next block's conv data gradient.  Each branch has its own gqkv / win / relw
+  // (default 2 = behind both C = 256 launches): the conv / qkv weight gradients then run under the halo gathers, the
+  // C = 64 / C = 16 attention (which lose less than the step gains), the data-gradient GEMMs and the norm backward.  Each branch has its own gqkv / win / relw
   // buffers, so the lag is harmless.
   const bool gated = p->use_gated_side && sd != st;
   const int gate = p->gate_branch;          // branch index after whose attention launch the block's side work is released
