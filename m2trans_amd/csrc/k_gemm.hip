@@ -28,8 +28,10 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __r
   __shared__ __attribute__((aligned(16))) T Ws[GEMM_BN][GEMM_BK + GEMM_PAD];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
-  const long long m0 = (long long)blockIdx.x * GEMM_BM;
-  const int n0 = blockIdx.y * GEMM_BN;
+  // 1-D grid, XCD-aware, column tile fastest: the workgroups that share a row strip of A are neighbours behind one L2
+  const int gy = (N + GEMM_BN - 1) / GEMM_BN, L = xcd_block_index();
+  const long long m0 = (long long)(L / gy) * GEMM_BM;
+  const int n0 = (L % gy) * GEMM_BN;
 
   f32x4 acc[2][4];
 #pragma unroll
@@ -150,8 +152,9 @@ gemm_nt_wide_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T
   T(*Ws)[BN][LD] = reinterpret_cast<T(*)[BN][LD]>(smem + sizeof(T) * 2 * BM * LD);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
-  const long long m0 = (long long)blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  const int gy = N / BN, L = xcd_block_index();         // 1-D grid, XCD-aware, column tile fastest (see gemm_nt_kernel)
+  const long long m0 = (long long)(L / gy) * BM;
+  const int n0 = (L % gy) * BN;
   f32x4 acc[MT][8];
 #pragma unroll
   for (int a = 0; a < MT; ++a)
@@ -226,7 +229,7 @@ static int launch_gemm_nt_wide(const m2t_gemm_args& a, hipStream_t st) {
     if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
     attr_set = true;
   }
-  dim3 grid((unsigned)ceil_divll(a.M, BM), (unsigned)(a.N / 128));
+  dim3 grid((unsigned)(ceil_divll(a.M, BM) * (a.N / 128)));
   hipLaunchKernelGGL((gemm_nt_wide_kernel<T, BM>), grid, dim3(256), sh, st, (const T*)a.A, a.lda, (const T*)a.W, (T*)a.Y, a.ldy,
                      a.M, a.N, a.K);
   M2T_LAUNCH_CHECK();
@@ -242,7 +245,7 @@ static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStr
     if (sizeof(T) == 2 && blocks128 >= 512) return launch_gemm_nt_wide<T, 128>(a, st);
     return launch_gemm_nt_wide<T, 64>(a, st);
   }
-  dim3 grid((unsigned)ceil_divll(a.M, GEMM_BM), (unsigned)ceil_div(a.N, GEMM_BN));
+  dim3 grid((unsigned)(ceil_divll(a.M, GEMM_BM) * ceil_div(a.N, GEMM_BN)));
   ShufGeom sg{a.H, a.Wd, a.r, a.C, a.halo_win, a.M};
 #define GO(AM, EM)                                                                                              \
   hipLaunchKernelGGL((gemm_nt_kernel<T, AM, EM>), grid, dim3(256), 0, st, (const T*)a.A, a.lda, (const T*)a.W, \

@@ -297,70 +297,81 @@ int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float
 // x, xc: [B][H][W][64];  xin: [B][H][W][16];  d: [B][H/S][W/S][16*4^L]
 // one thread = one (2^L)^2 pixel block x 4 channels
 // =======================================================================================
-template <typename T, int L>
+// CH channels per thread: 4 (fp32 parity path: 16-byte accesses) or 8 (bf16: 16-byte accesses instead of 8-byte ones --
+// the kernel is bound by memory INSTRUCTIONS, not bytes: 2.9 TB/s with 8-byte accesses)
+template <int CH, typename T> __device__ __forceinline__ void load_ch(const T* p, float (&o)[CH]) {
+  if constexpr (CH == 4) load4(p, o); else load8f(p, o);
+}
+template <int CH, typename T> __device__ __forceinline__ void store_ch(T* p, const float (&o)[CH]) {
+  if constexpr (CH == 4) store4(p, o); else store8f(p, o);
+}
+template <typename T, int L, int CH>
 __global__ void __launch_bounds__(256) branch_prep_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const T* __restrict__ xc,
                                                           int k, T* __restrict__ xin, T* __restrict__ d, int B, int H, int W) {
-  constexpr int S = Haar<L>::S, N = Haar<L>::N;
+  constexpr int S = Haar<L>::S, N = Haar<L>::N, G = 16 / CH;
   const int hb = H / S, wb = W / S;
   const long long npix = (long long)B * H * W;
-  const long long total = (long long)B * hb * wb * 4;
+  const long long total = (long long)B * hb * wb * G;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
-    const int g = (int)(t & 3);
-    long long r = t >> 2;
+    const int g = (int)(t % G);
+    long long r = t / G;
     const int j = (int)(r % wb); r /= wb;
     const int i = (int)(r % hb);
     const int b = (int)(r / hb);
-    float mu[4], rs[4];
+    float mu[CH], rs[CH];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { mu[c] = mean[b * 64 + k * 16 + g * 4 + c]; rs[c] = rstd[b * 64 + k * 16 + g * 4 + c]; }
-    float v[4][S][S];
+    for (int c = 0; c < CH; ++c) { mu[c] = mean[b * 64 + k * 16 + g * CH + c]; rs[c] = rstd[b * 64 + k * 16 + g * CH + c]; }
+    float v[CH][S][S];
 #pragma unroll
     for (int y = 0; y < S; ++y)
 #pragma unroll
       for (int xx = 0; xx < S; ++xx) {
         const long long pix = ((long long)b * H + (i * S + y)) * W + (j * S + xx);
-        float q[4];
-        load4(x + ((long long)k * npix + pix) * 16 + g * 4, q);            // P64: chunk k is a dense plane
+        float q[CH];
+        load_ch<CH>(x + ((long long)k * npix + pix) * 16 + g * CH, q);            // P64: chunk k is a dense plane
 #pragma unroll
-        for (int c = 0; c < 4; ++c) q[c] = (q[c] - mu[c]) * rs[c];
+        for (int c = 0; c < CH; ++c) q[c] = (q[c] - mu[c]) * rs[c];
         if (k > 0) {
-          float p[4];
-          load4(xc + ((long long)(k - 1) * npix + pix) * 16 + g * 4, p);
+          float p[CH];
+          load_ch<CH>(xc + ((long long)(k - 1) * npix + pix) * 16 + g * CH, p);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) q[c] = (q[c] + p[c]) * 0.5f;
+          for (int c = 0; c < CH; ++c) q[c] = (q[c] + p[c]) * 0.5f;
         }
         if (L > 0) {
           // keep the stored (rounded) value and the transformed value identical
-          store4(xin + pix * 16 + g * 4, q);
+          store_ch<CH>(xin + pix * 16 + g * CH, q);
           if (sizeof(T) == 2) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) q[c] = to_f(from_f<T>(q[c]));
+            for (int c = 0; c < CH; ++c) q[c] = to_f(from_f<T>(q[c]));
           }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c][y][xx] = q[c];
+        for (int c = 0; c < CH; ++c) v[c][y][xx] = q[c];
       }
-    float o[4][N];
+    float o[CH][N];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) Haar<L>::fwd(v[c], o[c]);
-    T* dp = d + (((long long)b * hb + i) * wb + j) * (16 * N) + g * 4;
+    for (int c = 0; c < CH; ++c) Haar<L>::fwd(v[c], o[c]);
+    T* dp = d + (((long long)b * hb + i) * wb + j) * (16 * N) + g * CH;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-      float q[4] = {o[0][n], o[1][n], o[2][n], o[3][n]};
-      store4(dp + n * 16, q);
+      float q[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) q[c] = o[c][n];
+      store_ch<CH>(dp + n * 16, q);
     }
   }
 }
 template <typename T>
 int launch_branch_prep_t(int L, const T* x, const float* mean, const float* rstd, const T* xc, int k, T* xin, T* d,
                          int B, int H, int W, hipStream_t st) {
+  constexpr int CH = sizeof(T) == 2 ? 8 : 4;
   const int S = 1 << L;
-  const int g = grid_for((long long)B * (H / S) * (W / S) * 4);
-  if (L == 0) hipLaunchKernelGGL((branch_prep_kernel<T, 0>), dim3(g), dim3(256), 0, st, x, mean, rstd, xc, k, xin, d, B, H, W);
-  else if (L == 1) hipLaunchKernelGGL((branch_prep_kernel<T, 1>), dim3(g), dim3(256), 0, st, x, mean, rstd, xc, k, xin, d, B, H, W);
-  else hipLaunchKernelGGL((branch_prep_kernel<T, 2>), dim3(g), dim3(256), 0, st, x, mean, rstd, xc, k, xin, d, B, H, W);
+  const int g = grid_for((long long)B * (H / S) * (W / S) * (16 / CH));
+  if (L == 0) hipLaunchKernelGGL((branch_prep_kernel<T, 0, CH>), dim3(g), dim3(256), 0, st, x, mean, rstd, xc, k, xin, d, B, H, W);
+  else if (L == 1) hipLaunchKernelGGL((branch_prep_kernel<T, 1, CH>), dim3(g), dim3(256), 0, st, x, mean, rstd, xc, k, xin, d, B, H, W);
+  else hipLaunchKernelGGL((branch_prep_kernel<T, 2, CH>), dim3(g), dim3(256), 0, st, x, mean, rstd, xc, k, xin, d, B, H, W);
   M2T_LAUNCH_CHECK();
   return 0;
 }
@@ -437,51 +448,51 @@ int launch_branch_post_bwd(int dt, int L, const void* gxc, int k, void* ga, int 
 // and for k = 0 (L = 0):   g_n[chunk 0] = g_d + g_xc[chunk 0]
 // g_n, g_xc: P64 ([4][B*H*W][16])
 // =======================================================================================
-template <typename T, int L>
+template <typename T, int L, int CH>
 __global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restrict__ gd, T* __restrict__ gxc,
                                                               T* __restrict__ gn, int k, int B, int H, int W) {
-  constexpr int S = Haar<L>::S, N = Haar<L>::N;
+  constexpr int S = Haar<L>::S, N = Haar<L>::N, G = 16 / CH;
   const int hb = H / S, wb = W / S;
   const long long npix = (long long)B * H * W;          // gxc, gn are P64
-  const long long total = (long long)B * hb * wb * 4;
+  const long long total = (long long)B * hb * wb * G;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
-    const int g = (int)(t & 3);
-    long long r = t >> 2;
+    const int g = (int)(t % G);
+    long long r = t / G;
     const int j = (int)(r % wb); r /= wb;
     const int i = (int)(r % hb);
     const int b = (int)(r / hb);
-    float o[4][N];
-    const T* sp = gd + (((long long)b * hb + i) * wb + j) * (16 * N) + g * 4;
+    float o[CH][N];
+    const T* sp = gd + (((long long)b * hb + i) * wb + j) * (16 * N) + g * CH;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
-      float q[4];
-      load4(sp + n * 16, q);
+      float q[CH];
+      load_ch<CH>(sp + n * 16, q);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) o[c][n] = q[c];
+      for (int c = 0; c < CH; ++c) o[c][n] = q[c];
     }
-    float v[4][S][S];
+    float v[CH][S][S];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) Haar<L>::inv(o[c], v[c]);
+    for (int c = 0; c < CH; ++c) Haar<L>::inv(o[c], v[c]);
 #pragma unroll
     for (int y = 0; y < S; ++y)
 #pragma unroll
       for (int xx = 0; xx < S; ++xx) {
         const long long pix = ((long long)b * H + (i * S + y)) * W + (j * S + xx);
-        float p[4];
-        load4(gxc + ((long long)k * npix + pix) * 16 + g * 4, p);
-        float q[4];
+        float p[CH];
+        load_ch<CH>(gxc + ((long long)k * npix + pix) * 16 + g * CH, p);
+        float q[CH];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) q[c] = v[c][y][xx] + p[c];
+        for (int c = 0; c < CH; ++c) q[c] = v[c][y][xx] + p[c];
         if (k == 0) {
-          store4(gn + pix * 16 + g * 4, q);
+          store_ch<CH>(gn + pix * 16 + g * CH, q);
         } else {
-          float pp[4];
-          load4(gxc + ((long long)(k - 1) * npix + pix) * 16 + g * 4, pp);
+          float pp[CH];
+          load_ch<CH>(gxc + ((long long)(k - 1) * npix + pix) * 16 + g * CH, pp);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { q[c] *= 0.5f; pp[c] += q[c]; }
-          store4(gn + ((long long)k * npix + pix) * 16 + g * 4, q);
-          store4(gxc + ((long long)(k - 1) * npix + pix) * 16 + g * 4, pp);
+          for (int c = 0; c < CH; ++c) { q[c] *= 0.5f; pp[c] += q[c]; }
+          store_ch<CH>(gn + ((long long)k * npix + pix) * 16 + g * CH, q);
+          store_ch<CH>(gxc + ((long long)(k - 1) * npix + pix) * 16 + g * CH, pp);
         }
       }
   }
@@ -489,10 +500,11 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restric
 int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, int k, int B, int H, int W,
                            hipStream_t st) {
   const int S = 1 << L;
-  const int g = grid_for((long long)B * (H / S) * (W / S) * 4);
-#define BP(T_, L_) hipLaunchKernelGGL((branch_prep_bwd_kernel<T_, L_>), dim3(g), dim3(256), 0, st, (const T_*)gd, (T_*)gxc, (T_*)gn, k, B, H, W)
-  if (dt == M2T_F32) { if (L == 0) BP(float, 0); else if (L == 1) BP(float, 1); else BP(float, 2); }
-  else { if (L == 0) BP(bf16_t, 0); else if (L == 1) BP(bf16_t, 1); else BP(bf16_t, 2); }
+  const int CH = dt == M2T_F32 ? 4 : 8;
+  const int g = grid_for((long long)B * (H / S) * (W / S) * (16 / CH));
+#define BP(T_, L_, CH_) hipLaunchKernelGGL((branch_prep_bwd_kernel<T_, L_, CH_>), dim3(g), dim3(256), 0, st, (const T_*)gd, (T_*)gxc, (T_*)gn, k, B, H, W)
+  if (dt == M2T_F32) { if (L == 0) BP(float, 0, 4); else if (L == 1) BP(float, 1, 4); else BP(float, 2, 4); }
+  else { if (L == 0) BP(bf16_t, 0, 8); else if (L == 1) BP(bf16_t, 1, 8); else BP(bf16_t, 2, 8); }
 #undef BP
   M2T_LAUNCH_CHECK();
   return 0;
