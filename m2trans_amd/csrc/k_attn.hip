@@ -556,15 +556,14 @@ __global__ void __launch_bounds__(256) halo_gather_kernel(const T* __restrict__ 
                                                           int w, int C) {
   const int nv = 2 * C / 8;
   const int nh = h / 8, nw = w / 8;
-  const long long total = (long long)B * nh * nw * 28 * nv;       // 28 border pixels per window
-  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
-       t += (long long)gridDim.x * blockDim.x) {
-    const int cv = (int)(t % nv);
-    long long r = t / nv;
-    const int bp = (int)(r % 28); r /= 28;
-    const int wx0 = (int)(r % nw); r /= nw;
-    const int wy0 = (int)(r % nh);
-    const int b = (int)(r / nh);
+  const int total = B * nh * nw * 28 * nv;       // 28 border pixels per window; < 2^31 (checked by the launcher):
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {   // 32-bit index math --
+    const int cv = t % nv;                        // five 64-bit divisions per thread cost more than its three 16-byte accesses
+    int r = t / nv;
+    const int bp = r % 28; r /= 28;
+    const int wx0 = r % nw; r /= nw;
+    const int wy0 = r % nh;
+    const int b = r / nh;
     // border pixel bp of the 8x8 window: rows 0 and 7 (8 each), then columns 0 and 7 of rows 1..6 (6 each)
     int py, px;
     if (bp < 8) { py = 0; px = bp; }
@@ -673,6 +672,7 @@ static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const floa
   M2T_LAUNCH_CHECK();
   if (gather) {
     const long long total = (long long)B * (h / 8) * (w / 8) * 28 * (2 * C / 8);
+    if (total >= (1LL << 31)) return m2t_set_error(-2, "halo_gather: too many border vectors for 32-bit indexing");
     const int g = (int)std::min<long long>(ceil_divll(total, 256), 4096);
     hipLaunchKernelGGL(halo_gather_kernel<T>, dim3(g), dim3(256), 0, st, win, gqkv, B, h, w, C);
     M2T_LAUNCH_CHECK();

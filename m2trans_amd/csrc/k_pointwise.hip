@@ -312,14 +312,13 @@ __global__ void __launch_bounds__(256) branch_prep_kernel(const T* __restrict__ 
   constexpr int S = Haar<L>::S, N = Haar<L>::N, G = 16 / CH;
   const int hb = H / S, wb = W / S;
   const long long npix = (long long)B * H * W;
-  const long long total = (long long)B * hb * wb * G;
-  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
-       t += (long long)gridDim.x * blockDim.x) {
-    const int g = (int)(t % G);
-    long long r = t / G;
-    const int j = (int)(r % wb); r /= wb;
-    const int i = (int)(r % hb);
-    const int b = (int)(r / hb);
+  const int total = B * hb * wb * G;              // < 2^31: 32-bit index math (64-bit division is a software loop)
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int g = t % G;
+    int r = t / G;
+    const int j = r % wb; r /= wb;
+    const int i = r % hb;
+    const int b = r / hb;
     float mu[CH], rs[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) { mu[c] = mean[b * 64 + k * 16 + g * CH + c]; rs[c] = rstd[b * 64 + k * 16 + g * CH + c]; }
@@ -367,6 +366,7 @@ template <typename T>
 int launch_branch_prep_t(int L, const T* x, const float* mean, const float* rstd, const T* xc, int k, T* xin, T* d,
                          int B, int H, int W, hipStream_t st) {
   constexpr int CH = sizeof(T) == 2 ? 8 : 4;
+  if ((long long)B * H * W * 4 >= (1LL << 31)) return m2t_set_error(-2, "branch_prep: B*H*W too large for 32-bit indexing");
   const int S = 1 << L;
   const int g = grid_for((long long)B * (H / S) * (W / S) * (16 / CH));
   if (L == 0) hipLaunchKernelGGL((branch_prep_kernel<T, 0, CH>), dim3(g), dim3(256), 0, st, x, mean, rstd, xc, k, xin, d, B, H, W);
@@ -454,14 +454,13 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restric
   constexpr int S = Haar<L>::S, N = Haar<L>::N, G = 16 / CH;
   const int hb = H / S, wb = W / S;
   const long long npix = (long long)B * H * W;          // gxc, gn are P64
-  const long long total = (long long)B * hb * wb * G;
-  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
-       t += (long long)gridDim.x * blockDim.x) {
-    const int g = (int)(t % G);
-    long long r = t / G;
-    const int j = (int)(r % wb); r /= wb;
-    const int i = (int)(r % hb);
-    const int b = (int)(r / hb);
+  const int total = B * hb * wb * G;              // < 2^31: 32-bit index math (64-bit division is a software loop)
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int g = t % G;
+    int r = t / G;
+    const int j = r % wb; r /= wb;
+    const int i = r % hb;
+    const int b = r / hb;
     float o[CH][N];
     const T* sp = gd + (((long long)b * hb + i) * wb + j) * (16 * N) + g * CH;
 #pragma unroll
@@ -499,6 +498,7 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restric
 }
 int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, int k, int B, int H, int W,
                            hipStream_t st) {
+  if ((long long)B * H * W * 4 >= (1LL << 31)) return m2t_set_error(-2, "branch_prep_bwd: B*H*W too large for 32-bit indexing");
   const int S = 1 << L;
   const int CH = dt == M2T_F32 ? 4 : 8;
   const int g = grid_for((long long)B * (H / S) * (W / S) * (16 / CH));
@@ -584,12 +584,11 @@ __global__ void __launch_bounds__(256) instnorm_bwd_apply_kernel(const T* __rest
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ s, const T* __restrict__ gres,
                                                                  T* __restrict__ gx, int B, int P) {
-  const long long total = (long long)B * P * 8;
-  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
-       t += (long long)gridDim.x * blockDim.x) {
-    const int cgp = (int)(t & 7);
-    const long long pix = t >> 3;
-    const int b = (int)(pix / P);
+  const int total = B * P * 8;                    // < 2^31 (checked by the launcher): 32-bit index math
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int cgp = t & 7;
+    const int pix = t >> 3;
+    const int b = pix / P;
     float g[8], v[8], r[8];
     const long long o64 = p64((long long)B * P, pix, cgp * 8);     // all four tensors are P64
     load8f(gn + o64, g);
@@ -607,6 +606,7 @@ __global__ void __launch_bounds__(256) instnorm_bwd_apply_kernel(const T* __rest
 }
 int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean, const float* rstd, const void* gres,
                         void* gx, float* part, float* s, int B, int P, hipStream_t st) {
+  if ((long long)B * P * 8 >= (1LL << 31)) return m2t_set_error(-2, "instnorm_bwd: B*P too large for 32-bit indexing");
   const int nsplit = M2T_NORM_SPLIT;
   if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_red1_kernel<float>, dim3(nsplit, B), dim3(256), 0, st, (const float*)gn, (const float*)x, mean, rstd, part, P, nsplit);
   else hipLaunchKernelGGL(instnorm_bwd_red1_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, part, P, nsplit);
