@@ -751,8 +751,11 @@ __global__ void __launch_bounds__(256) final_conv_fwd_kernel(const T* __restrict
       }
     }
   };
-  if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
-  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  // tiles are dealt round-robin over LOGICAL workgroup indices (XCD-aware): in every round an XCD owns a contiguous
+  // run of tiles, so horizontally adjacent tiles share their halo columns in one L2
+  const int lb = xcd_block_index();
+  if ((long long)lb < ntiles) fetch(lb);
+  for (long long t = lb; t < ntiles; t += gridDim.x) {
     const int x0 = (int)(t % tw) * FC_T;
     const long long q = t / tw;
     const int y0 = (int)(q % th) * FC_T;

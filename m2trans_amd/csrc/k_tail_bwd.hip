@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
   const long long ntiles = (long long)a.B * th * tw;
   const long long hw = (long long)H * W;
   // tiles are dealt round-robin (tile = block + i * grid): border tiles, which cost more, spread over all workgroups
-  const long long t0 = blockIdx.x, tstep = gridDim.x, t1 = ntiles;
+  // (LOGICAL workgroup index, XCD-aware: in every round an XCD owns a contiguous run of tiles -> halo columns shared in one L2)
+  const long long t0 = xcd_block_index(), tstep = gridDim.x, t1 = ntiles;
 
   for (int i = tid; i < 64 * 32; i += 512) {
     const int ic = i >> 5, n = i & 31;
