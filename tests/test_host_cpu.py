@@ -267,3 +267,25 @@ def test_checkpoint_round_trip_reference_format():
     assert torch.equal(m2.flat_params, m.flat_params)
     assert torch.equal(fs2.exp_avg, fs.exp_avg) and torch.equal(fs2.exp_avg_sq, fs.exp_avg_sq)
     assert fs2.step_count == 7 and fs2.lr == 5e-5
+
+
+def test_eval_and_data_entry_points_validate_arguments_without_a_gpu():
+    """m2t_eval_metrics / m2t_crop_patches / m2t_image_to_tensor reject bad arguments before any launch (so this runs on
+    the CPU box): sizes, descriptors out of the image, crops larger than the image."""
+    import ctypes as C
+    import numpy as np
+    from m2trans_amd import _lib
+    L = _lib.load()
+    assert L.m2t_eval_metrics_scratch_bytes(1, 8, 8, 4) == 0                      # nothing left after the border crop
+    assert L.m2t_eval_metrics_scratch_bytes(2, 64, 64, 4) == 8 * 2 * (64 + 2 * 2)  # 64 MSE chunks + 2x2 SSIM tiles per image
+    one = C.c_void_p(16)                                                          # never dereferenced: the checks come first
+    assert L.m2t_eval_metrics(one, one, 1, 8, 8, 4, 1.0, None, one, one, None) == -2
+    assert b"m2t_eval_metrics" in L.m2t_last_error_string()
+    desc = np.array([[0, 0, 53, 212, 50, 0, 0, 37]], dtype=np.int64)              # lx + 12 > 53
+    assert L.m2t_crop_patches(one, one, desc.ctypes.data_as(C.c_void_p), 1, 3, 48, 4, one, one, None) == -2
+    assert b"descriptor out of range" in L.m2t_last_error_string()
+    desc[0, 4] = 0; desc[0, 6] = 8                                                # unknown flag bit
+    assert L.m2t_crop_patches(one, one, desc.ctypes.data_as(C.c_void_p), 1, 3, 48, 4, one, one, None) == -2
+    assert L.m2t_crop_patches(one, one, desc.ctypes.data_as(C.c_void_p), 1, 3, 50, 4, one, one, None) == -2   # 50 % 4 != 0
+    assert L.m2t_image_to_tensor(one, 20, 30, 3, 21, 30, one, None) == -2         # crop taller than the image
+    assert b"m2t_image_to_tensor" in L.m2t_last_error_string()
