@@ -210,7 +210,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "train-step HR patches/sec at 128x128 LR x4",
+            "metric": f"train-step HR patches/sec at {args.lr_size}x{args.lr_size} LR x{args.scale}",
             "value": round(world * B * args.steps / dt, 3),
             "unit": "HR patches/s",
             "n_gpus": world,
