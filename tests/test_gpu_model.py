@@ -336,3 +336,25 @@ def test_training_drift_psnr_vs_oracle():
             ps = O.psnr_y(model(lr_v.cuda()).cpu(), hr_v, scale)
         print(f"training drift {dt}: PSNR {ps:.4f} dB vs oracle {ps_o:.4f} dB (untrained {ps_0:.4f})")
         assert abs(ps - ps_o) <= tol, (dt, ps, ps_o)
+
+
+def test_training_is_bitwise_reproducible_with_the_two_stream_schedule():
+    """No atomics anywhere and every cross-stream hand-over is an event: two runs of the same six bf16 steps (full
+    depth, 128x128, side stream + gates + deferred reductions live) must end with bit-identical parameters and Adam
+    state.  A missing dependency between the two streams shows up here as a run-to-run difference."""
+    from m2trans_amd.train_step import TrainStep
+    scale, nb, B, H, W = 4, 8, 4, 128, 128
+    finals = []
+    for run in range(2):
+        model, _ = build_model(scale, nb, "bf16")
+        ts = TrainStep(model, lr=1e-4, lambda_l1=1.0, world_size=1)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):            # a non-default caller stream, like bench.py
+            for s in range(6):
+                x = O.closed_form_image(B, 3, H, W, phase=0.2 * s).cuda()
+                hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.5 + 0.2 * s).cuda()
+                loss = ts.step(x, hr)
+            side.synchronize()
+        finals.append((float(loss), model.flat_params.detach().clone(), ts.exp_avg.clone(), ts.exp_avg_sq.clone()))
+    (la, pa, ma, va), (lb, pb, mb, vb) = finals
+    assert la == lb and torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
