@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--force-comm-path", action="store_true", help="issue the gradient collectives even with one rank (needs an initialised process group)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=INT", help="m2t_set_option on the plan (experiments)")
     ap.add_argument("--gate-branch", type=int, default=None, help="side-stream gate position (experiment)")
-    ap.add_argument("--tail-wgrad-side", action="store_true", help="tail weight gradients on the side stream (experiment)")
+    ap.add_argument("--tail-wgrad-main", action="store_true", help="tail weight gradients on the main stream (experiment; default: side stream)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the whole backward on one stream")
     ap.add_argument("--debug-skip-side", action="store_true", help="TIMING EXPERIMENT: skip all parameter-gradient kernels (wrong results)")
     ap.add_argument("--semantic-loss", action="store_true",
@@ -160,9 +160,9 @@ def main():
     if args.gate_branch is not None:
         plan = model._plan_for(batches[0][0])
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"gate_branch", args.gate_branch), "m2t_set_option")
-    if args.tail_wgrad_side:
+    if args.tail_wgrad_main:
         plan = model._plan_for(batches[0][0])
-        _lib.check(_lib.load().m2t_set_option(plan.handle, b"tail_wgrad_main", 0), "m2t_set_option")
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"tail_wgrad_main", 1), "m2t_set_option")
     if args.no_side_stream:
         plan = model._plan_for(batches[0][0])
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"side_stream", 0), "m2t_set_option")

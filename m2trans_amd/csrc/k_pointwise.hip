@@ -988,29 +988,30 @@ __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ mas
   const m2t_pack_desc d = descs[blockIdx.y];
   const float* s = master + d.src_off;
   T* o = packed + d.dst_off;
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < d.n; e += (long long)gridDim.x * blockDim.x) {
+  const int n = (int)d.n;                  // every packed tensor has < 2^31 elements: 32-bit index math (64-bit division is a software loop)
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
     long long si = e;
     switch (d.kind) {
       case M2T_PACK_COPY: break;
       case M2T_PACK_TRANSPOSE: {        // src [d0][d1] -> dst [d1][d0]
-        const int r = (int)(e / d.d0), c = (int)(e % d.d0);   // dst row r (0..d1), col c (0..d0)
+        const int r = e / d.d0, c = e % d.d0;   // dst row r (0..d1), col c (0..d0)
         si = (long long)c * d.d1 + r;
       } break;
       case M2T_PACK_CONV3: {            // src [O=d0][I=d1][9] -> dst [tap][O][I]
-        const int i = (int)(e % d.d1); const int oo = (int)((e / d.d1) % d.d0); const int tap = (int)(e / ((long long)d.d0 * d.d1));
+        const int i = e % d.d1; const int oo = (e / d.d1) % d.d0; const int tap = e / (d.d0 * d.d1);
         si = ((long long)oo * d.d1 + i) * 9 + tap;
       } break;
       case M2T_PACK_CONV3_T: {          // src [O=d0][I=d1][9] -> dst [tap'][I][O], tap' = 8 - tap (flipped kernel)
-        const int oo = (int)(e % d.d0); const int i = (int)((e / d.d0) % d.d1); const int tp = (int)(e / ((long long)d.d0 * d.d1));
+        const int oo = e % d.d0; const int i = (e / d.d0) % d.d1; const int tp = e / (d.d0 * d.d1);
         si = ((long long)oo * d.d1 + i) * 9 + (8 - tp);
       } break;
       case M2T_PACK_SHUF_ROWS: {        // src [C*rr][K=d2] (row c*rr+sub) -> dst [sub*C + c][K]; d0 = C, d1 = rr
-        const int kk = (int)(e % d.d2); const int np = (int)(e / d.d2);
+        const int kk = e % d.d2; const int np = e / d.d2;
         const int sub = np / d.d0, c = np % d.d0;
         si = ((long long)c * d.d1 + sub) * d.d2 + kk;
       } break;
       case M2T_PACK_SHUF_ROWS_T: {      // src [C*rr][K] -> dst [K][sub*C + c]
-        const int np = (int)(e % ((long long)d.d0 * d.d1)); const int kk = (int)(e / ((long long)d.d0 * d.d1));
+        const int np = e % (d.d0 * d.d1); const int kk = e / (d.d0 * d.d1);
         const int sub = np / d.d0, c = np % d.d0;
         si = ((long long)c * d.d1 + sub) * d.d2 + kk;
       } break;

@@ -101,7 +101,7 @@ struct m2t_plan {
   bool debug_skip_side = false;    // timing experiments only: skip every parameter-gradient kernel (results are WRONG)      // halo gather + qkv dgrad GEMM + prep_bwd as one kernel (k_branch.hip)
   bool use_persistent_conv = false;  // bf16 conv3x3 with LDS-resident weights: bit-identical, measured a tie (see k_conv.hip)
   bool use_fused_tail_bwd = true;  // x4 bf16: k_tail_bwd.hip instead of four HR kernels
-  bool tail_wgrad_main = true;     // tail weight gradients on the main stream (see m2t_backward)
+  bool tail_wgrad_main = false;    // tail weight gradients on the side stream (same-box A/B: +0.5 % over the main stream)
   int gate_branch = 2;             // 2: after the two C = 256 attention launches of the block (same-box A/B, 6 alternating
                                    // runs: 6.17 ms against 6.24 for 0 = after all four, 6.34 for 3, 6.23 ungated)
   bool use_gated_side = true;      // see the side-stream schedule in m2t_backward
