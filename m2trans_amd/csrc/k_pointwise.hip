@@ -362,6 +362,66 @@ __global__ void __launch_bounds__(256) branch_prep_kernel(const T* __restrict__ 
     }
   }
 }
+// ---------------------------------------------------------------------------------------
+// bf16, L = 2 (the two C = 256 branches): tiled through LDS.  The register kernel above gives each thread a 4x4 pixel
+// block, so one wave-load touches 32 different 128-byte lines and uses 32 bytes of each (the rest comes back three
+// loads later, after the 16-32 KB L1 has turned over): 14 us for 34 MB.  Here a workgroup owns 4 rows x TX pixels:
+// phase A reads x / xc and writes xin with consecutive lanes on consecutive 16 bytes, phase B does the Haar
+// butterflies per (block, channel) out of LDS, phase C writes the d rows as one contiguous run.  Same fp32 operations
+// and rounding points as the register kernel -> identical bits.
+// ---------------------------------------------------------------------------------------
+template <int TX>
+__global__ void __launch_bounds__(256) branch_prep_l2_tiled_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, const bf16_t* __restrict__ xc, int k,
+                                                                   bf16_t* __restrict__ xin, bf16_t* __restrict__ d, int B, int H, int W) {
+  constexpr int NB = TX / 4;                       // 4x4 blocks per tile
+  constexpr int NV = 4 * TX * 2;                   // 16-byte vectors of the full-resolution tile (4 rows x TX px x 2 halves)
+  __shared__ __attribute__((aligned(16))) bf16_t Q[4][TX][16];
+  __shared__ __attribute__((aligned(16))) bf16_t D[NB][256];
+  const int tid = threadIdx.x;
+  const int tpr = W / TX;                          // tiles per image row
+  const int t = blockIdx.x;                        // tile = (b, LR2 row i, tile column)
+  const int tc = t % tpr, i = (t / tpr) % (H / 4), b = t / (tpr * (H / 4));
+  const long long npix = (long long)B * H * W;
+  const int x0 = tc * TX;
+  // ---- phase A ----
+  for (int v = tid; v < NV; v += 256) {
+    const int row = v / (2 * TX), cv = v % (2 * TX), px = cv >> 1, half = cv & 1;
+    const long long pix = ((long long)b * H + 4 * i + row) * W + x0 + px;
+    float q[8];
+    load8f(x + ((long long)k * npix + pix) * 16 + half * 8, q);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ch = b * 64 + k * 16 + half * 8 + c;
+      q[c] = (q[c] - mean[ch]) * rstd[ch];
+    }
+    float p[8];
+    load8f(xc + ((long long)(k - 1) * npix + pix) * 16 + half * 8, p);        // k >= 2 for the L = 2 branches
+#pragma unroll
+    for (int c = 0; c < 8; ++c) q[c] = (q[c] + p[c]) * 0.5f;
+    store8f(xin + pix * 16 + half * 8, q);
+    store8f(&Q[row][px][half * 8], q);             // the transformed value is the stored (rounded) one
+  }
+  __syncthreads();
+  // ---- phase B: (block, channel) items ----
+  for (int it = tid; it < NB * 16; it += 256) {
+    const int blk = it >> 4, ch = it & 15;
+    float vv[4][4];
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int xx = 0; xx < 4; ++xx) vv[y][xx] = to_f(Q[y][4 * blk + xx][ch]);
+    float o[16];
+    Haar<2>::fwd(vv, o);
+#pragma unroll
+    for (int n = 0; n < 16; ++n) D[blk][n * 16 + ch] = from_f<bf16_t>(o[n]);
+  }
+  __syncthreads();
+  // ---- phase C: NB consecutive d rows = one contiguous run of NB * 512 bytes ----
+  bf16_t* dp = d + (((long long)b * (H / 4) + i) * (W / 4) + x0 / 4) * 256;
+  for (int v = tid; v < NB * 32; v += 256) store8(dp + v * 8, load8(&D[0][0] + v * 8));
+}
+
 template <typename T>
 int launch_branch_prep_t(int L, const T* x, const float* mean, const float* rstd, const T* xc, int k, T* xin, T* d,
                          int B, int H, int W, hipStream_t st) {
@@ -378,6 +438,14 @@ int launch_branch_prep_t(int L, const T* x, const float* mean, const float* rstd
 int launch_branch_prep(int dt, int L, const void* x, const float* mean, const float* rstd, const void* xc, int k,
                        void* xin, void* d, int B, int H, int W, hipStream_t st) {
   if (dt == M2T_F32) return launch_branch_prep_t<float>(L, (const float*)x, mean, rstd, (const float*)xc, k, (float*)xin, (float*)d, B, H, W, st);
+  if (L == 2 && k >= 1 && W % 32 == 0 && H % 4 == 0) {
+    if (W % 64 == 0) hipLaunchKernelGGL(branch_prep_l2_tiled_kernel<64>, dim3(B * (H / 4) * (W / 64)), dim3(256), 0, st, (const bf16_t*)x, mean, rstd,
+                                        (const bf16_t*)xc, k, (bf16_t*)xin, (bf16_t*)d, B, H, W);
+    else hipLaunchKernelGGL(branch_prep_l2_tiled_kernel<32>, dim3(B * (H / 4) * (W / 32)), dim3(256), 0, st, (const bf16_t*)x, mean, rstd,
+                            (const bf16_t*)xc, k, (bf16_t*)xin, (bf16_t*)d, B, H, W);
+    M2T_LAUNCH_CHECK();
+    return 0;
+  }
   return launch_branch_prep_t<bf16_t>(L, (const bf16_t*)x, mean, rstd, (const bf16_t*)xc, k, (bf16_t*)xin, (bf16_t*)d, B, H, W, st);
 }
 
@@ -496,9 +564,64 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restric
       }
   }
 }
+// bf16, L = 2 backward, tiled through LDS like branch_prep_l2_tiled_kernel (the register kernel: 14 us for 42 MB):
+// phase A stages the g_d rows, phase B the inverse butterflies per (block, channel), phase C the full-resolution
+// read-modify-writes with consecutive lanes on consecutive 16 bytes.
+template <int TX>
+__global__ void __launch_bounds__(256) branch_prep_bwd_l2_tiled_kernel(const bf16_t* __restrict__ gd, bf16_t* __restrict__ gxc,
+                                                                       bf16_t* __restrict__ gn, int k, int B, int H, int W) {
+  constexpr int NB = TX / 4, NV = 4 * TX * 2;
+  __shared__ __attribute__((aligned(16))) bf16_t D[NB][256];
+  __shared__ __attribute__((aligned(16))) float V[4][TX][16];
+  const int tid = threadIdx.x;
+  const int tpr = W / TX;
+  const int t = blockIdx.x;
+  const int tc = t % tpr, i = (t / tpr) % (H / 4), b = t / (tpr * (H / 4));
+  const long long npix = (long long)B * H * W;
+  const int x0 = tc * TX;
+  const bf16_t* sp = gd + (((long long)b * (H / 4) + i) * (W / 4) + x0 / 4) * 256;
+  for (int v = tid; v < NB * 32; v += 256) store8(&D[0][0] + v * 8, load8(sp + v * 8));
+  __syncthreads();
+  for (int it = tid; it < NB * 16; it += 256) {
+    const int blk = it >> 4, ch = it & 15;
+    float o[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) o[n] = to_f(D[blk][n * 16 + ch]);
+    float vv[4][4];
+    Haar<2>::inv(o, vv);
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+      for (int xx = 0; xx < 4; ++xx) V[y][4 * blk + xx][ch] = vv[y][xx];
+  }
+  __syncthreads();
+  for (int v = tid; v < NV; v += 256) {
+    const int row = v / (2 * TX), cv = v % (2 * TX), px = cv >> 1, half = cv & 1;
+    const long long pix = ((long long)b * H + 4 * i + row) * W + x0 + px;
+    float p[8], pp[8], q[8];
+    load8f(gxc + ((long long)k * npix + pix) * 16 + half * 8, p);
+    load8f(gxc + ((long long)(k - 1) * npix + pix) * 16 + half * 8, pp);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      q[c] = (V[row][px][half * 8 + c] + p[c]) * 0.5f;
+      pp[c] += q[c];
+    }
+    store8f(gn + ((long long)k * npix + pix) * 16 + half * 8, q);
+    store8f(gxc + ((long long)(k - 1) * npix + pix) * 16 + half * 8, pp);
+  }
+}
+
 int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, int k, int B, int H, int W,
                            hipStream_t st) {
   if ((long long)B * H * W * 4 >= (1LL << 31)) return m2t_set_error(-2, "branch_prep_bwd: B*H*W too large for 32-bit indexing");
+  if (dt != M2T_F32 && L == 2 && k >= 1 && W % 32 == 0 && H % 4 == 0) {
+    if (W % 64 == 0) hipLaunchKernelGGL(branch_prep_bwd_l2_tiled_kernel<64>, dim3(B * (H / 4) * (W / 64)), dim3(256), 0, st, (const bf16_t*)gd,
+                                        (bf16_t*)gxc, (bf16_t*)gn, k, B, H, W);
+    else hipLaunchKernelGGL(branch_prep_bwd_l2_tiled_kernel<32>, dim3(B * (H / 4) * (W / 32)), dim3(256), 0, st, (const bf16_t*)gd, (bf16_t*)gxc,
+                            (bf16_t*)gn, k, B, H, W);
+    M2T_LAUNCH_CHECK();
+    return 0;
+  }
   const int S = 1 << L;
   const int CH = dt == M2T_F32 ? 4 : 8;
   const int g = grid_for((long long)B * (H / S) * (W / S) * (16 / CH));
