@@ -254,6 +254,16 @@ __global__ void __launch_bounds__(256, 4) window_attn_fwd_c16_kernel(const bf16_
   const int nw = w / 8, nh = h / 8;
   const int wx = wi % nw, wy = (wi / nw) % nh, b = wi / (nw * nh);
   const long long img = (long long)b * h * w;
+  // every global load of the window is issued up front: q and the residual used to be loaded inside the query-tile
+  // loop, four dependent round trips of ~2 us each on a wave that has nothing else to run
+  bf16x4 qraw[4], rraw[4];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int q = 16 * qt + lr;
+    const long long qpix = img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
+    qraw[qt] = ld4(qkv + qpix * (3 * C16) + 4 * g);
+    rraw[qt] = res ? ld4(res + qpix * ldr + 4 * g) : zero4();
+  }
   bf16x4 kA[WA_KT];
   {
     bf16x4 kraw[WA_KT], vraw[WA_KT];
@@ -292,7 +302,7 @@ __global__ void __launch_bounds__(256, 4) window_attn_fwd_c16_kernel(const bf16_
   for (int qt = 0; qt < 4; ++qt) {
     const int q = 16 * qt + lr;
     const long long qpix = img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
-    const bf16x4 qv = ld4(qkv + qpix * (3 * C16) + 4 * g);
+    const bf16x4 qv = qraw[qt];
     const bf16x4 qB = pack4(0.25f * (float)qv[0], 0.25f * (float)qv[1], 0.25f * (float)qv[2], 0.25f * (float)qv[3]);   // C^-1/2, exact
     f32x4 s[WA_KT];
 #pragma unroll
@@ -330,7 +340,7 @@ __global__ void __launch_bounds__(256, 4) window_attn_fwd_c16_kernel(const bf16_
       mma4(o, vT[t], pack4(pv[0], pv[1], pv[2], pv[3]));
     }
     if (res) {
-      const bf16x4 rv = ld4(res + qpix * ldr + 4 * g);
+      const bf16x4 rv = rraw[qt];
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] += (float)rv[r];
     }
