@@ -31,9 +31,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (configs[1]: 16)")
-    ap.add_argument("--lr-size", type=int, default=128)
-    ap.add_argument("--scale", type=int, default=4)
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="BASELINE.json configs[i] preset: 1 = x4 128x128 batch 16 L1 only (the headline; default at --gpus 1); "
+                         "2 = x4 batch 32 + MedCLIP regulariser; 3 = x4 batch 32/GPU (256 on 8 GPUs; default at --gpus N > 1); "
+                         "4 = x3 256x256 LR, batch 8/GPU.  --batch / --lr-size / --scale override the preset")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (configs[1]: 16)")
+    ap.add_argument("--lr-size", type=int, default=None)
+    ap.add_argument("--scale", type=int, default=None)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events")
@@ -48,8 +52,36 @@ def parse():
     ap.add_argument("--debug-skip-side", action="store_true", help="TIMING EXPERIMENT: skip all parameter-gradient kernels (wrong results)")
     ap.add_argument("--semantic-loss", action="store_true",
                     help="BASELINE configs[2]: add the MedCLIP(Swin-T) image-text regulariser (random-init tower, hash text features)")
-    ap.add_argument("--cpu-baseline-batch", type=int, default=2)
-    return ap.parse_args()
+    ap.add_argument("--cpu-baseline-batch", type=int, default=None)
+    args = ap.parse_args()
+    # presets = BASELINE.json configs[i]; configs[0] (x2 64x64 CPU forward) is a parity case, not a bench line
+    if args.config is None:
+        args.config = 1 if args.gpus == 1 else 3
+    preset = {1: dict(batch=16, lr_size=128, scale=4, sem=False), 2: dict(batch=32, lr_size=128, scale=4, sem=True),
+              3: dict(batch=32, lr_size=128, scale=4, sem=False), 4: dict(batch=8, lr_size=256, scale=3, sem=False)}[args.config]
+    args.preset_overridden = any(v is not None for v in (args.batch, args.lr_size, args.scale))
+    if args.batch is None:
+        args.batch = preset["batch"]
+    if args.lr_size is None:
+        args.lr_size = preset["lr_size"]
+    if args.scale is None:
+        args.scale = preset["scale"]
+    args.semantic_loss = bool(args.semantic_loss or preset["sem"])
+    if args.cpu_baseline_batch is None:
+        args.cpu_baseline_batch = 2 if args.lr_size <= 128 else 1
+    return args
+
+
+def source_stamp() -> str:
+    """sha256 over the kernel sources the library is built from: profiles/pmc_traffic.json carries the stamp of the
+    build its counters were collected on, and roofline.traffic is reported only when it matches this build."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "m2trans_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def synthetic_batch(B, h, scale, rank, step, device):
@@ -118,9 +150,13 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
+    backend = None
     if world > 1 or (args.force_comm_path and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = torch.distributed.get_backend()
+        if torch.distributed.get_world_size() != args.gpus and world > 1:
+            raise SystemExit(f"process group has {torch.distributed.get_world_size()} ranks, --gpus says {args.gpus}")
 
     from m2trans_amd import _lib
     from m2trans_amd.M2Trans_network import create_model
@@ -135,7 +171,7 @@ def main():
     B = args.batch
     if args.semantic_loss:
         from m2trans_amd.losses import SemanticLoss
-        sem = SemanticLoss(criterion="l1", N_patches=3, device=device, compute_dtype=args.dtype, max_batch=B)
+        sem = SemanticLoss(criterion="l1", N_patches=3, device=device, compute_dtype=args.dtype, max_batch=B, synthetic_text=True)
         enc = sem._enc = None
         from m2trans_amd.losses import SwinEncoder
         e = SwinEncoder(2 * B, _lib.F32 if args.dtype == "fp32" else _lib.BF16, device)
@@ -205,13 +241,25 @@ def main():
     roofline = None
     if rank == 0 and not args.no_kernel_events:
         roofline = m2t_profile.roofline_report(B, args.lr_size, args.scale, args.dtype, args.steps,
-                                               os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+                                               os.path.join(ROOT, "profiles", "pmc_traffic.json"), source_stamp(),
+                                               workload=f"config{args.config}" if not args.preset_overridden else None)
         m2t_profile.enable(0)
 
     if rank == 0:
+        what = {1: "L1 loss only (BASELINE configs[1])", 2: "L1 + MedCLIP(Swin-T) regulariser (BASELINE configs[2])",
+                3: "L1 loss only (BASELINE configs[3]: 32 patches per GPU, 256 on 8 GPUs)",
+                4: "L1 loss only (BASELINE configs[4])"}[args.config]
+        if args.preset_overridden:
+            what = ("L1 + MedCLIP(Swin-T) regulariser" if args.semantic_loss else "L1 loss only") + " (preset overridden on the command line)"
+        # every switch that changes the measured work or schedule is echoed, so an experiment cannot pass for a headline
+        experiment = {k: v for k, v in {
+            "option": args.option or None, "gate_branch": args.gate_branch, "tail_wgrad_main": args.tail_wgrad_main or None,
+            "no_side_stream": args.no_side_stream or None, "null_stream": args.null_stream or None,
+            "no_overlap_comm": args.no_overlap_comm or None, "force_comm_path": args.force_comm_path or None,
+            "all_kernel_events": args.all_kernel_events or None, "debug_skip_side": args.debug_skip_side or None}.items() if v is not None}
         out = {
             "metric": f"train-step HR patches/sec at {args.lr_size}x{args.lr_size} LR x{args.scale}",
-            "value": round(world * B * args.steps / dt, 3),
+            "value": None if args.debug_skip_side else round(world * B * args.steps / dt, 3),
             "unit": "HR patches/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -221,12 +269,22 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic U[0,1) LR/HR patches resident in HBM, seed-33 reference init",
+            "data": "synthetic U[0,1) LR/HR patches resident in HBM, seed-33 reference init" + (
+                "; MedCLIP image tower = random-init Swin-T, text features = hash stand-ins (weights not vendored)" if args.semantic_loss else ""),
             "config": {"workload": f"x{args.scale} SR train step (fwd + L1 + bwd + Adam), {args.lr_size}x{args.lr_size} LR "
-                                   f"patches, batch {B}/GPU, " + ("L1 + MedCLIP(Swin-T) regulariser (BASELINE configs[2])" if args.semantic_loss else "L1 loss only (BASELINE configs[1])"),
-                       "global_batch": world * B, "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
+                                   f"patches, batch {B}/GPU, " + what,
+                       "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
+                       "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if backend else "none (single process)",
+                       "world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                       "grad_exchange": ("none" if ts.bucket is None else
+                                         ("bucketed all-reduce overlapped with backward" if ts.overlap_comm else "one all-reduce after backward")),
+                       "final_loss": round(loss, 6)},
             "roofline": roofline,
         }
+        if experiment:
+            out["config"]["experiment_flags"] = experiment
+        if args.debug_skip_side:
+            out["invalid"] = True          # parameter-gradient kernels skipped: not a train step
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -94,9 +94,13 @@ class _M2TransFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, model, *params):
         plan = model._plan_for(x)
-        sr = model._run_forward(plan, x, keep=True)
+        # the kernels (forward AND the head weight gradient of backward) read raw contiguous fp32 NCHW memory:
+        # convert once and save the CONVERTED tensor (a channels_last / sliced / half-precision input would
+        # otherwise hand m2t_backward a pointer with the wrong layout or element size)
+        xc = x.detach().contiguous().float()
+        sr = model._run_forward(plan, xc, keep=True)
         ctx.model, ctx.plan, ctx.gen = model, plan, plan.gen
-        ctx.save_for_backward(x)
+        ctx.save_for_backward(xc)
         return sr
 
     @staticmethod

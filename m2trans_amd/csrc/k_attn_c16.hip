@@ -354,12 +354,7 @@ int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float*
                                void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st) {
   const int nwin = B * (h / 8) * (w / 8);
   const size_t sh = 4 * sizeof(C16WaveLds);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)window_attn_bwd_c16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
-    attr_set = true;
-  }
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_bwd_c16_kernel, (int)sh)) return rc__;
   M2T_LAUNCH_TIMED(window_attn_bwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), sh, st, (const bf16_t*)qkv, rel_h, rel_w,
                      (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, h, w, nwin);
   M2T_LAUNCH_CHECK();

@@ -569,12 +569,7 @@ template <int C, int L>
 int go_fwd_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, bf16_t* out, int ldo, int oc0, const bf16_t* res, int ldr,
                int nwin, int h, int w, hipStream_t st) {
   const size_t sh = sizeof(bf16_t) * 2 * 101 * (C + 8);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)window_attn_fwd_res_kernel<C, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
-    attr_set = true;
-  }
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_fwd_res_kernel<C, L>, (int)sh)) return rc__;
   M2T_LAUNCH_TIMED((window_attn_fwd_res_kernel<C, L>), dim3(nwin), dim3(256), sh, st, qkv, rel_h, rel_w, out, ldo, oc0, res, ldr, h, w);
   return 0;
 }
@@ -583,12 +578,7 @@ template <int C, int L, int NW>
 int go_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, const bf16_t* gout, int ldg, int gc0, bf16_t* gqkv,
            bf16_t* win, float* relw, int nwin, int h, int w, hipStream_t st) {
   const size_t sh = ResCfg<C>::total;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)window_attn_bwd_res_kernel<C, L, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
-    attr_set = true;
-  }
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_bwd_res_kernel<C, L, NW>, (int)sh)) return rc__;
   M2T_LAUNCH_TIMED((window_attn_bwd_res_kernel<C, L, NW>), dim3(nwin), dim3(NW * 64), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0,
                      gqkv, win, relw, h, w);
   return 0;

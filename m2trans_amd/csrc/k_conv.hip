@@ -488,12 +488,7 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
   const long long ntiles = (long long)B * (H / C3_TH) * (W / C3_TW);
   if (dt != M2T_F32 && persistent && ntiles >= 512) {
     const size_t sh = sizeof(bf16_t) * C3_LD * (9 * 64 + 2 * (C3_TH + 2) * (C3_TW + 2));   // weights + one halo tile per wave group
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute((const void*)conv3x3_c64_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-      if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
-      attr_set = true;
-    }
+    if (int rc__ = m2t_ensure_dynamic_lds((const void*)conv3x3_c64_persistent_kernel, (int)sh)) return rc__;
     int nblk = 256;
     const int tpb = (int)ceil_divll(ntiles, nblk);
     nblk = (int)ceil_divll(ntiles, tpb);
@@ -824,12 +819,12 @@ int launch_final_conv_fwd(int dt, const void* tpre, const float* w, float* out, 
   const long long ntiles = (long long)B * (H / FC_T) * (W / FC_T);
   if (dt == M2T_F32) {
     const size_t sh = final_fwd_smem<float>();
-    (void)hipFuncSetAttribute((const void*)final_conv_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (int rc__ = m2t_ensure_dynamic_lds((const void*)final_conv_fwd_kernel<float>, (int)sh)) return rc__;
     const int grid = (int)std::min<long long>(ntiles, 256);        // fp32: 101 KB of LDS, one workgroup per CU
     M2T_LAUNCH_TIMED(final_conv_fwd_kernel<float>, dim3(grid), dim3(256), sh, st, (const float*)tpre, w, out, B, H, W);
   } else {
     const size_t sh = final_fwd_smem<bf16_t>();
-    (void)hipFuncSetAttribute((const void*)final_conv_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (int rc__ = m2t_ensure_dynamic_lds((const void*)final_conv_fwd_kernel<bf16_t>, (int)sh)) return rc__;
     const int grid = (int)std::min<long long>(ntiles, 768);        // bf16: 53 KB of LDS, three workgroups per CU
     M2T_LAUNCH_TIMED(final_conv_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, st, (const bf16_t*)tpre, w, out, B, H, W);
   }

@@ -223,12 +223,7 @@ gemm_nt_wide_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T
 template <typename T, int BM>
 static int launch_gemm_nt_wide(const m2t_gemm_args& a, hipStream_t st) {
   const size_t sh = sizeof(T) * 2 * (BM + 128) * 72;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_wide_kernel<T, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
-    attr_set = true;
-  }
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)gemm_nt_wide_kernel<T, BM>, (int)sh)) return rc__;
   dim3 grid((unsigned)(ceil_divll(a.M, BM) * (a.N / 128)));
   hipLaunchKernelGGL((gemm_nt_wide_kernel<T, BM>), grid, dim3(256), sh, st, (const T*)a.A, a.lda, (const T*)a.W, (T*)a.Y, a.ldy,
                      a.M, a.N, a.K);

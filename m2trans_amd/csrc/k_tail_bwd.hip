@@ -337,12 +337,7 @@ int launch_tail_bwd_fused(const float* gout, const float* wf, const void* act, c
   (void)ntiles;
   const int nblk = tail_bwd_fused_blocks(B, H, W);
   const size_t sh = tail_bwd_smem();
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)tail_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
-    attr_set = true;
-  }
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)tail_bwd_fused_kernel, (int)sh)) return rc__;
   TailBwdArgs a{gout, wf, (const bf16_t*)act, (const bf16_t*)der, (const bf16_t*)a1, (const bf16_t*)d1, (const bf16_t*)w3t,
                 (bf16_t*)gt1, slab_wf, slab_w3, slab_b3, B, H, W};
   M2T_LAUNCH_TIMED(tail_bwd_fused_kernel, dim3(nblk), dim3(512), sh, st, a);

@@ -20,6 +20,19 @@ int m2t_set_hip_error(hipError_t e, const char* file, int line) {
 }
 int m2t_set_error(int code, const char* msg) { g_err = msg; return code; }
 
+int m2t_ensure_dynamic_lds(const void* kernel, int bytes) {
+  static thread_local std::map<std::pair<int, const void*>, int> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+  auto it = done.find({dev, kernel});
+  if (it != done.end() && it->second >= bytes) return 0;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+  done[{dev, kernel}] = bytes;
+  return 0;
+}
+
 // ---- optional per-kernel timing with HIP events on the launch stream -------------------------
 namespace {
 struct ProfRec { hipEvent_t a, b; int cat; };
@@ -28,7 +41,8 @@ struct ProfState {
   std::vector<ProfRec> pool;
   size_t used = 0;
   bool open = false, taken = false;      // a dispatch-timed scope is open / its events went out with a launch
-} g_prof;
+};
+thread_local ProfState g_prof;           // per calling thread, like the error string: no process-global mutable state
 }
 void m2t_prof_begin(int cat, hipStream_t st) {
   if (!((g_prof.mask >> cat) & 1ull) || g_prof.used >= g_prof.pool.size()) return;
@@ -125,8 +139,9 @@ struct m2t_plan {
     // The parameter-gradient kernels are filler.  They run on a CU-masked stream (side_cus of the chip's CUs; the
     // mask bits interleave over the XCDs) so that main-chain workgroups always find empty CUs: a 160 KB-LDS
     // attention workgroup otherwise starves until a concurrent wgrad kernel has drained completely.
-    int ncu = 0;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0);
+    int ncu = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const char* ev = getenv("M2T_SIDE_CUS");
     int cus = ev ? atoi(ev) : side_cus;
     // (a CU-masked stream is a BLOCKING stream: against the legacy default stream it would serialise)
@@ -501,13 +516,17 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   std::vector<m2t_red_desc> descs;
   size_t flushed = 0;
   bool overflow = false;
+  // returns nullptr (and the caller returns M2T_ERR_STATE through ARENA) BEFORE any kernel could write past the arena
   auto arena_alloc = [&](size_t nfloats) -> float* {
     arena_top = (arena_top + 63) & ~(size_t)63;
+    if (arena_top + nfloats > p->arena_floats) { overflow = true; return nullptr; }
     float* ptr = arena + arena_top;
     arena_top += nfloats;
-    if (arena_top > p->arena_floats) overflow = true;
     return ptr;
   };
+#define ARENA(var, nfloats)                                                                              \
+  float* var = arena_alloc(nfloats);                                                                     \
+  if (!var) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: slab arena too small for this plan")
   auto defer = [&](const float* slab, long long dst_off, int ns, long long n, int perm, int p0, int p1, int p2) {
     m2t_red_desc d;
     d.src_off = (long long)(slab - arena); d.dst_off = dst_off; d.n = n; d.ns = ns; d.perm = perm; d.p0 = p0; d.p1 = p1; d.p2 = p2; d.pad_ = 0;
@@ -546,9 +565,9 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   if (fused_tail) {
     // one pass over the high-resolution tensors (k_tail_bwd.hip): tail conv dgrad + wgrad, GELU', tail.3 dgrad + wgrad
     const int nb = tail_bwd_fused_blocks(B, p->Hsp, p->Wsp);
-    float* swf = arena_alloc((size_t)nb * 32 * 64);
-    float* sw3 = arena_alloc((size_t)nb * 256 * 64);
-    float* sb3 = arena_alloc((size_t)nb * 256);
+    ARENA(swf, (size_t)nb * 32 * 64);
+    ARENA(sw3, (size_t)nb * 256 * 64);
+    ARENA(sb3, (size_t)nb * 256);
     { M2TProfScope ps(M2T_PROF_FINAL_DGRAD, st);
       CK(launch_tail_bwd_fused(gpre, params + p->poff.at(wl), WSP("t2act"), WSP("t2der"), WSP("t1act"), WSP("t1der"),
                                packed_ptr(p, workspace, "t3T"), WSP("g_t1pre"), swf, sw3, sb3, &ns, B, p->Hsp, p->Wsp, st)); }
@@ -557,7 +576,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     defer(sb3, p->poff.at("tail.3.bias"), ns, 256, 2, 64, 4, 1);
   } else {
   if (!skip) {
-    float* slabs = arena_alloc((size_t)1024 * 32 * 64);
+    ARENA(slabs, (size_t)1024 * 32 * 64);
     { M2TProfScope ps(M2T_PROF_FINAL_WGRAD, tws); CK(launch_final_conv_wgrad(dt, gpre, last_act, slabs, &ns, B, p->Hsp, p->Wsp, tws)); }
     defer(slabs, p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0);
   }
@@ -565,8 +584,8 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   if (s == 4) {
     // tail.3: u = t1act W3^T + b3 (t1act = gelu(t1)), shuffled; g(t1) = (g_u W3) * t1der
     fork();
-    float* slabs = arena_alloc((size_t)wgrad_slab_count(BP * 4, 256, 64) * 256 * 64);
-    float* colp = arena_alloc((size_t)wgrad_slab_count(BP * 4, 256, 64) * 256);
+    ARENA(slabs, (size_t)wgrad_slab_count(BP * 4, 256, 64) * 256 * 64);
+    ARENA(colp, (size_t)wgrad_slab_count(BP * 4, 256, 64) * 256);
     m2t_wgrad_args wa{};
     if (!skip) {
     wa.G = WSP("g_t2pre"); wa.gmode = M2T_A_UNSHUF; wa.X = WSP("t1act"); wa.ldx = 64; wa.xmode = M2T_A_PLAIN;
@@ -586,8 +605,8 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   {
     const int N0 = 64 * r0 * r0;
     fork();
-    float* slabs = arena_alloc((size_t)wgrad_slab_count(BP, N0, 64) * N0 * 64);
-    float* colp = arena_alloc((size_t)wgrad_slab_count(BP, N0, 64) * N0);
+    ARENA(slabs, (size_t)wgrad_slab_count(BP, N0, 64) * N0 * 64);
+    ARENA(colp, (size_t)wgrad_slab_count(BP, N0, 64) * N0);
     m2t_wgrad_args wa{};
     wa.G = WSP("g_t1pre"); wa.gmode = M2T_A_UNSHUF; wa.X = Y; wa.ldx = M2T_LD_P64; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = N0; wa.K = 64; wa.H = H; wa.Wd = W; wa.r = r0; wa.C = 64;
@@ -634,8 +653,8 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     // feed_forward conv: weight / bias gradients on the side stream, data gradient on the main one
     auto side_conv = [&]() -> int {
       if (skip) return 0;
-      float* slabs = arena_alloc((size_t)256 * 9 * 64 * 64);
-      float* colp = arena_alloc((size_t)256 * 64);
+      ARENA(slabs, (size_t)256 * 9 * 64 * 64);
+      ARENA(colp, (size_t)256 * 64);
       { M2TProfScope ps(M2T_PROF_CONV3_WGRAD, sd); CK(launch_conv3x3_c64_wgrad(dt, xc, gy_blk, slabs, colp, &ns, B, H, W, sd)); }
       defer(slabs, p->poff.at(pre + "feed_forward.0.weight"), ns, 9 * 64 * 64, 1, 64, 64, 0);
       defer(colp, p->poff.at(pre + "feed_forward.0.bias"), ns, 64, 0, 0, 0, 0);     // bias gradient rode along
@@ -647,13 +666,13 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       const int h = H >> L, w = W >> L;
       const long long M = (long long)B * h * w;
       const std::string an = pre + "attn" + std::to_string(i + 1) + ".";
-      float* slabs = arena_alloc((size_t)wgrad_slab_count(M, 3 * C, C) * 3 * C * C);
+      ARENA(slabs, (size_t)wgrad_slab_count(M, 3 * C, C) * 3 * C * C);
       m2t_wgrad_args wa{};
       wa.G = gqkv_buf[i]; wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = WSP(k + "d" + std::to_string(i + 1)); wa.ldx = C; wa.xmode = M2T_A_PLAIN;
       wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = h; wa.Wd = w; wa.r = 1; wa.C = C; wa.halo_win = win_buf[i];
       { M2TProfScope ps(M2T_PROF_WGRAD_QKV, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
       defer(slabs, p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0);
-      float* relp = arena_alloc((size_t)32 * 10 * C);
+      ARENA(relp, (size_t)32 * 10 * C);
       int nsp = 0;
       CK(launch_rel_reduce1(relw_buf[i], relp, (int)(M / 64), C, &nsp, sd));
       defer(relp, p->poff.at(an + "rel_h"), nsp, 10LL * C, 4, C, 0, 0);     // rel_h then rel_w are adjacent parameters
@@ -725,8 +744,8 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   if (!skip) {
     // head conv: im2col'd input (made at the start of this backward, off the critical path) x output gradient
     const int nsl = wgrad_slab_count(BP, 64, 32);
-    float* slabs = arena_alloc((size_t)nsl * 64 * 32);
-    float* colp = arena_alloc((size_t)nsl * 64);
+    ARENA(slabs, (size_t)nsl * 64 * 32);
+    ARENA(colp, (size_t)nsl * 64);
     m2t_wgrad_args wa{};
     wa.G = WSP("gxc"); wa.ldg = M2T_LD_P64; wa.gmode = M2T_A_PLAIN; wa.X = WSP("head_cols"); wa.ldx = 32; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = 64; wa.K = 32; wa.H = H; wa.Wd = W; wa.r = 1; wa.C = 64;

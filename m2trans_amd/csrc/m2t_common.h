@@ -232,6 +232,10 @@ __device__ __forceinline__ int xcd_block_index() {
 
 int m2t_set_hip_error(hipError_t e, const char* file, int line);
 int m2t_set_error(int code, const char* msg);
+// Raises the dynamic-LDS limit of `kernel` to `bytes` on the CURRENT device, once per (calling thread, device, kernel):
+// the attribute is per device, and the cache is thread-local, so the library keeps no process-global mutable state
+// (two host threads driving two GPUs each set it for their own device).  Returns 0 or the hipError_t.
+int m2t_ensure_dynamic_lds(const void* kernel, int bytes);
 
 // ---------------------------------------------------------------------------------------
 // "P64": the chunk-planar layout of every 64-channel low-resolution feature map (X_b, xc, their gradients):

@@ -55,13 +55,19 @@ class GradBucket:
     comm_dtype=torch.bfloat16 halves the bytes on the wire (7.3 MB); the sum is then carried out
     in bf16 by the collective, so fp32 is the default and the parity path."""
 
-    def __init__(self, flat: torch.Tensor, process_group=None, comm_dtype: torch.dtype = torch.float32, force: bool = False):
+    def __init__(self, flat: torch.Tensor, process_group=None, comm_dtype: torch.dtype = torch.float32, force: bool = False,
+                 expect_world: Optional[int] = None):
         if flat.dim() != 1 or not flat.is_contiguous():
             raise ValueError("GradBucket needs a contiguous 1-D buffer")
         self.flat = flat
         self.pg = process_group
         self.comm_dtype = comm_dtype
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        if expect_world is not None and int(expect_world) != self.world:
+            # TrainStep divides the loss by world_size: without a matching process group every rank would train on
+            # gradients scaled by 1/N with no exchange and no error
+            raise RuntimeError(f"GradBucket: world_size {expect_world} was requested but the process group has {self.world} "
+                               "rank(s) (torch.distributed not initialised?)")
         self._wire = None if comm_dtype == flat.dtype else torch.empty_like(flat, dtype=comm_dtype)
         # force: issue the collectives even in a one-rank group (exercises the RCCL / stream path on a single GPU)
         self.force = bool(force) and dist.is_available() and dist.is_initialized()
@@ -77,11 +83,19 @@ class GradBucket:
         return None
 
     def all_reduce_range(self, lo: int, hi: int):
-        """SUM-all-reduce flat[lo:hi] in place on the CURRENT stream (fp32 wire; used by the overlapped exchange:
-        every rank issues the same ranges in the same order)."""
+        """SUM-all-reduce flat[lo:hi] in place on the CURRENT stream (used by the overlapped exchange: every rank
+        issues the same ranges in the same order).  With a bf16 wire only THIS range is staged through the wire
+        buffer (cast, collective, cast back, all on the current stream), so the overlap with the backward pass is
+        kept and no full-buffer copy is made."""
         if (self.world == 1 and not self.force) or hi <= lo:
             return None
-        return dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+        if self._wire is None:
+            return dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg)
+        w = self._wire[lo:hi]
+        w.copy_(self.flat[lo:hi])
+        dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.pg)
+        self.flat[lo:hi].copy_(w)
+        return None
 
 
 def broadcast_params(flat_params: torch.Tensor, src: int = 0, process_group=None):

@@ -16,8 +16,8 @@ evaluated without gradient (losses.py:63): the term shifts the logged loss, not 
 PARITY UNPINNED: the `medclip` package, its Swin/BERT checkpoints and tokenizer are not vendored
 by the reference.  Weights are therefore injected (``load_state_dict`` with HF swin-tiny names,
 4.24 or 5.x spelling, plus ``projection_head.weight``); text features are injected per caption
-(``set_text_features``) -- they are constants of the frozen text tower.  Without injected text
-features a deterministic hash embedding is used so the pipeline runs end to end.
+(``set_text_features``) -- they are constants of the frozen text tower.  A caption without an injected
+text feature RAISES (``synthetic_text=True`` opts into a deterministic hash stand-in for benchmarks).
 """
 from __future__ import annotations
 
@@ -116,8 +116,12 @@ def hash_text_feature(caption: str) -> torch.Tensor:
 
 class SemanticLoss(nn.Module):
     def __init__(self, criterion: str = "l1", N_patches: int = 3, device=None, compute_dtype: str = "fp32",
-                 max_batch: int = 32):
+                 max_batch: int = 32, synthetic_text: bool = False):
         super().__init__()
+        # synthetic_text=True (benchmarks / tests with no MedCLIP weights): a caption without an injected text feature
+        # gets a deterministic hash embedding.  The default is to RAISE: a silent stand-in behind a drop-in surface
+        # would log a wrong regulariser value (the reference loads the real text tower itself, losses.py:22-23).
+        self.synthetic_text = bool(synthetic_text)
         self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
         self.N_patches = int(N_patches)
         self.compute_dtype = compute_dtype
@@ -149,7 +153,13 @@ class SemanticLoss(nn.Module):
 
     def _text_feature(self, caption: str) -> torch.Tensor:
         t = self._text.get(caption)
-        return t if t is not None else hash_text_feature(caption)
+        if t is not None:
+            return t
+        if not self.synthetic_text:
+            raise M2TError(f"SemanticLoss: no text feature for caption {caption!r}: inject the MedCLIP text embeddings with "
+                           "set_text_features({caption: tensor[512]}) (the text tower is not part of this build), or construct "
+                           "SemanticLoss(synthetic_text=True) for a benchmark with stand-in embeddings")
+        return hash_text_feature(caption)
 
     # ---- reference semantics ------------------------------------------------------------------
     def createNRandompatches(self, hs: int, ws: int, N: int, patch_size: int = 224):

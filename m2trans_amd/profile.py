@@ -114,15 +114,20 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8)
     return w
 
 
-def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_file: str | None = None):
+def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_file: str | None = None,
+                    source_stamp: str | None = None, workload: str | None = None):
     """Roofline object for the dominant (largest total time) kernel category measured in the
-    timed region, plus a compact table of the others."""
+    timed region, plus a compact table of the others.  `traffic` (PMC bytes per launch) comes from a separate
+    rocprofv3 --pmc collection (tools/pmc_traffic.py -> profiles/pmc_traffic.json); it is reported only when that
+    file was collected on THIS build (same kernel-source stamp) and workload, otherwise null."""
     t = read_all()
     work = algorithmic_work(B, lr, scale, dtype)
     traffic = {}
     if pmc_file and os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get("traffic_bytes_per_launch", {})
+            blob = json.load(open(pmc_file))
+            if source_stamp is not None and blob.get("source_stamp") == source_stamp and blob.get("workload", "config1") == workload:
+                traffic = blob.get("traffic_bytes_per_launch", {})
         except Exception:
             traffic = {}
     rows = []

@@ -63,9 +63,10 @@ class TrainStep:
         self.l1_loss = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.loss = self.l1_loss
         # force_comm_path: build the exchange machinery even for one rank (tests exercise the stream / event logic)
-        self.bucket = GradBucket(self.grads, process_group, grad_bucket_dtype, force=force_comm_path) if (self.world_size > 1 or force_comm_path) else None
-        # overlapped exchange: fp32 wire only (the bf16 wire format needs a staging copy of the whole buffer)
-        self.overlap_comm = bool(overlap_comm) and self.bucket is not None and grad_bucket_dtype == torch.float32
+        self.bucket = GradBucket(self.grads, process_group, grad_bucket_dtype, force=force_comm_path,
+                                 expect_world=self.world_size) if (self.world_size > 1 or force_comm_path) else None
+        # overlapped exchange for either wire format (a bf16 wire stages each range through a slice of the wire buffer)
+        self.overlap_comm = bool(overlap_comm) and self.bucket is not None
         self.comm_stream = torch.cuda.Stream(device=flat.device) if self.overlap_comm else None
         self._last_plan = None
 

@@ -127,6 +127,65 @@ def closed_form_image(b: int, c: int, h: int, w: int, phase: float = 0.0,
 
 
 # --------------------------------------------------------------------------------------
+# bf16 emulation (test infrastructure for the bf16 throughput mode of the HIP path)
+#
+# The reference is fp32 end to end; the HIP path's bf16 mode keeps fp32 accumulation, statistics,
+# softmax, loss and master weights but STORES activations and packed weights in bf16.  With ``emulate_bf16=True``
+# the restatement below rounds to bf16 at exactly those storage points (listed in each function), so a bf16 HIP
+# run can be held to a ~10x tighter bound than against the un-rounded fp32 arithmetic: what remains is the order
+# of fp32 accumulation.  Gradients are rounded where the forward value is (the HIP backward stores the matching
+# gradient tensors -- g(X_b), g(xc), g(qkv), g(d), g(t1) -- in bf16 too); that part is an approximation of the
+# HIP schedule, not a restatement of it.  None of this is reference arithmetic: the pinned path is emulate_bf16=False.
+# --------------------------------------------------------------------------------------
+class _RoundBoth(torch.autograd.Function):
+    """value -> bf16 -> fp32 in forward, gradient -> bf16 -> fp32 in backward."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """packed weights: rounded for the products, gradient accumulated in fp32 (straight through)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _GeluStored(torch.autograd.Function):
+    """tail expansion of the HIP path: stores gelu(t) and gelu'(t) in bf16; the backward multiplies by the STORED
+    derivative (csrc/k_gemm.hip tail_expand_kernel, k_tail_bwd.hip)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        act = F.gelu(t).to(torch.bfloat16).to(t.dtype)
+        ctx.save_for_backward(gelu_derivative(t).to(torch.bfloat16).to(t.dtype))
+        return act
+
+    @staticmethod
+    def backward(ctx, g):
+        (der,) = ctx.saved_tensors
+        return (g * der).to(torch.bfloat16).to(g.dtype)
+
+
+def _r(x: Tensor, emu: bool) -> Tensor:
+    return _RoundBoth.apply(x) if emu else x
+
+
+def _rw(w: Tensor, emu: bool) -> Tensor:
+    return _RoundFwd.apply(w) if emu else w
+
+
+# --------------------------------------------------------------------------------------
 # Haar DWT / IWT   (models/M2Trans_network.py:198-237)
 # --------------------------------------------------------------------------------------
 def dwt(x: Tensor) -> Tensor:
@@ -160,8 +219,8 @@ def iwt(x: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------
 # halo window attention   (models/M2Trans_network.py:290-340 with sr=1, heads=1)
 # --------------------------------------------------------------------------------------
-def window_attention_core(q: Tensor, k: Tensor, v: Tensor, rel_h: Tensor, rel_w: Tensor
-                          ) -> Tensor:
+def window_attention_core(q: Tensor, k: Tensor, v: Tensor, rel_h: Tensor, rel_w: Tensor,
+                          emulate_bf16: bool = False) -> Tensor:
     """q,k,v: [B,C,h,w] (already projected).  Returns [B,C,h,w].
 
     Restates models/M2Trans_network.py:310-332: 8x8 query windows, 10x10 key windows cut
@@ -174,7 +233,9 @@ def window_attention_core(q: Tensor, k: Tensor, v: Tensor, rel_h: Tensor, rel_w:
     nh, nw = h // BLOCK, w // BLOCK
     scale = float(C) ** -0.5                               # :311 (head_ch = C, heads = 1)
     qw = q.view(B, C, nh, BLOCK, nw, BLOCK).permute(0, 2, 4, 3, 5, 1)   # B nh nw 8 8 C
-    qw = qw.reshape(B * nh * nw, BLOCK * BLOCK, C) * scale
+    qw = qw.reshape(B * nh * nw, BLOCK * BLOCK, C)
+    if not emulate_bf16:
+        qw = qw * scale                                    # (bf16 mode: the fp32 scores are scaled instead)
     kp = F.pad(k, (HALO, HALO, HALO, HALO))                # zero padding (:313 padding=halo)
     vp = F.pad(v, (HALO, HALO, HALO, HALO))
     # explicit gather of the 10x10 neighbourhoods: window (i,j) covers padded rows
@@ -186,23 +247,26 @@ def window_attention_core(q: Tensor, k: Tensor, v: Tensor, rel_h: Tensor, rel_w:
     half = C // 2
     bias = torch.cat((rel_h.reshape(1, KWIN, 1, half).expand(1, KWIN, KWIN, half),
                       rel_w.reshape(1, 1, KWIN, half).expand(1, KWIN, KWIN, half)), dim=-1)
-    kw = (kw + bias).reshape(B * nh * nw, KWIN * KWIN, C)
+    kw = _r((kw + bias).reshape(B * nh * nw, KWIN * KWIN, C), emulate_bf16)   # bf16 mode: K^ = bf16(k + rel) in LDS
     sim = torch.bmm(qw, kw.transpose(1, 2))                # :328
-    attn = torch.softmax(sim, dim=-1)                      # :329
+    if emulate_bf16:
+        sim = sim * scale
+    attn = _r(torch.softmax(sim, dim=-1), emulate_bf16)    # :329   (bf16 mode: P is the bf16 operand of P V)
     out = torch.bmm(attn, vw)                              # :331  [BL,64,C]
     out = out.view(B, nh, nw, BLOCK, BLOCK, C).permute(0, 5, 1, 3, 2, 4)
     return out.reshape(B, C, h, w)                         # :332
 
 
-def tblock(x: Tensor, p: Params, prefix: str, cap=None, cap_key: str = "") -> Tensor:
+def tblock(x: Tensor, p: Params, prefix: str, cap=None, cap_key: str = "", emulate_bf16: bool = False) -> Tensor:
     """TBlock.forward (models/M2Trans_network.py:290-340), sr=1, no pad branch.
-    ``cap`` (optional dict) records intermediates for the kernel-level parity tests."""
-    wq = p[prefix + "qkv_conv.weight"]
-    qkv = F.conv2d(x, wq)                                  # :307
+    ``cap`` (optional dict) records intermediates for the kernel-level parity tests.
+    bf16 storage points: the packed qkv weight, the qkv tensor, K^ and P (window_attention_core)."""
+    wq = _rw(p[prefix + "qkv_conv.weight"], emulate_bf16)
+    qkv = _r(F.conv2d(x, wq), emulate_bf16)                # :307
     if cap is not None:
         cap[cap_key] = qkv
     q, k, v = torch.chunk(qkv, 3, dim=1)                   # :308
-    return window_attention_core(q, k, v, p[prefix + "rel_h"], p[prefix + "rel_w"])
+    return window_attention_core(q, k, v, p[prefix + "rel_h"], p[prefix + "rel_w"], emulate_bf16)
 
 
 # --------------------------------------------------------------------------------------
@@ -216,25 +280,34 @@ def instance_norm(x: Tensor, eps: float = 1e-5) -> Tensor:
     return (x - mu) / torch.sqrt(var + eps)
 
 
-def cftm(x: Tensor, p: Params, prefix: str, cap=None, ck: str = "") -> Tensor:
-    """CFTM.forward, norm branch (models/M2Trans_network.py:132-164)."""
+def cftm(x: Tensor, p: Params, prefix: str, cap=None, ck: str = "", emulate_bf16: bool = False,
+         extra_residual: Tensor | None = None) -> Tensor:
+    """CFTM.forward, norm branch (models/M2Trans_network.py:132-164).
+    bf16 storage points (csrc/k_pointwise.hip branch_prep, k_attn*.hip epilogue, k_conv.hip): each branch input
+    xin = (norm chunk + previous branch) / 2, its transform d = DWT^L(xin), each branch output x_k' (a chunk of xc),
+    the packed 3x3 weight and the block output.  ``extra_residual``: the `res + x` of M2Trans.forward:70, which the
+    HIP path folds into the LAST block's conv epilogue (one rounding instead of two)."""
+    e = emulate_bf16
     x1, x2, x3, x4 = torch.chunk(instance_norm(x), 4, dim=1)
-    d1 = x1
-    x1 = tblock(d1, p, prefix + "attn1.", cap, ck + "qkv1") + x1
-    x2 = (x2 + x1) / 2.0
-    d2 = dwt(x2)
-    x2 = iwt(tblock(d2, p, prefix + "attn2.", cap, ck + "qkv2")) + x2
-    x3 = (x3 + x2) / 2.0
-    d3 = dwt(dwt(x3))
-    x3 = iwt(iwt(tblock(d3, p, prefix + "attn3.", cap, ck + "qkv3"))) + x3
-    x4 = (x4 + x3) / 2.0
-    d4 = dwt(dwt(x4))
-    x4 = iwt(iwt(tblock(d4, p, prefix + "attn4.", cap, ck + "qkv4"))) + x4
+    d1 = _r(x1, e)
+    x1 = _r(tblock(d1, p, prefix + "attn1.", cap, ck + "qkv1", e) + d1, e)
+    x2 = _r((x2 + x1) / 2.0, e)
+    d2 = _r(dwt(x2), e)
+    x2 = _r(iwt(tblock(d2, p, prefix + "attn2.", cap, ck + "qkv2", e)) + x2, e)
+    x3 = _r((x3 + x2) / 2.0, e)
+    d3 = _r(dwt(dwt(x3)), e)
+    x3 = _r(iwt(iwt(tblock(d3, p, prefix + "attn3.", cap, ck + "qkv3", e))) + x3, e)
+    x4 = _r((x4 + x3) / 2.0, e)
+    d4 = _r(dwt(dwt(x4)), e)
+    x4 = _r(iwt(iwt(tblock(d4, p, prefix + "attn4.", cap, ck + "qkv4", e))) + x4, e)
     xc = torch.cat((x1, x2, x3, x4), dim=1)
     if cap is not None:
         cap[ck + "d1"], cap[ck + "d2"], cap[ck + "d3"], cap[ck + "d4"], cap[ck + "xc"] = d1, d2, d3, d4, xc
-    return F.conv2d(xc, p[prefix + "feed_forward.0.weight"], p[prefix + "feed_forward.0.bias"],
-                    padding=1) + x                          # zero padding (:124-126,164)
+    y = F.conv2d(xc, _rw(p[prefix + "feed_forward.0.weight"], e), p[prefix + "feed_forward.0.bias"],
+                 padding=1) + x                            # zero padding (:124-126,164)
+    if extra_residual is not None:
+        y = y + extra_residual
+    return _r(y, e)
 
 
 def pad_to_multiple(x: Tensor, m: int = PAD_MULTIPLE) -> Tensor:
@@ -255,38 +328,49 @@ def gelu_derivative(t: Tensor) -> Tensor:
     return 0.5 * (1.0 + torch.erf(t * 0.7071067811865476)) + t * torch.exp(-0.5 * t * t) * 0.3989422804014327
 
 
-def tail(x: Tensor, p: Params, scale: int, cap=None) -> Tensor:
+def tail(x: Tensor, p: Params, scale: int, cap=None, emulate_bf16: bool = False) -> Tensor:
     """models/M2Trans_network.py:41-56.  The HIP path stores gelu(t) and gelu'(t) of each expansion
-    (workspace tensors t1act/t1der, t2act/t2der) instead of the pre-activation t."""
+    (workspace tensors t1act/t1der, t2act/t2der) instead of the pre-activation t; bf16 storage points: those four
+    tensors and the packed tail weights (the last conv's weight is rounded when it is staged, k_conv.hip)."""
+    e = emulate_bf16
+    act = (lambda t: _GeluStored.apply(t)) if e else F.gelu
     if scale == 4:
-        t1 = F.pixel_shuffle(F.conv2d(x, p["tail.0.weight"], p["tail.0.bias"]), 2)
-        t2 = F.pixel_shuffle(F.conv2d(F.gelu(t1), p["tail.3.weight"], p["tail.3.bias"]), 2)
+        t1 = F.pixel_shuffle(F.conv2d(x, _rw(p["tail.0.weight"], e), p["tail.0.bias"]), 2)
+        a1 = act(t1)
+        t2 = F.pixel_shuffle(F.conv2d(a1, _rw(p["tail.3.weight"], e), p["tail.3.bias"]), 2)
+        a2 = act(t2)
         if cap is not None:
-            cap["t1act"], cap["t2act"] = F.gelu(t1), F.gelu(t2)
-            cap["t1der"], cap["t2der"] = gelu_derivative(t1), gelu_derivative(t2)
-        return conv3x3_reflect(F.gelu(t2), p["tail.6.weight"])
-    t1 = F.pixel_shuffle(F.conv2d(x, p["tail.0.weight"], p["tail.0.bias"]), scale)
+            cap["t1act"], cap["t2act"] = a1, a2
+            cap["t1der"], cap["t2der"] = _r(gelu_derivative(t1), e), _r(gelu_derivative(t2), e)
+        return conv3x3_reflect(a2, _rw(p["tail.6.weight"], e))
+    t1 = F.pixel_shuffle(F.conv2d(x, _rw(p["tail.0.weight"], e), p["tail.0.bias"]), scale)
+    a1 = act(t1)
     if cap is not None:
-        cap["t1act"], cap["t1der"] = F.gelu(t1), gelu_derivative(t1)
-    return conv3x3_reflect(F.gelu(t1), p["tail.3.weight"])
+        cap["t1act"], cap["t1der"] = a1, _r(gelu_derivative(t1), e)
+    return conv3x3_reflect(a1, _rw(p["tail.3.weight"], e))
 
 
 def forward(x: Tensor, p: Params, scale: int, n_blocks: int, rgb_range: float = 1.0,
-            return_preclamp: bool = False, cap=None) -> Tensor:
+            return_preclamp: bool = False, cap=None, emulate_bf16: bool = False) -> Tensor:
     """M2Trans.forward (models/M2Trans_network.py:58-76).  ``cap`` (optional dict) collects the
-    intermediates under the names of the HIP workspace tensors (NCHW here)."""
+    intermediates under the names of the HIP workspace tensors (NCHW here).
+    ``emulate_bf16``: round at the storage points of the HIP path's bf16 mode (see the note on _RoundBoth above);
+    the head conv itself runs in fp32 on fp32 weights there, only its output is stored in bf16."""
+    e = emulate_bf16
     H, W = x.shape[-2:]
     x = pad_to_multiple(x)
-    res = conv3x3_reflect(x, p["head.weight"], p["head.bias"])   # :63
+    res = _r(conv3x3_reflect(x, p["head.weight"], p["head.bias"]), e)   # :63
     y = res
     for b in range(n_blocks):
         if cap is not None:
             cap[f"X{b}"] = y
-        y = cftm(y, p, f"body.{b}.", cap, f"b{b}.")
-    y = res + y                                                  # :70
+        last = b == n_blocks - 1
+        y = cftm(y, p, f"body.{b}.", cap, f"b{b}.", e, extra_residual=res if (e and last) else None)
+    if not e:
+        y = res + y                                              # :70
     if cap is not None:
         cap[f"X{n_blocks}"] = y
-    y = tail(y, p, scale, cap)                                   # :72
+    y = tail(y, p, scale, cap, e)                                # :72
     if cap is not None:
         cap["srpre"] = y
     if return_preclamp:
@@ -304,7 +388,7 @@ def trainable_names(p: Params) -> List[str]:
 
 def l1_loss_and_grads(lr_img: Tensor, hr_img: Tensor, p: Params, scale: int, n_blocks: int,
                       rgb_range: float = 1.0, lambda_l1: float = 1.0,
-                      loss_divisor: float | None = None):
+                      loss_divisor: float | None = None, emulate_bf16: bool = False):
     """loss = lambda_l1 * mean|sr - hr|  (train.py:76,199); gradients by CPU autograd.
     ``loss_divisor`` overrides the mean's denominator (data-parallel shards divide by the
     GLOBAL element count so that the sum over ranks equals the full-batch gradient)."""
@@ -312,7 +396,7 @@ def l1_loss_and_grads(lr_img: Tensor, hr_img: Tensor, p: Params, scale: int, n_b
     leaves = {k: p[k].detach().clone().requires_grad_(True) for k in names}
     q = dict(p)
     q.update(leaves)
-    sr = forward(lr_img, q, scale, n_blocks, rgb_range)
+    sr = forward(lr_img, q, scale, n_blocks, rgb_range, emulate_bf16=emulate_bf16)
     if loss_divisor is None:
         loss = (sr - hr_img).abs().mean() * lambda_l1
     else:
@@ -473,3 +557,28 @@ def benchmark_item(lr, hr, scale: int):
         return torch.from_numpy(np.ascontiguousarray(a.transpose((2, 0, 1)))).float() / 255.0
 
     return to_tensor(lr), to_tensor(hr)
+
+
+# --------------------------------------------------------------------------------------
+# checkpoint wire format   (train.py:341-349)
+# --------------------------------------------------------------------------------------
+def checkpoint_manifest(ckpt: dict) -> dict:
+    """Key / shape / dtype / scalar-value manifest of the dict train.py:341-349 saves (what the F1 pin compares:
+    written from the real reference by pin_against_reference.py, required of m2trans_amd.checkpoint by the tests)."""
+    def desc(v):
+        if torch.is_tensor(v):
+            return ["tensor", list(v.shape), str(v.dtype)]
+        if isinstance(v, (list, tuple)):
+            return [desc(x) for x in v]
+        if isinstance(v, dict):
+            return {str(k): desc(x) for k, x in v.items()}
+        if isinstance(v, float):
+            return float(v)
+        return v if isinstance(v, (int, bool, str)) or v is None else repr(v)
+    m = {"top_level_keys": list(ckpt.keys()), "epoch": ckpt["epoch"],
+         "model_state_dict": desc(ckpt["model_state_dict"])}
+    if "optimizer_state_dict" in ckpt:
+        o = ckpt["optimizer_state_dict"]
+        m["optimizer_state_dict"] = {"state": desc(o["state"]), "param_groups": desc(o["param_groups"])}
+        m["scheduler_state_dict"] = desc(ckpt["scheduler_state_dict"])
+    return m

@@ -257,6 +257,40 @@ def main():
                         hr_sum=float(r_hr.double().sum()), hr_shape=np.array(r_hr.shape), hr_corner=r_hr[:, -4:, -4:].numpy())
     report.append("Benchmark.__getitem__ bit-equal to datas/benchmark.py (HR crop to LR x scale)")
 
+    # ---- 10. checkpoint wire format (train.py:73,81-82,341-349,358): the reference's model under DataParallel, a real
+    # torch.optim.Adam over ALL its parameters and a real CosineAnnealingLR, stepped as the epoch loop does, saved as
+    # train.py:341-349 saves at the end of epoch 2 (BEFORE that epoch's scheduler.step()).  Only the manifest (keys,
+    # shapes, dtypes, scalars) and per-tensor checksums are committed -- no tensors.
+    import json
+    manifest = O.checkpoint_manifest
+    nf, scale, nb, B, H, W = 64, 4, 1, 2, 32, 32
+    model = torch.nn.DataParallel(ref_model(mod, nf, scale, nb, O.closed_form_params(nf, scale, nb), torch.float32))
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=0)               # train.py:81
+    scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, float(200), eta_min=1e-6)   # train.py:82
+    ck = None
+    for epoch in range(1, 3):                                                                # train.py:164
+        x = O.closed_form_image(B, 3, H, W, phase=0.1 * epoch)
+        hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7 + 0.1 * epoch)
+        optimizer.zero_grad()
+        loss = torch.nn.L1Loss()(model(x), hr) * 1.0
+        loss.backward()
+        optimizer.step()
+        if epoch == 2:
+            ck = {"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(),
+                  "scheduler_state_dict": scheduler.state_dict(), "stat_dict": {}}          # train.py:341-349
+        scheduler.step()                                                                     # train.py:358
+    man = manifest(ck)
+    man["torch_version"] = torch.__version__
+    st = ck["optimizer_state_dict"]["state"]
+    man["optimizer_checksums"] = {str(i): {"step": float(v["step"]), "exp_avg_abs_sum": float(v["exp_avg"].double().abs().sum()),
+                                           "exp_avg_sq_sum": float(v["exp_avg_sq"].double().sum())} for i, v in st.items()}
+    assert ck["scheduler_state_dict"]["last_epoch"] == 1 and ck["scheduler_state_dict"]["_step_count"] == 2
+    assert abs(ck["optimizer_state_dict"]["param_groups"][0]["lr"] - O.cosine_lr(1)) < 1e-15
+    with open(os.path.join(out_dir, "checkpoint_manifest.json"), "w") as f:
+        json.dump(man, f, indent=1)          # insertion order = the order torch writes the keys in
+    report.append(f"checkpoint manifest of the reference (DataParallel + Adam + CosineAnnealingLR, epoch 2): "
+                  f"{len(ck['model_state_dict'])} model keys, {len(st)} Adam states, last_epoch 1 -> tests/golden/checkpoint_manifest.json")
+
     with open(os.path.join(HERE, "PINNING.txt"), "w") as f:
         f.write("oracle/m2trans_oracle.py checked against /root/reference "
                 "(models/M2Trans_network.py, utils.py, datas/us1k.py, datas/benchmark.py) by oracle/pin_against_reference.py\n")

@@ -137,61 +137,28 @@ def test_train_two_steps_vs_reference_golden(golden_dir):
         assert float((got - want).abs().max()) < 0.05 * 2e-4, name     # 5 % of the 2-step update size
 
 
-def test_bf16_forward_and_grads_close_to_fp32_oracle():
-    """bf16 MFMA mode (fp32 accumulate / statistics / softmax / master weights): stated
-    tolerance vs the fp32 oracle: output rel-rms <= 3e-2, every gradient tensor rel-rms <= 0.15."""
-    scale, nb, B, H, W = 4, 2, 2, 32, 32
-    model, p = build_model(scale, nb, "bf16")
-    x = O.closed_form_image(B, 3, H, W)
-    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7)
-    loss_o, sr_o, g_o = O.l1_loss_and_grads(x, hr, p, scale, nb)
-    sr = model(x.cuda())
-    loss = torch.nn.L1Loss()(sr, hr.cuda())
-    loss.backward()
-    # Stated bf16 tolerance (measured on MI355X, this configuration): output rel-rms 3.2e-2 (the
-    # network output is ~1e-2 in magnitude with 54 % of the pixels on the clamp floor, so tiny
-    # perturbations flip clamp-mask entries of the L1 seed); whole-gradient cosine >= 0.99; each
-    # tensor's error norm <= 25 % of its own norm or <= 1 % of the whole gradient's norm (tensors
-    # whose gradient is a sum with heavy cancellation, e.g. block-0 rel_h, are tiny in norm).
-    assert rms_rel(sr, sr_o) < 5e-2
-    assert abs(float(loss.detach()) - float(loss_o)) < 2e-2 * abs(float(loss_o)) + 1e-4
-    names = [n for n, q in model.named_parameters() if q.requires_grad]
-    got = torch.cat([dict(model.named_parameters())[n].grad.reshape(-1).double().cpu() for n in names])
-    want = torch.cat([g_o[n].reshape(-1).double() for n in names])
-    cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
-    gnorm = float(want.norm())
-    rows, bad = [], []
-    for n, q in model.named_parameters():
-        if not q.requires_grad:
-            continue
-        err = float((q.grad.double().cpu() - g_o[n].double()).norm())
-        nrm = float(g_o[n].double().norm())
-        rows.append((n, err / (nrm + 1e-30), err / gnorm))
-        if not (err <= 0.25 * nrm or err <= 0.01 * gnorm):
-            bad.append(n)
-    table = "\n".join(f"{n:40s} rel {a:.3e}  of-total {b:.3e}" for n, a, b in rows)
-    assert cos > 0.99, (cos, table)
-    assert not bad, (bad, table)
-
-
-@pytest.mark.parametrize("scale", [2, 3])
-def test_bf16_other_scales_close_to_fp32_oracle(scale):
-    """The x2 / x3 tails (one expansion with r = 2 / 3, unfused tail backward) in bf16 mode against the fp32 oracle,
-    same stated tolerance as the x4 test: output rel-rms <= 5e-2, whole-gradient cosine >= 0.99."""
-    nb, B, H, W = 2, 2, 32, 32
-    model, p = build_model(scale, nb, "bf16")
-    x = O.closed_form_image(B, 3, H, W)
-    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7)
-    loss_o, sr_o, g_o = O.l1_loss_and_grads(x, hr, p, scale, nb)
-    sr = model(x.cuda())
-    loss = torch.nn.L1Loss()(sr, hr.cuda())
-    loss.backward()
-    assert rms_rel(sr, sr_o) < 5e-2
-    names = [n for n, q in model.named_parameters() if q.requires_grad]
-    got = torch.cat([dict(model.named_parameters())[n].grad.reshape(-1).double().cpu() for n in names])
-    want = torch.cat([g_o[n].reshape(-1).double() for n in names])
-    cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
-    assert cos > 0.99, cos
+def test_bf16_forward_close_to_fp32_oracle():
+    """bf16 MFMA mode (fp32 accumulate / statistics / softmax / master weights) against the FP32 oracle, i.e. the size of
+    the bf16 effect itself: output rel-rms <= 5e-2, loss <= 2 %, whole-gradient cosine >= 0.99 (x2 / x3 / x4).  The
+    per-tensor gradient gate is in tests/test_gpu_baseline_configs.py::test_bf16_small_model_against_bf16_rounding_oracle,
+    against the oracle that rounds to bf16 at the same storage points (<= 2e-2 per tensor instead of the 25 % a comparison
+    with un-rounded arithmetic needs)."""
+    for scale in (4, 2, 3):
+        nb, B, H, W = 2, 2, 32, 32
+        model, p = build_model(scale, nb, "bf16")
+        x = O.closed_form_image(B, 3, H, W)
+        hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7)
+        loss_o, sr_o, g_o = O.l1_loss_and_grads(x, hr, p, scale, nb)
+        sr = model(x.cuda())
+        loss = torch.nn.L1Loss()(sr, hr.cuda())
+        loss.backward()
+        assert rms_rel(sr, sr_o) < 5e-2
+        assert abs(float(loss.detach()) - float(loss_o)) < 2e-2 * abs(float(loss_o)) + 1e-4
+        names = [n for n, q in model.named_parameters() if q.requires_grad]
+        got = torch.cat([dict(model.named_parameters())[n].grad.reshape(-1).double().cpu() for n in names])
+        want = torch.cat([g_o[n].reshape(-1).double() for n in names])
+        cos = float(torch.dot(got, want) / (got.norm() * want.norm()))
+        assert cos > 0.99, (scale, cos)
 
 
 def test_bf16_fast_kernels_match_plain_kernels():
@@ -358,3 +325,83 @@ def test_training_is_bitwise_reproducible_with_the_two_stream_schedule():
         finals.append((float(loss), model.flat_params.detach().clone(), ts.exp_avg.clone(), ts.exp_avg_sq.clone()))
     (la, pa, ma, va), (lb, pb, mb, vb) = finals
     assert la == lb and torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
+def test_checkpoint_resume_is_bit_identical():
+    """F1 (train.py:92-108,341-349): 2 steps -> export_checkpoint -> (through torch.save / torch.load) -> a FRESH model and
+    TrainStep -> import_checkpoint -> 2 more steps must equal 4 uninterrupted steps bit for bit (weights, both Adam
+    moments, step count), in bf16 mode with the two-stream schedule live."""
+    import io
+    from m2trans_amd.checkpoint import export_checkpoint, import_checkpoint
+    from m2trans_amd.train_step import TrainStep, cosine_lr
+    scale, nb, B, H, W = 4, 2, 2, 64, 64
+    data = [(O.closed_form_image(B, 3, H, W, phase=0.2 * s).cuda(),
+             O.closed_form_image(B, 3, H * scale, W * scale, phase=0.5 + 0.2 * s).cuda()) for s in range(4)]
+    model, _ = build_model(scale, nb, "bf16")
+    ts = TrainStep(model, lr=cosine_lr(2), world_size=1)
+    for s in range(4):
+        ts.step(*data[s])
+    torch.cuda.synchronize()
+    want = (model.flat_params.clone(), ts.exp_avg.clone(), ts.exp_avg_sq.clone())
+    model_a, _ = build_model(scale, nb, "bf16")
+    ts_a = TrainStep(model_a, lr=cosine_lr(2), world_size=1)
+    for s in range(2):
+        ts_a.step(*data[s])
+    buf = io.BytesIO()
+    torch.save(export_checkpoint(model_a, ts_a, epoch=3), buf)
+    buf.seek(0)
+    ck = torch.load(buf, weights_only=False)
+    assert ck["scheduler_state_dict"]["last_epoch"] == 2 and abs(ck["optimizer_state_dict"]["param_groups"][0]["lr"] - cosine_lr(2)) < 1e-18
+    model_b, _ = build_model(scale, nb, "bf16", params=O.closed_form_params(64, scale, nb, gain=0.5))   # different weights
+    ts_b = TrainStep(model_b, lr=1.0, world_size=1)
+    assert import_checkpoint(ck, model_b, ts_b) == 4
+    assert ts_b.step_count == 2 and ts_b.lr == cosine_lr(2) and ts_b.scheduler_last_epoch == 2
+    for s in range(2, 4):
+        ts_b.step(*data[s])
+    torch.cuda.synchronize()
+    assert torch.equal(model_b.flat_params, want[0]) and torch.equal(ts_b.exp_avg, want[1]) and torch.equal(ts_b.exp_avg_sq, want[2])
+
+
+def test_two_rank_data_parallel_over_rccl_when_two_gpus_are_visible():
+    """tools/dp2_check.py under torch.distributed.run with one rank per GPU over RCCL: overlapped == plain exchange bit
+    for bit, replicas identical, DP == single-process full batch.  Skipped on the 1-GPU boxes (there the same tool
+    runs both ranks on one GPU over gloo: `tools/run_tests_bench.sh`)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", M2T_DP_BACKEND="nccl")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(root, "tools", "dp2_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "overlap == plain: True" in r.stdout
+
+
+def test_autograd_path_accepts_non_contiguous_and_half_inputs():
+    """The kernels read raw contiguous fp32 NCHW memory; model(x) under autograd must therefore convert once and hand
+    the CONVERTED tensor to m2t_backward too (the head weight gradient re-reads the input): a channels_last view and a
+    float64 copy of the same values must give the gradients of the plain tensor bit for bit."""
+    scale, nb, B, H, W = 4, 1, 2, 32, 32
+    x = O.closed_form_image(B, 3, H, W).cuda()
+    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+    outs = []
+    for variant in ("plain", "channels_last", "float64", "sliced"):
+        model, _ = build_model(scale, nb, "fp32")
+        if variant == "plain":
+            xi = x
+        elif variant == "channels_last":
+            xi = x.to(memory_format=torch.channels_last)
+            assert not xi.is_contiguous()
+        elif variant == "float64":
+            xi = x.double()
+        else:
+            big = torch.zeros(B, 3, H, 2 * W, device="cuda")
+            big[..., ::2] = x
+            xi = big[..., ::2]
+            assert not xi.is_contiguous()
+        torch.nn.L1Loss()(model(xi), hr).backward()
+        outs.append({n: q.grad.clone() for n, q in model.named_parameters() if q.requires_grad})
+    for o in outs[1:]:
+        for n in outs[0]:
+            assert torch.equal(o[n], outs[0][n]), n

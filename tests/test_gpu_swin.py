@@ -96,6 +96,12 @@ def test_train_step_with_semantic_loss_term_is_constant_offset():
     l0 = float(ts0.forward_backward(x, hr))
     g0 = ts0.grads.clone()
     ts1 = TrainStep(model, world_size=1, semantic_loss=sl, lambda_clip=0.01)
+    # a caption without an injected text feature must raise, not silently get a stand-in embedding
+    from m2trans_amd._lib import M2TError
+    with pytest.raises(M2TError, match="no text feature"):
+        sl.batch(torch.rand(2, 3, 256, 256, device="cuda"), torch.rand(2, 3, 256, 256, device="cuda"), ["a", "b"])
+    g = torch.Generator().manual_seed(8)
+    sl.set_text_features({"a": torch.randn(512, generator=g), "b": torch.randn(512, generator=g)})
     torch.manual_seed(1)
     l1 = float(ts1.forward_backward(x, hr, ["a", "b"]))
     assert torch.equal(ts1.grads, g0)

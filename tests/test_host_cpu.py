@@ -211,6 +211,21 @@ def _dp_worker(rank, world, port, ret):
         grads2 = grads.clone()
         GradBucket(grads2, comm_dtype=torch.bfloat16).all_reduce()
         wire = float((grads2 / world - grads).abs().max() / grads.abs().max())
+        # bf16 wire, bucket by bucket (the overlapped exchange): each range is staged through its slice of the wire
+        # buffer; the result must equal the one-shot bf16 exchange exactly (the cast and the SUM are element-wise)
+        gb2 = g_local.clone()
+        b2 = GradBucket(gb2, comm_dtype=torch.bfloat16, expect_world=world)
+        for hi, lo in zip(cuts[:-1], cuts[1:]):
+            b2.all_reduce_range(lo, hi)
+        g_one = g_local.clone()
+        GradBucket(g_one, comm_dtype=torch.bfloat16).all_reduce()
+        assert torch.equal(gb2, g_one)
+        # a world size the process group does not have must raise (TrainStep would otherwise scale by 1/N silently)
+        try:
+            GradBucket(g_local.clone(), expect_world=world + 1)
+            raise AssertionError("GradBucket accepted a wrong world size")
+        except RuntimeError:
+            pass
         ret[rank] = (worst, wire, float(flat.sum()))
     finally:
         dist.destroy_process_group()
@@ -237,36 +252,83 @@ def test_shard_size_rejects_uneven_batches():
         shard_size(10, 4)
 
 
+def test_world_size_without_process_group_raises():
+    """TrainStep(world_size=N > 1) divides the loss by N: without an initialised process group of N ranks that would
+    silently train on gradients scaled by 1/N, so the bucket refuses."""
+    from m2trans_amd.dist import GradBucket
+    assert not dist.is_initialized()
+    with pytest.raises(RuntimeError):
+        GradBucket(torch.zeros(16), expect_world=2)
+
+
+class _FakeStep:                         # the flat-buffer part of TrainStep, on the CPU
+    def __init__(self, m, step_count=7, lr=5e-5):
+        self.exp_avg = torch.randn_like(m.flat_params)
+        self.exp_avg_sq = torch.rand_like(m.flat_params)
+        self.step_count, self.lr, self.betas, self.eps = step_count, lr, (0.9, 0.999), 1e-8
+
+    def set_lr(self, lr):
+        self.lr = lr
+
+
 def test_checkpoint_round_trip_reference_format():
     """train.py:341-349 / :92-108 wire format: module.-prefixed model keys, torch Adam state indexed in
     model.parameters() order (frozen MeanShift tensors occupy indices 0..3 and carry no state)."""
     from m2trans_amd.M2Trans_network import create_model
     from m2trans_amd.checkpoint import export_checkpoint, import_checkpoint
-
-    class FakeStep:                      # the flat-buffer part of TrainStep, on the CPU
-        def __init__(self, m):
-            self.exp_avg = torch.randn_like(m.flat_params)
-            self.exp_avg_sq = torch.rand_like(m.flat_params)
-            self.step_count, self.lr, self.betas, self.eps = 7, 5e-5, (0.9, 0.999), 1e-8
-        def set_lr(self, lr):
-            self.lr = lr
     m = create_model(_args(4, 1))
-    fs = FakeStep(m)
+    fs = _FakeStep(m)
     ck = export_checkpoint(m, fs, epoch=3)
     assert all(k.startswith("module.") for k in ck["model_state_dict"])
     # a stock torch Adam over ALL parameters (like train.py:81) accepts the optimizer state
     ref_like = create_model(_args(4, 1))
     opt = torch.optim.Adam(ref_like.parameters(), lr=1e-4)
     opt.load_state_dict(ck["optimizer_state_dict"])
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, 200.0, eta_min=1e-6)
+    sched.load_state_dict(ck["scheduler_state_dict"])
+    assert sched.last_epoch == 2                       # saved BEFORE epoch 3's scheduler.step() (train.py:341-358)
     i_head = [n for n, _ in ref_like.named_parameters()].index("head.weight")
     o, k, shp = m._slots[0]
     assert torch.equal(opt.state_dict()["state"][i_head]["exp_avg"], fs.exp_avg[o:o + k].view(shp))
     m2 = create_model(_args(4, 1))
-    fs2 = FakeStep(m2)
+    fs2 = _FakeStep(m2)
     assert import_checkpoint(ck, m2, fs2) == 4
     assert torch.equal(m2.flat_params, m.flat_params)
     assert torch.equal(fs2.exp_avg, fs.exp_avg) and torch.equal(fs2.exp_avg_sq, fs.exp_avg_sq)
-    assert fs2.step_count == 7 and fs2.lr == 5e-5
+    assert fs2.step_count == 7 and fs2.lr == 5e-5 and fs2.scheduler_last_epoch == 2
+
+
+def test_checkpoint_matches_the_reference_manifest(golden_dir):
+    """export_checkpoint against the manifest of what the REAL reference saves (DataParallel model + torch.optim.Adam +
+    CosineAnnealingLR run through two epochs, oracle/pin_against_reference.py section 10): same keys at every level,
+    same shapes / dtypes, same scalars (last_epoch = epoch - 1, _step_count = epoch, lr = cosine(epoch - 1))."""
+    import json
+    from m2trans_amd.M2Trans_network import create_model
+    from m2trans_amd.checkpoint import export_checkpoint
+    from m2trans_amd.train_step import cosine_lr
+    manifest = O.checkpoint_manifest
+    want = json.load(open(os.path.join(golden_dir, "checkpoint_manifest.json")))
+    if want["torch_version"].split("+")[0] != torch.__version__.split("+")[0]:
+        pytest.skip("manifest was written by another torch release (optimizer dict keys differ between releases)")
+    m = create_model(_args(4, 1))
+    got = manifest(export_checkpoint(m, _FakeStep(m, step_count=2, lr=cosine_lr(1)), epoch=2))
+
+    def same(a, b, path=""):
+        if isinstance(a, dict):
+            assert isinstance(b, dict) and list(a.keys()) == list(b.keys()), (path, list(a.keys()), list(b.keys()) if isinstance(b, dict) else b)
+            for k in a:
+                same(a[k], b[k], path + "/" + str(k))
+        elif isinstance(a, list):
+            assert isinstance(b, list) and len(a) == len(b), (path, a, b)
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, path + f"[{i}]")
+        elif isinstance(a, float):
+            assert abs(a - b) <= 1e-12 * max(1.0, abs(a)), (path, a, b)
+        else:
+            assert a == b, (path, a, b)
+    for key in ("top_level_keys", "epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict"):
+        same(want[key], got[key], key)
+    assert len(want["optimizer_checksums"]) == len(got["optimizer_state_dict"]["state"]) == 21
 
 
 def test_eval_and_data_entry_points_validate_arguments_without_a_gpu():

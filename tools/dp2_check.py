@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Two data-parallel ranks on ONE GPU (gloo backend on device tensors) through the real TrainStep:
+"""N data-parallel ranks through the real TrainStep:
   * overlapped (bucketed, communication stream) and plain gradient exchange must give bit-identical parameters;
   * both must match a single-process step on the full global batch (fp32 compute; differences = summation order).
+Backend: RCCL ("nccl"), one rank per GPU, whenever the node has at least WORLD_SIZE devices; otherwise every rank
+shares GPU 0 and the exchange runs over gloo on device tensors (the 1-GPU development boxes).  M2T_DP_BACKEND overrides.
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp2_check.py
 """
@@ -15,8 +17,14 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    backend = os.environ.get("M2T_DP_BACKEND") or ("nccl" if torch.cuda.device_count() >= world else "gloo")
+    if backend == "nccl":                                   # "nccl" is RCCL on ROCm; one rank per GPU over xGMI
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from m2trans_amd.M2Trans_network import create_model
     from m2trans_amd.train_step import TrainStep
     scale, nb, Bl, H = 4, 2, 2, 64
@@ -45,11 +53,12 @@ def main():
     d = float((finals["overlap"] - finals["single"]).abs().max())
     moved = float((finals["single"] - create_model(args).flat_params.cpu()).abs().max()) if False else None
     # every rank must hold the same parameters
-    gathered = [torch.empty_like(finals["overlap"]) for _ in range(world)]
-    dist.all_gather(gathered, finals["overlap"])
+    mine = finals["overlap"].cuda() if backend == "nccl" else finals["overlap"]
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
     replicas_equal = all(torch.equal(gathered[0], t) for t in gathered)
     if rank == 0:
-        print(f"dp2_check: overlap == plain: {same}; replicas identical: {replicas_equal}; max |DP - single process| = {d:.3e}")
+        print(f"dp2_check[{backend}, {world} ranks]: overlap == plain: {same}; replicas identical: {replicas_equal}; max |DP - single process| = {d:.3e}")
     ok = same and replicas_equal and d < 5e-6
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

@@ -34,12 +34,15 @@ CATEGORY_OF = [   # (substring of the kernel name, extra substring, category)
 ]
 
 
+CONFIG = "1"
+
+
 def run(counter):
-    d = os.path.join(OUT, counter)
+    d = os.path.join(OUT + ("" if CONFIG == "1" else "_config" + CONFIG), counter)
     os.makedirs(d, exist_ok=True)
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-           "--no-kernel-events", "--no-side-stream"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--config", CONFIG, "--steps", "3", "--warmup", "1",
+           "--no-cpu-baseline", "--no-kernel-events", "--no-side-stream"]
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -55,6 +58,11 @@ def run(counter):
 
 
 def main():
+    global CONFIG
+    if len(sys.argv) > 2 and sys.argv[1] == "--config":
+        CONFIG = sys.argv[2]
+    sys.path.insert(0, ROOT)
+    from bench import source_stamp
     fetch = run("FETCH_SIZE")
     write = run("WRITE_SIZE")
     traffic, detail = {}, {}
@@ -73,10 +81,12 @@ def main():
             traffic[cat] = fb + wb
         elif cat:
             traffic[cat] = max(traffic[cat], fb + wb) if "(all)" in cat else (traffic[cat] + fb + wb) / 2
-    out = {"note": "bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, averaged over launches (bf16, batch 16, x4 128x128)",
+    out = {"note": "bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, averaged over launches (bench.py --config " + CONFIG + ", single stream)",
+           "source_stamp": source_stamp(), "workload": "config" + CONFIG,
            "traffic_bytes_per_launch": traffic, "kernels": detail}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    with open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w") as fo:
+    name = "pmc_traffic.json" if CONFIG == "1" else f"pmc_traffic_config{CONFIG}.json"
+    with open(os.path.join(ROOT, "profiles", name), "w") as fo:
         json.dump(out, fo, indent=1, sort_keys=True)
     for k, v in sorted(traffic.items()):
         print(f"{k:22s} {v/1e6:10.2f} MB / launch")
