@@ -51,3 +51,28 @@ def ws_nchw(plan, name, B, H, W, C):
         t = t.view(4, B, H, W, 16).permute(1, 2, 3, 0, 4).reshape(B, H, W, 64)
         return nhwc_to_nchw(t.float()).cpu()
     return nhwc_to_nchw(t.view(B, H, W, C).float()).cpu()
+
+
+BR_C = (16, 64, 256, 256)
+BR_L = (0, 1, 2, 2)
+
+
+def hip_forward_trace(plan, scale, n_blocks, B, H, W):
+    """Every stored activation of the last m2t_forward, read back from the workspace as float32 NCHW on the CPU, under the
+    names the oracle's ``force`` / ``cap`` dicts use (H, W = padded LR size)."""
+    t = {"X0": ws_nchw(plan, "X0", B, H, W, 64)}
+    for b in range(n_blocks):
+        for i in range(4):
+            h, w = H >> BR_L[i], W >> BR_L[i]
+            t[f"b{b}.d{i+1}"] = ws_nchw(plan, f"b{b}.d{i+1}", B, h, w, BR_C[i])
+            t[f"b{b}.qkv{i+1}"] = ws_nchw(plan, f"b{b}.qkv{i+1}", B, h, w, 3 * BR_C[i])
+        t[f"b{b}.xc"] = ws_nchw(plan, f"b{b}.xc", B, H, W, 64)
+        t[f"X{b+1}"] = ws_nchw(plan, f"X{b+1}", B, H, W, 64)
+    r0 = 2 if scale == 4 else scale
+    for nm in ("t1act", "t1der"):
+        t[nm] = ws_nchw(plan, nm, B, H * r0, W * r0, 64)
+    if scale == 4:
+        for nm in ("t2act", "t2der"):
+            t[nm] = ws_nchw(plan, nm, B, H * 4, W * 4, 64)
+    t["srpre"] = plan.ws_tensor("srpre", dtype=torch.float32).view(B, 3, H * scale, W * scale).cpu().clone()
+    return t

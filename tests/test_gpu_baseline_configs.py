@@ -6,8 +6,14 @@ configs[4]  x3, 256x256 LR, bf16, batch 8 (the multi-tile `tpb > 1` schedule of 
 
 The oracle finishes the full-depth model at batch 2 (x4 128x128) / batch 1 (x3 256x256) in seconds, so every such
 test has two legs:
-  (a) small batch, HIP vs oracle: forward and EVERY parameter gradient (fp32 mode vs the fp32 restatement of the
-      reference; bf16 mode vs the same restatement with bf16 rounding at the HIP path's storage points);
+  (a) small batch, HIP vs oracle: forward and EVERY parameter gradient.  fp32 mode: against the fp32 restatement of the
+      reference, end to end.  bf16 mode: the network amplifies a bf16-sized perturbation ~2x per block, so two bf16
+      evaluations that differ only in fp32 summation order are 8 % apart after four blocks (measured; see the note in
+      oracle/m2trans_oracle.py) and an end-to-end bound says nothing.  Instead the oracle is TEACHER-FORCED: it rounds
+      to bf16 at the HIP path's storage points and, after computing each stored tensor from the HIP path's own
+      inputs, continues from the HIP path's value.  That yields (1) one kernel's worth of error for each of the ~80
+      stored tensors and (2) gradients along the HIP path's own forward trajectory, against which the HIP backward
+      differs only by its bf16 gradient storage;
   (b) the benchmarked batch = the small batch repeated: samples are independent (InstanceNorm per (b, c), attention per
       window, no atomics), so sr[0:small] must be BIT-equal to leg (a)'s output although the launch geometry (grid
       sizes, XCD-aware tile orders, tiles per workgroup, slab counts) is that of the benchmark, and with a common loss
@@ -60,30 +66,51 @@ def fmt(rows):
     return "\n".join(f"{n:40s} rel {a:.3e}  of-total {b:.3e}" for n, a, b in rows)
 
 
-def check_vs_oracle(scale, lr, B, dtype):
+# bf16 mode, stated tolerances.  Measured on MI355X (x4 128x128 nb 8, x3 256x256 nb 8, x2/x3/x4 32x32 nb 2): stored tensors
+# rel-rms <= 6.7e-5, max <= 7e-3 (1-2 bf16 ulps of the tensor's largest value: a rounding that fp32 summation order
+# flipped); sr 2e-7; gradient tensors 2e-3 typical (= 2^-9, the bf16 storage of the backward's gradient tensors),
+# qkv weights up to 3e-2 and rel-pos tables up to 8.5e-2 of their own norm at <= 3e-8 of the whole gradient.
+STAGE_RMS = 3e-4         # each stored tensor vs the oracle evaluated on the HIP path's inputs: rel-rms
+STAGE_MAX = 1.6e-2       # ... and max error / max value (2 bf16 ulps)
+GRAD_REL = 2e-2          # each parameter-gradient tensor: error norm / its own norm ...
+GRAD_OF_TOTAL = 1e-5     # ... or, for the near-cancelling sums (rel-pos tables, early qkv weights), error norm / norm of the whole gradient
+
+
+def check_vs_oracle(scale, lr, B, dtype, nb=8, verbose=True):
     """leg (a).  Returns what leg (b) needs."""
-    nb = 8
     model, p = build_model(scale, nb, dtype)
     x = O.closed_form_image(B, 3, lr, lr)
     hr = O.closed_form_image(B, 3, lr * scale, lr * scale, phase=0.7)
-    loss_o, sr_o, g_o = O.l1_loss_and_grads(x, hr, p, scale, nb, emulate_bf16=(dtype == "bf16"))
     sr, loss, grads = fwd_bwd(model, x.cuda(), hr.cuda(), hr.numel())
-    rows = grad_table(model, grads, g_o)
     if dtype == "fp32":
-        # SURVEY 8d: forward <= 1e-4, gradients: stated 5e-4 of each tensor's norm at full depth
+        loss_o, sr_o, g_o = O.l1_loss_and_grads(x, hr, p, scale, nb)
+        rows = grad_table(model, grads, g_o)
+        # SURVEY 8d: forward <= 1e-4; gradients: 5e-4 of each tensor's norm (1e-8 of the whole gradient for the rel-pos
+        # tensors whose gradient is a sum over every window that cancels to ~1e-7 of the total)
         assert rel(sr, sr_o) < 1e-4, rel(sr, sr_o)
         assert abs(loss - float(loss_o)) < 1e-5
-        bad = [r for r in rows if not r[1] < 5e-4]
+        bad = [r for r in rows if not (r[1] < 5e-4 or r[2] < 1e-8)]
+        stage_txt = ""
     else:
-        # bf16 mode against the restatement that rounds to bf16 at the same storage points: what is left is fp32
-        # summation order (plus the few elements it pushes across a rounding boundary).  Stated tolerance: output
-        # rel-rms <= 5e-3, each gradient tensor <= 2e-2 of its own norm (or <= 1e-3 of the whole gradient for the
-        # tensors whose gradient is a near-cancelling sum).
-        assert rms_rel(sr, sr_o) < 5e-3, rms_rel(sr, sr_o)
-        assert abs(loss - float(loss_o)) < 2e-3 * abs(float(loss_o))
-        bad = [r for r in rows if not (r[1] < 2e-2 or r[2] < 1e-3)]
-    print(f"x{scale} {lr}x{lr} B={B} {dtype}: sr rel {rel(sr, sr_o):.3e} rms {rms_rel(sr, sr_o):.3e}; worst gradient tensor "
-          f"{max(r[1] for r in rows):.3e} of its norm")
+        from tests.gpu_util import hip_forward_trace
+        plan = model._plan_for(x.cuda())
+        H, W = plan.query("padded_h"), plan.query("padded_w")
+        trace = hip_forward_trace(plan, scale, nb, B, H, W)
+        rep = {}
+        loss_o, sr_o, g_o = O.l1_loss_and_grads(x, hr, p, scale, nb, emulate_bf16=True, force=trace, stage_report=rep)
+        rows = grad_table(model, grads, g_o)
+        worst_rms = max(rep.items(), key=lambda kv: kv[1][1])
+        worst_max = max(rep.items(), key=lambda kv: kv[1][0])
+        stage_txt = f"; {len(rep)} stored tensors: worst rel-rms {worst_rms[1][1]:.2e} ({worst_rms[0]}), worst max {worst_max[1][0]:.2e} ({worst_max[0]})"
+        bad_stage = {k: v for k, v in rep.items() if not (v[1] < STAGE_RMS and v[0] < STAGE_MAX)}
+        assert not bad_stage, bad_stage
+        # the last stage: fp32 tail conv output, clamp and crop on the HIP path's own t2act / t1act
+        assert rel(sr, sr_o) < 2e-4, rel(sr, sr_o)
+        assert abs(loss - float(loss_o)) < 1e-4 * abs(float(loss_o))
+        bad = [r for r in rows if not (r[1] < GRAD_REL or r[2] < GRAD_OF_TOTAL)]
+    if verbose:
+        print(f"x{scale} {lr}x{lr} B={B} nb={nb} {dtype}: sr rel {rel(sr, sr_o):.3e}; worst gradient tensor "
+              f"{max(r[1] for r in rows):.3e} of its norm, {max(r[2] for r in rows):.3e} of the whole gradient" + stage_txt)
     assert not bad, fmt(rows)
     return model, x, hr, sr, grads
 
@@ -183,16 +210,8 @@ def test_config2_x4_batch32_with_semantic_loss():
 
 def test_bf16_small_model_against_bf16_rounding_oracle():
     """The tightened bf16 gate (replaces the 25 % / 1 % per-tensor gate against the fp32 oracle): bf16 mode at x2 / x3 / x4
-    on the small configurations against the oracle with bf16 rounding at the HIP path's storage points; stated
-    tolerance per gradient tensor: <= 2e-2 of its own norm (or <= 1e-3 of the whole gradient)."""
+    on the small configurations against the teacher-forced bf16-rounding oracle: every stored tensor within
+    STAGE_RMS / STAGE_MAX of the oracle evaluated on the same inputs, every gradient tensor within GRAD_REL of its norm
+    (or GRAD_OF_TOTAL of the whole gradient)."""
     for scale in (4, 2, 3):
-        nb, B, H, W = 2, 2, 32, 32
-        model, p = build_model(scale, nb, "bf16")
-        x = O.closed_form_image(B, 3, H, W)
-        hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7)
-        loss_o, sr_o, g_o = O.l1_loss_and_grads(x, hr, p, scale, nb, emulate_bf16=True)
-        sr, loss, grads = fwd_bwd(model, x.cuda(), hr.cuda(), hr.numel())
-        rows = grad_table(model, grads, g_o)
-        assert rms_rel(sr, sr_o) < 5e-3, (scale, rms_rel(sr, sr_o))
-        bad = [r for r in rows if not (r[1] < 2e-2 or r[2] < 1e-3)]
-        assert not bad, (scale, fmt(rows))
+        check_vs_oracle(scale, 32, 2, "bf16", nb=2)
