@@ -62,6 +62,8 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "tail_wgrad_main"   [0] 1: tail weight gradients on the caller's stream instead of the side stream (0.5 % slower)
  *   "fused_tail_bwd"    [1] bf16 x4: one fused kernel for the high-resolution half of the tail backward
  *   "resident_attn_bwd" [1] bf16: whole-window-resident / wave-per-window attention backward kernels
+ *   "fused_attn_fwd"    [1] bf16, C = 64 / 256 branches: qkv projection + window attention + IWT / residual epilogue in one
+ *                           kernel per window (k_attn_fused.hip) instead of a GEMM launch + an attention launch
  *   "persistent_conv"   [0] bf16: conv3x3 with LDS-resident weights (bit-identical, measured slower)
  *   "side_cus"          [0] CU mask size of the side stream (0 = all CUs; masking measured slower); set before the
  *                           first m2t_backward, and only effective when the caller's stream is not the NULL stream

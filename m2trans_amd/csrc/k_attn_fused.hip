@@ -1,0 +1,452 @@
+// k_attn_fused.hip -- TBlock.forward in ONE kernel per window (bf16, C = 64 / 256): the 1x1 qkv projection
+// (models/M2Trans_network.py:281,307-308), the 8x8 / 10x10 halo window attention with the relative-position key bias
+// (:310-332) and the branch epilogue xc = IWT^L(attention) + xin (:145,153,161).  q | k | v of the window's own 64
+// pixels are still written out (the backward kernels recompute P from them), but they are never re-read here: the
+// 3C-wide round trip through HBM between `gemm_nt_wide_kernel` and the attention kernel (50 MB per launch at C = 256,
+// batch 16) and the second launch are gone.
+//
+// Why one workgroup per window: at the benchmarked size the C = 256 branches have 256 windows -- one per CU.  The K / V
+// rows of the 36 halo pixels are projected redundantly (x1.56 on the K and V thirds: 100 instead of 64 rows).
+//
+// Data flow (C = 256, 8 waves; C = 64: 4 waves, two workgroups per CU):
+//   phase 0  x rows of the 100 key pixels -> LDS Xs (zero rows outside the image: the projection of a zero row is the
+//            zero padding F.unfold applies to k and v, :313); keys are ordered own-pixels-first, so key j = query j for
+//            j < 64 and the first four 16-row tiles serve the q projection too.
+//   phase 1  K^T and Q^T tiles: weight rows are the MFMA A operand, taken straight from L2 in fragment order
+//            (M2T_PACK_FRAG16: one contiguous 1 KB per wave load) and held in registers -- wave w owns output channels
+//            [32 w, 32 w + 32) of q, k and v -- pixels are the B operand from Xs.  k -> HBM (raw) and, + rel-pos, -> LDS
+//            Kh (bf16(bf16(k) + rel): the rounding points of the unfused kernels); q -> HBM and LDS Qs.
+//   phase 2  waves 0..3: S^T = K^ Q^T, softmax over the 100 keys in registers, P -> LDS (bf16);
+//            all waves: the V projection into registers (its LDS home is Kh's, which S is still reading).
+//   phase 3  V -> LDS (over Kh) and HBM.
+//   phase 4  O^T = V^T P^T for the wave's channels x all 64 queries -> LDS (fp32, over Xs | Qs).
+//   phase 5  epilogue: IWT^L over the 4^L bands of each base channel + residual, stored to the full-resolution
+//            chunk of xc.
+// LDS (C = 256): Xs 53 328 + Qs 33 792 + Kh|Vs 53 328 + P 17 408 = 157 856 B.
+#include "m2t_kernels.h"
+#include "m2t_haar.h"
+#include "m2t_window.h"
+
+#ifndef M2T_FUSED_STAMP
+#define M2T_FUSED_STAMP(i) do { } while (0)      // scratch/bench_fused.hip defines it to record s_memtime per phase
+#endif
+
+namespace {
+
+// key order of this kernel: 0..63 the window's own pixels (= query order), 64..99 the ring in ring_index order
+__device__ __forceinline__ void fused_key_rc(int k, int& kr, int& kc) {
+  // branch-free (selects): the callers issue loads whose addresses depend on the result
+  const int r = k - 64;
+  const int kr_ring = (r < 10) ? 0 : ((r < 20) ? 9 : ((r < 28) ? r - 19 : r - 27));
+  const int kc_ring = (r < 10) ? r : ((r < 20) ? r - 10 : ((r < 28) ? 0 : 9));
+  kr = (k < 64) ? (k >> 3) + 1 : kr_ring;
+  kc = (k < 64) ? (k & 7) + 1 : kc_ring;
+}
+
+template <int C> struct FusedCfg {
+  static constexpr int LD = C + 8;          // bf16 rows of Xs / Qs / Kh|Vs
+  static constexpr int PLD = 128 + 8;       // P [query][key 0..127]
+  static constexpr int OLD = C + 4;         // O [query][channel] fp32
+  static constexpr int ZR = 100;            // the zero row of Xs and Kh|Vs (every padding key aliases it)
+  static constexpr size_t szX = sizeof(bf16_t) * 101 * LD;
+  static constexpr size_t szQ = sizeof(bf16_t) * 64 * LD;
+  static constexpr size_t szP = sizeof(bf16_t) * 64 * PLD;
+  static constexpr size_t offX = 0, offQ = szX, offKV = szX + szQ, offP = offKV + szX;
+  static constexpr size_t total = offP + szP;
+  static_assert(sizeof(float) * 64 * OLD <= szX + szQ, "the fp32 O tile overlays Xs | Qs");
+  static_assert(szX % 16 == 0 && szQ % 16 == 0 && szP % 16 == 0, "16-byte carve offsets");
+};
+
+__device__ __forceinline__ Frag8<bf16_t> tr8z(const bf16_t* base, int ld, int row_lo_base, int row_hi_base, int col0, int lane,
+                                              int zero_row) {
+  const int i = lane & 15, qq = i >> 2, pp = i & 3;
+  typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+  const int rlo = min(row_lo_base + qq, zero_row), rhi = min(row_hi_base + qq, zero_row);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(base + rlo * ld + col0 + 4 * pp));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(base + rhi * ld + col0 + 4 * pp));
+  Frag8<bf16_t> f;
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+
+__device__ __forceinline__ bf16x4 pack4(const f32x4& a) {
+  bf16x4 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
+  return r;
+}
+
+template <int C, int L, int NW>
+__global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wfrag,
+                                                                        const float* __restrict__ rel_h, const float* __restrict__ rel_w,
+                                                                        bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ldo, int oc0,
+                                                                        const bf16_t* __restrict__ res, int ldr, int h, int w) {
+  using T = bf16_t;
+  using Cfg = FusedCfg<C>;
+  constexpr int LD = Cfg::LD, PLD = Cfg::PLD, OLD = Cfg::OLD, ZR = Cfg::ZR;
+  constexpr int NTHR = NW * 64, VEC = C / 8, NT = C / 16, NKS = C / 32, TPW = NT / NW;
+  static_assert(NT % NW == 0 && TPW >= 1, "channel tiles must split evenly over the waves");
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(L == 0 || C == (16 << (2 * L)), "fused IWT needs C = 16 * 4^L");
+  static_assert(Cfg::total <= 163840, "LDS budget");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T(*Xs)[LD] = reinterpret_cast<T(*)[LD]>(smem + Cfg::offX);
+  T(*Qs)[LD] = reinterpret_cast<T(*)[LD]>(smem + Cfg::offQ);
+  T(*KV)[LD] = reinterpret_cast<T(*)[LD]>(smem + Cfg::offKV);
+  T(*Ps)[PLD] = reinterpret_cast<T(*)[PLD]>(smem + Cfg::offP);
+  float(*Os)[OLD] = reinterpret_cast<float(*)[OLD]>(smem + Cfg::offX);        // phase 4 on: overlays Xs | Qs
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const WinGeom gm = make_geom(h, w);
+  const bf16x8* wf8 = reinterpret_cast<const bf16x8*>(wfrag);
+  // fragment (projection p, channel tile ct of it, k-step ks): one contiguous 1 KB per wave
+  auto wload = [&](int p, int ct, int ks) -> Frag8<T> {
+    Frag8<T> f;
+    f.v = wf8[((size_t)((p * NT + ct) * NKS + ks)) * 64 + lane];
+    return f;
+  };
+
+  M2T_FUSED_STAMP(0);
+  // ---- phase 0: x rows of the 100 keys (own pixels first) and the rel-pos table -> LDS; the K and Q weight slices of
+  // this wave follow them into flight.
+  // Two rules shape every global access of this kernel (both measured):
+  //  * no load under a lane-dependent branch: hipcc then waits vmcnt(0) per load (seven serial HBM round trips here), so
+  //    out-of-image keys read a clamped, valid address and are zeroed by a select, and surplus slots rewrite the zero row;
+  //  * vmcnt retires in order and counts STORES too: a load issued after a global store cannot complete before that
+  //    store is acknowledged (~2 k cycles under load).  Hence: the rel-pos table comes through LDS instead of per-tile
+  //    loads, and every later load (V weights, residual rows) is issued BEFORE the stores that precede its use.
+  constexpr int XIT = (101 * VEC + NTHR - 1) / NTHR;          // row 100 = the zero row: written like any other row
+  constexpr int RIT = (10 * C / 4 + NTHR - 1) / NTHR;         // rel table [10][C] fp32 as float4s
+  float(*RelS)[C] = reinterpret_cast<float(*)[C]>(smem + Cfg::offP);      // phases 0-1 only: P's region
+  static_assert(sizeof(float) * 10 * C <= Cfg::szP, "the rel-pos table borrows P's region");
+  Frag8<T> wk[TPW][NKS], wq[TPW][NKS];
+  {
+    Frag8<T> xf[XIT];
+    bool ok[XIT];
+    f32x4 rf[RIT];
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int idx = tid + it * NTHR;
+      const int key = min(idx / VEC, 100), cv = idx % VEC;
+      int kr, kc;
+      fused_key_rc(min(key, 99), kr, kc);
+      const int yy = 8 * gm.wy + kr - 1, xx = 8 * gm.wx + kc - 1;
+      ok[it] = (key < 100) && yy >= 0 && yy < h && xx >= 0 && xx < w;
+      const int yc = min(max(yy, 0), h - 1), xc = min(max(xx, 0), w - 1);
+      xf[it] = load8(x + (((long long)gm.b * h + yc) * w + xc) * C + cv * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      // T[kk][ch] = ch < C/2 ? rel_h[kk][ch] : rel_w[kk][ch - C/2]   (row kk is a key ROW for the first half of the
+      // channels and a key COLUMN for the second, models/M2Trans_network.py:322-325)
+      const int idx = min(tid + it * NTHR, 10 * C / 4 - 1);
+      const int kk = idx / (C / 4), c4 = (idx % (C / 4)) * 4;
+      const float* rp = (c4 < C / 2) ? (rel_h + kk * (C / 2) + c4) : (rel_w + kk * (C / 2) + (c4 - C / 2));
+      rf[it] = *reinterpret_cast<const f32x4*>(rp);
+    }
+    // weight fragments in the order the first key tile consumes them
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) {
+        wk[m][ks] = wload(1, wv * TPW + m, ks);
+        wq[m][ks] = wload(0, wv * TPW + m, ks);
+      }
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+      const int idx = tid + it * NTHR;
+      const int key = min(idx / VEC, 100), cv = idx % VEC;
+      store8(&Xs[key][cv * 8], ok[it] ? xf[it] : frag_zero<T>());
+    }
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      const int idx = min(tid + it * NTHR, 10 * C / 4 - 1);
+      *reinterpret_cast<f32x4*>(&RelS[idx / (C / 4)][(idx % (C / 4)) * 4]) = rf[it];
+    }
+    if (tid < VEC) store8(&KV[ZR][tid * 8], frag_zero<T>());
+  }
+  __syncthreads();
+  M2T_FUSED_STAMP(1);
+
+  // ---- phase 1: K (7 key tiles) and Q (key tiles 0..3 = the query tiles) ----
+  // lane (pixel = lr, g) ends with channels 16 ct + 4 g .. + 3 of its pixel
+  bf16x4 kown[4][TPW];                  // raw k of the window's own pixels: stored to HBM after the V weights are in flight
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) {
+    const bool with_q = t < 4;
+    const int key = 16 * t + lr;
+    const int row = min(key, ZR);
+    f32x4 ak[TPW], aq[TPW];
+#pragma unroll
+    for (int m = 0; m < TPW; ++m) { ak[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; aq[m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const Frag8<T> b = load8(&Xs[row][32 * ks + 8 * g]);
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) {
+        mma16(ak[m], wk[m][ks], b);
+        if (with_q) mma16(aq[m], wq[m][ks], b);
+      }
+    }
+    if (key < WA_NK) {
+      int kr, kc;
+      fused_key_rc(key, kr, kc);
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) {
+        const int ch = 16 * (wv * TPW + m) + 4 * g;
+        const bf16x4 kb = pack4(ak[m]);
+        if (with_q) kown[t & 3][m] = kb;
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(&RelS[(ch < C / 2) ? kr : kc][ch]);
+        float kh[4] = {(float)kb[0] + r4[0], (float)kb[1] + r4[1], (float)kb[2] + r4[2], (float)kb[3] + r4[3]};
+        store4(&KV[key][ch], kh);
+        if (with_q) *reinterpret_cast<bf16x4*>(&Qs[key][ch]) = pack4(aq[m]);
+      }
+    }
+    if (t == 3) {
+      // the Q slice is dead: its registers take the V slice, in flight under the three ring tiles and the S phase.
+      // No global store has been issued yet, so nothing delays these loads; the k stores follow them.
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int m = 0; m < TPW; ++m) wq[m][ks] = wload(2, wv * TPW + m, ks);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t2 = 0; t2 < 4; ++t2) {
+        const long long qp = gm.query_pixel(16 * t2 + lr);
+#pragma unroll
+        for (int m = 0; m < TPW; ++m)
+          *reinterpret_cast<bf16x4*>(qkv + qp * (3 * C) + C + 16 * (wv * TPW + m) + 4 * g) = kown[t2][m];
+      }
+    }
+  }
+  M2T_FUSED_STAMP(2);
+  __syncthreads();                      // Kh, Qs complete
+  M2T_FUSED_STAMP(3);
+  // q -> HBM as whole rows out of Qs (16 bytes per lane)
+  for (int idx = tid; idx < 64 * VEC; idx += NTHR) {
+    const int q = idx / VEC, cv = idx % VEC;
+    store8(qkv + gm.query_pixel(q) * (3 * C) + cv * 8, load8(&Qs[q][cv * 8]));
+  }
+
+  // ---- phase 2a (waves 0..3): S^T = K^ Q^T, softmax, P -> LDS ----
+  if (wv < 4) {
+    const int q = 16 * wv + lr;
+    f32x4 s[WA_KT];
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const Frag8<T> qf = load8(&Qs[q][32 * ks + 8 * g]);
+#pragma unroll
+      for (int t = 0; t < WA_KT; ++t) mma16(s[t], load8(&KV[min(16 * t + lr, ZR)][32 * ks + 8 * g]), qf);
+    }
+    // lane (q, g) holds keys 16 t + 4 g + r
+    const float scale = rsqrtf((float)C);
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * t + 4 * g + r;
+        s[t][r] = (key < WA_NK) ? s[t][r] * scale : -3.0e38f;
+        mx = fmaxf(mx, s[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * t + 4 * g + r;
+        const float e = (key < WA_NK) ? __expf(s[t][r] - mx) : 0.f;
+        s[t][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      float pv[4] = {s[t][0] * inv, s[t][1] * inv, s[t][2] * inv, s[t][3] * inv};
+      store4(&Ps[q][16 * t + 4 * g], pv);
+    }
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    store4(&Ps[q][112 + 4 * g], z);                      // keys 112..127: contraction padding of P V
+  }
+  // ---- phase 2b (all waves): V projection into registers ----
+  bf16x4 vreg[WA_KT][TPW];
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) {
+    const int row = min(16 * t + lr, ZR);
+    f32x4 av[TPW];
+#pragma unroll
+    for (int m = 0; m < TPW; ++m) av[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const Frag8<T> b = load8(&Xs[row][32 * ks + 8 * g]);
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) mma16(av[m], wq[m][ks], b);
+    }
+#pragma unroll
+    for (int m = 0; m < TPW; ++m) vreg[t][m] = pack4(av[m]);
+  }
+  M2T_FUSED_STAMP(4);
+  __syncthreads();                      // every wave is done with Kh, Qs and Xs; P is visible
+
+  // the residual rows of the epilogue are fetched now (ahead of the v stores: vmcnt retires in order), under phases 3-4
+  constexpr int ES = Haar<L>::S, EPARTS = (L == 0) ? 1 : NTHR / 256, EROWS = (L == 0) ? 1 : ES / EPARTS;
+  bf16x4 resv[EROWS][ES];
+  const int e_item = tid & 255, e_part = tid >> 8;
+  const int e_q = e_item >> 2, e_cg = e_item & 3;
+  if constexpr (L > 0) {
+    const int H = h * ES, W = w * ES;
+    const int by = 8 * gm.wy + (e_q >> 3), bx = 8 * gm.wx + (e_q & 7);
+#pragma unroll
+    for (int yy = 0; yy < EROWS; ++yy)
+#pragma unroll
+      for (int xx = 0; xx < ES; ++xx) {
+        const long long pix = ((long long)gm.b * H + ES * by + e_part * EROWS + yy) * W + ES * bx + xx;
+        resv[yy][xx] = *reinterpret_cast<const bf16x4*>(res + pix * ldr + 4 * e_cg);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- phase 3: V -> LDS (over Kh) and HBM ----
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) {
+    const int key = 16 * t + lr;
+    if (key < WA_NK) {
+      const long long qp = (key < 64) ? gm.query_pixel(key) : 0;
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) {
+        const int ch = 16 * (wv * TPW + m) + 4 * g;
+        *reinterpret_cast<bf16x4*>(&KV[key][ch]) = vreg[t][m];
+        if (key < 64) *reinterpret_cast<bf16x4*>(qkv + qp * (3 * C) + 2 * C + ch) = vreg[t][m];
+      }
+    }
+  }
+  M2T_FUSED_STAMP(5);
+  __syncthreads();
+
+  // ---- phase 4: O^T = V^T P^T for this wave's channel tiles, all 64 queries ----
+  {
+    f32x4 o[TPW][4];
+#pragma unroll
+    for (int m = 0; m < TPW; ++m)
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) o[m][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      Frag8<T> a[TPW];
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) a[m] = tr8z(&KV[0][0], LD, 32 * c4 + 8 * g, 32 * c4 + 8 * g + 4, 16 * (wv * TPW + m), lane, ZR);
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        const Frag8<T> b = load8(&Ps[16 * qt + lr][32 * c4 + 8 * g]);
+#pragma unroll
+        for (int m = 0; m < TPW; ++m) mma16(o[m][qt], a[m], b);
+      }
+    }
+    // Os overlays Xs | Qs, dead since the barrier before phase 3
+#pragma unroll
+    for (int m = 0; m < TPW; ++m)
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) *reinterpret_cast<f32x4*>(&Os[16 * qt + lr][16 * (wv * TPW + m) + 4 * g]) = o[m][qt];
+  }
+  M2T_FUSED_STAMP(6);
+  __syncthreads();
+
+  // ---- phase 5: epilogue ----
+  if constexpr (L == 0) {
+    for (int idx = tid; idx < 64 * VEC; idx += NTHR) {
+      const int q = idx / VEC, cv = idx % VEC;
+      const long long qp = gm.query_pixel(q);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = Os[q][cv * 8 + e];
+      if (res) {
+        float p[8];
+        load8f(res + qp * ldr + cv * 8, p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += p[e];
+      }
+      store8f(out + qp * ldo + oc0 + cv * 8, v);
+    }
+  } else {
+    // channel = band * 16 + base channel (band-major nesting of repeated DWTs); item = (query, 4 base channels);
+    // with 512 threads the two halves of the workgroup store the upper / lower rows of the (2^L)^2 block
+    constexpr int S = ES, NB = Haar<L>::N, PARTS = EPARTS, ROWS = EROWS;
+    static_assert(NB == NT && S % PARTS == 0, "one 16-channel tile per band");
+    const int q = e_q, cg = e_cg, part = e_part;
+    float vv[4][S][S];
+    {
+      f32x4 ob[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) ob[b] = *reinterpret_cast<const f32x4*>(&Os[q][16 * b + 4 * cg]);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float bands[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bands[b] = ob[b][c];
+        Haar<L>::inv(bands, vv[c]);
+      }
+    }
+    const int H = h * S, W = w * S;
+    const int by = 8 * gm.wy + (q >> 3), bx = 8 * gm.wx + (q & 7);
+#pragma unroll
+    for (int yy = 0; yy < ROWS; ++yy)
+#pragma unroll
+      for (int xx = 0; xx < S; ++xx) {
+        // (static indices into vv: select the row with a compile-time loop over the parts)
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pp = 0; pp < PARTS; ++pp)
+          if (pp == part) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = vv[c][pp * ROWS + yy][xx];
+          }
+        const int y = part * ROWS + yy;
+        const long long pix = ((long long)gm.b * H + S * by + y) * W + S * bx + xx;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += (float)resv[yy][xx][c];
+        store4(out + pix * ldo + oc0 + 4 * cg, v);
+      }
+  }
+  M2T_FUSED_STAMP(7);
+}
+
+template <int C, int L, int NW>
+int go_fused(const bf16_t* x, const bf16_t* wfrag, const float* rel_h, const float* rel_w, bf16_t* qkv, bf16_t* out, int ldo, int oc0,
+             const bf16_t* res, int ldr, int nwin, int h, int w, hipStream_t st) {
+  const size_t sh = FusedCfg<C>::total;
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_fused_fwd_kernel<C, L, NW>, (int)sh)) return rc__;
+  M2T_LAUNCH_TIMED((window_attn_fused_fwd_kernel<C, L, NW>), dim3(nwin), dim3(NW * 64), sh, st, x, wfrag, rel_h, rel_w, qkv, out, ldo,
+                   oc0, res, ldr, h, w);
+  return 0;
+}
+
+}  // namespace
+
+// bf16; (C, post_levels) in {(64, 0), (64, 1), (256, 0), (256, 2)}; M2T_UNSUPPORTED otherwise.
+// x [B][h][w][C]; wfrag: the qkv weight in M2T_PACK_FRAG16 order; qkv [B][h][w][3C] (written); out / res as in
+// launch_window_attn_fwd (post_levels > 0: the full-resolution xc chunk / xin planes; res is then mandatory).
+int launch_window_attn_fused_fwd(const void* x_, const void* wfrag_, const float* rel_h, const float* rel_w, void* qkv_, void* out_,
+                                 int ldo, int oc0, const void* res_, int ldr, int B, int h, int w, int C, int post_levels,
+                                 hipStream_t st) {
+  if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn_fused: h,w must be multiples of 8");
+  if (post_levels != 0 && !res_) return m2t_set_error(-2, "window_attn_fused: the fused IWT epilogue needs the residual");
+  const bf16_t* x = (const bf16_t*)x_;
+  const bf16_t* wfrag = (const bf16_t*)wfrag_;
+  bf16_t* qkv = (bf16_t*)qkv_;
+  bf16_t* out = (bf16_t*)out_;
+  const bf16_t* res = (const bf16_t*)res_;
+  const int nwin = B * (h / 8) * (w / 8);
+  int rc = M2T_UNSUPPORTED;
+  M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_FUSED_64 : M2T_PROF_ATTN_FUSED_256, st);
+  if (C == 256 && post_levels == 2) rc = go_fused<256, 2, 8>(x, wfrag, rel_h, rel_w, qkv, out, ldo, oc0, res, ldr, nwin, h, w, st);
+  else if (C == 256 && post_levels == 0) rc = go_fused<256, 0, 8>(x, wfrag, rel_h, rel_w, qkv, out, ldo, oc0, res, ldr, nwin, h, w, st);
+  else if (C == 64 && post_levels == 1) rc = go_fused<64, 1, 4>(x, wfrag, rel_h, rel_w, qkv, out, ldo, oc0, res, ldr, nwin, h, w, st);
+  else if (C == 64 && post_levels == 0) rc = go_fused<64, 0, 4>(x, wfrag, rel_h, rel_w, qkv, out, ldo, oc0, res, ldr, nwin, h, w, st);
+  if (rc != 0) return rc;
+  M2T_LAUNCH_CHECK();
+  return 0;
+}

@@ -1138,6 +1138,12 @@ __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ mas
         const int sub = np / d.d0, c = np % d.d0;
         si = ((long long)c * d.d1 + sub) * d.d2 + kk;
       } break;
+      case M2T_PACK_FRAG16: {           // src [N=d0][K=d1] -> [N/16][K/32][64][8] (see m2t_kernels.h)
+        const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
+        const int nks = d.d1 >> 5;
+        const int ks = f % nks, tile = f / nks;
+        si = (long long)(16 * tile + (l & 15)) * d.d1 + 32 * ks + 8 * (l >> 4) + j;
+      } break;
     }
     o[e] = from_f<T>(s[si]);
   }

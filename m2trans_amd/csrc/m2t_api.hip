@@ -122,6 +122,7 @@ struct m2t_plan {
   int side_conv_pos = 1;           // the block's conv weight gradient: 0 first at the gate, 1 after the gated branches (same-box A/B:
                                    // +1.9 % over 0: the 512-thread, LDS-heavy kernel then meets the C = 16 instead of the C = 64 attention), 2 after the last attention (+1.8 %)
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
+  bool use_fused_attn_fwd = true;      // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip)
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
   // region; the descriptor table is identical every step, so it is uploaded once
   std::vector<m2t_red_desc> red_descs;
@@ -232,6 +233,7 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
       const std::string k = "b" + std::to_string(b) + ".w" + std::to_string(i + 1);
       p->add_pack(k, pre + "qkv_conv.weight", M2T_PACK_COPY, 3LL * C * C, 0, 0, 0);
       p->add_pack(k + "T", pre + "qkv_conv.weight", M2T_PACK_TRANSPOSE, 3LL * C * C, 3 * C, C, 0);
+      if (C >= 64) p->add_pack(k + "F", pre + "qkv_conv.weight", M2T_PACK_FRAG16, 3LL * C * C, 3 * C, C, 0);   // k_attn_fused.hip
     }
     const std::string pre = "body." + std::to_string(b) + ".feed_forward.0.weight";
     p->add_pack("b" + std::to_string(b) + ".wf", pre, M2T_PACK_CONV3, 64 * 64 * 9, 64, 64, 0);
@@ -397,6 +399,12 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
       {
         void* xc_i = (char*)xc + (size_t)i * BP * 16 * p->esz;       // chunk i of the P64 concat buffer: a dense plane
         CK(launch_branch_prep(dt, L, X, mean, rstd, xc, i, WSP("xin"), d, B, H, W, st));
+        if (dt != M2T_F32 && p->use_fused_attn_fwd && C >= 64) {
+          // qkv projection + window attention + IWT^L / residual in one kernel; qkv is still written (the backward reads it)
+          CK(launch_window_attn_fused_fwd(d, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "F"), rh, rw, qkv, xc_i, 16, 0,
+                                          WSP("xin"), 16, B, h, w, C, L, st));
+          continue;
+        }
         m2t_gemm_args ga{};
         ga.A = d; ga.lda = C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1));
         ga.Y = qkv; ga.ldy = 3 * C; ga.M = M; ga.N = 3 * C; ga.K = C;
@@ -796,6 +804,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "gated_side") { p->use_gated_side = (value != 0); return 0; }
   if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
+  if (std::string(key) == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
   if (std::string(key) == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
   return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");
 }

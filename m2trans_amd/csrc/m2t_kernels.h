@@ -10,7 +10,9 @@
 
 enum m2t_pack_kind {
   M2T_PACK_COPY = 0, M2T_PACK_TRANSPOSE = 1, M2T_PACK_CONV3 = 2, M2T_PACK_CONV3_T = 3,
-  M2T_PACK_SHUF_ROWS = 4, M2T_PACK_SHUF_ROWS_T = 5
+  M2T_PACK_SHUF_ROWS = 4, M2T_PACK_SHUF_ROWS_T = 5,
+  M2T_PACK_FRAG16 = 6     // src [N = d0][K = d1] -> MFMA A-operand fragment order [N/16][K/32][64 lanes][8]: element j of lane l of
+                          // fragment (tile, ks) is src[16 tile + (l & 15)][32 ks + 8 (l >> 4) + j]; one wave load = 1 KB contiguous
 };
 struct m2t_red_desc {      // one deferred slab reduction: grads[dst_off + perm(e)] = sum_s arena[src_off + s*n + e]
   long long src_off, dst_off, n;
@@ -28,6 +30,7 @@ enum m2t_prof_cat {
   M2T_PROF_CONV3_FWD, M2T_PROF_CONV3_DGRAD, M2T_PROF_CONV3_WGRAD,
   M2T_PROF_GEMM_QKV, M2T_PROF_GEMM_QKV_DGRAD, M2T_PROF_WGRAD_QKV,
   M2T_PROF_TAIL_GEMM, M2T_PROF_TAIL_WGRAD, M2T_PROF_FINAL_FWD, M2T_PROF_FINAL_DGRAD, M2T_PROF_FINAL_WGRAD,
+  M2T_PROF_ATTN_FUSED_64, M2T_PROF_ATTN_FUSED_256,      // fused qkv projection + window attention forward (k_attn_fused.hip)
   M2T_PROF_NCAT
 };
 void m2t_prof_begin(int cat, hipStream_t st);
@@ -35,7 +38,8 @@ void m2t_prof_end(int cat, hipStream_t st);
 // Single-kernel categories (attention, conv3x3, final conv): the scope's two events ride on the kernel dispatch itself
 // (hipExtLaunchKernelGGL start / stop events = the dispatch's own begin / end timestamps, the quantity rocprofv3
 // reports) instead of bracketing it with marker packets, which add the ~5 us launch gap to every sample.
-#define M2T_PROF_DISPATCH_CATS ((1ull << M2T_PROF_GEMM_QKV) - 1ull | (1ull << M2T_PROF_FINAL_FWD) | (1ull << M2T_PROF_FINAL_DGRAD) | (1ull << M2T_PROF_FINAL_WGRAD))
+#define M2T_PROF_DISPATCH_CATS ((1ull << M2T_PROF_GEMM_QKV) - 1ull | (1ull << M2T_PROF_FINAL_FWD) | (1ull << M2T_PROF_FINAL_DGRAD) | (1ull << M2T_PROF_FINAL_WGRAD) | \
+                                (1ull << M2T_PROF_ATTN_FUSED_64) | (1ull << M2T_PROF_ATTN_FUSED_256))
 bool m2t_prof_take(hipEvent_t* a, hipEvent_t* b);
 #define M2T_LAUNCH_TIMED(kernel, grid, block, sh, st, ...)                                                       \
   do {                                                                                                           \
@@ -164,6 +168,11 @@ int launch_window_attn_fwd_resident(const void* qkv, const float* rel_h, const f
 // the resident kernel alone (bf16); M2T_UNSUPPORTED when (C, dwt_levels) has no instantiation
 int launch_window_attn_bwd_resident(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
                                     void* gqkv, void* win, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st);
+// k_attn_fused.hip: qkv projection + window attention + IWT / residual epilogue in one kernel (bf16, C = 64 / 256).
+// x [B][h][w][C]; wfrag = the [3C][C] qkv weight in M2T_PACK_FRAG16 order; qkv [B][h][w][3C] is WRITTEN (saved for the backward)
+int launch_window_attn_fused_fwd(const void* x, const void* wfrag, const float* rel_h, const float* rel_w, void* qkv, void* out,
+                                 int ldo, int oc0, const void* res, int ldr, int B, int h, int w, int C, int post_levels,
+                                 hipStream_t st);
 // relw [nwin][10][C] per-window partials -> grel_h / grel_w (torch layouts)
 int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st);
 int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int* nsplit_out, hipStream_t st);

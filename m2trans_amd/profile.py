@@ -4,6 +4,9 @@ bench.py.  Category ids mirror `enum m2t_prof_cat` in csrc/m2t_kernels.h.
 Algorithmic work per launch (per-unit figure x units per launch):
   window attention fwd : 2 products x 2*64*100*C FLOP per window           = 25 600 C FLOP/window
                          bytes: read q|k|v (3C) + write out (C) per pixel   = 4 C es B/pixel
+  fused qkv + attention: the projection's 2*C*3C FLOP per pixel (each pixel once: the halo rows a window projects
+                         again are not counted) + 25 600 C FLOP per window
+                         bytes: read d (C) + residual (C), write q|k|v (3C) + out (C) per pixel = 6 C es B/pixel
   window attention bwd : 5 products (S, dP, dq, dK, dV)                     = 64 000 C FLOP/window
                          bytes: read qkv (3C) + gO (C), write gqkv (3C)     = 7 C es B/pixel
   conv3x3 64->64       : 2*64*576 FLOP/pixel; bytes: in + out (+ residual)  = 128..192 es B/pixel
@@ -21,7 +24,8 @@ from . import _lib
 
 CATS = ["attn_fwd_c16", "attn_fwd_c64", "attn_fwd_c256", "attn_bwd_c16", "attn_bwd_c64", "attn_bwd_c256",
         "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "gemm_qkv", "gemm_qkv_dgrad", "wgrad_qkv",
-        "tail_gemm", "tail_wgrad", "final_conv_fwd", "final_conv_dgrad", "final_conv_wgrad"]
+        "tail_gemm", "tail_wgrad", "final_conv_fwd", "final_conv_dgrad", "final_conv_wgrad",
+        "attn_fused_c64", "attn_fused_c256"]
 KERNEL_OF = {
     "attn_fwd_c16": "window_attn_fwd_kernel<C=16>", "attn_fwd_c64": "window_attn_fwd_kernel<C=64>",
     "attn_fwd_c256": "window_attn_fwd_kernel<C=256>", "attn_bwd_c16": "window_attn_bwd_kernel<C=16>",
@@ -32,6 +36,8 @@ KERNEL_OF = {
     "tail_gemm": "gemm_nt_kernel (tail 1x1 + pixel shuffle, fwd+dgrad)", "tail_wgrad": "wgrad_tn_kernel (tail)",
     "final_conv_fwd": "final_conv_fwd_kernel", "final_conv_dgrad": "final_conv_dgrad_kernel",
     "final_conv_wgrad": "final_conv_wgrad_kernel",
+    "attn_fused_c64": "window_attn_fused_fwd_kernel<C=64,L=1> (qkv projection + window attention + IWT/residual)",
+    "attn_fused_c256": "window_attn_fused_fwd_kernel<C=256,L=2> (qkv projection + window attention + IWT^2/residual)",
 }
 KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these categories
     "attn_fwd_c16": "window_attn_fwd_c16_kernel (wave per window)",
@@ -64,8 +70,12 @@ def read_all():
     return out
 
 
-def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8):
-    """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr."""
+def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8, fused_attn_fwd: bool | None = None):
+    """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr.
+    fused_attn_fwd (default: bf16 mode): the C = 64 / 256 branches run qkv projection + attention as one kernel, so
+    the forward `gemm_qkv` / `attn_fwd_c64|c256` categories see only what is left (the C = 16 branch)."""
+    if fused_attn_fwd is None:
+        fused_attn_fwd = dtype == "bf16"
     es = 2 if dtype == "bf16" else 4
     H = W = (lr + 31) // 32 * 32
     P = H * W
@@ -80,9 +90,12 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8)
     for C_, L in br:
         M = B * P // (4 ** L)
         win = M // 64
-        add(f"attn_fwd_c{C_}", nb * win * 25600.0 * C_, nb * M * (4 * C_ + (C_ if C_ == 16 else 0)) * es, nb)
         add(f"attn_bwd_c{C_}", nb * win * 64000.0 * C_, nb * M * 7 * C_ * es, nb)
-        add("gemm_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
+        if C_ >= 64 and fused_attn_fwd:
+            add(f"attn_fused_c{C_}", nb * (win * 25600.0 * C_ + 2.0 * M * C_ * 3 * C_), nb * M * 6 * C_ * es, nb)
+        else:
+            add(f"attn_fwd_c{C_}", nb * win * 25600.0 * C_, nb * M * (4 * C_ + (C_ if C_ == 16 else 0)) * es, nb)
+            add("gemm_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
         add("gemm_qkv_dgrad", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
         add("wgrad_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
     conv_fl = 2.0 * B * P * 64 * 576

@@ -1,0 +1,103 @@
+// Stand-alone timing harness for k_attn_fused.hip (no torch): synthetic window data, hipEvent timing, optional
+// per-phase s_memtime stamps.   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off scratch/bench_fused.hip -o scratch/bench_fused
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <string>
+#ifdef STAMPS
+__device__ unsigned long long* g_stamps;
+#define M2T_FUSED_STAMP(i) do { if ((threadIdx.x & 63) == 0) g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
+#include "../m2trans_amd/csrc/k_attn_fused.hip"
+
+static thread_local std::string g_err;
+int m2t_set_hip_error(hipError_t e, const char* f, int l) { fprintf(stderr, "HIP error %d %s at %s:%d\n", (int)e, hipGetErrorString(e), f, l); return (int)e; }
+int m2t_set_error(int c, const char* m) { fprintf(stderr, "error %d %s\n", c, m); return c; }
+int m2t_ensure_dynamic_lds(const void* k, int b) { return (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, b); }
+void m2t_prof_begin(int, hipStream_t) {}
+void m2t_prof_end(int, hipStream_t) {}
+bool m2t_prof_take(hipEvent_t*, hipEvent_t*) { return false; }
+
+#define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static unsigned short f2bf(float f) { union { float f; unsigned u; } c; c.f = f; unsigned u = c.u; return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
+
+int main(int argc, char** argv) {
+  const int C = argc > 1 ? atoi(argv[1]) : 256;
+  const int B = argc > 2 ? atoi(argv[2]) : 16;
+  const int L = (C == 256) ? 2 : 1;
+  const int hw = 128 >> L;                 // branch grid at 128x128 LR
+  const int h = hw, w = hw;
+  const size_t M = (size_t)B * h * w;
+  const size_t full = (size_t)B * 128 * 128;
+  std::vector<unsigned short> hx(M * C), hwf((size_t)3 * C * C), hres(full * 16);
+  srand(1);
+  for (auto& v : hx) v = f2bf((rand() / (float)RAND_MAX - 0.5f) * 2.f);
+  for (auto& v : hwf) v = f2bf((rand() / (float)RAND_MAX - 0.5f) * 0.2f);
+  for (auto& v : hres) v = f2bf((rand() / (float)RAND_MAX - 0.5f));
+  std::vector<float> hrel(10 * C);
+  for (auto& v : hrel) v = (rand() / (float)RAND_MAX - 0.5f);
+  void *dx, *dwf, *dqkv, *dout, *dres; float* drel;
+  CKH(hipMalloc(&dx, M * C * 2)); CKH(hipMalloc(&dwf, (size_t)3 * C * C * 2)); CKH(hipMalloc(&dqkv, M * 3 * C * 2));
+  CKH(hipMalloc(&dout, full * 16 * 2)); CKH(hipMalloc(&dres, full * 16 * 2)); CKH(hipMalloc(&drel, 10 * C * 4));
+  CKH(hipMemcpy(dx, hx.data(), M * C * 2, hipMemcpyHostToDevice));
+  CKH(hipMemcpy(dwf, hwf.data(), (size_t)3 * C * C * 2, hipMemcpyHostToDevice));
+  CKH(hipMemcpy(dres, hres.data(), full * 16 * 2, hipMemcpyHostToDevice));
+  CKH(hipMemcpy(drel, hrel.data(), 10 * C * 4, hipMemcpyHostToDevice));
+  const int nwin = B * (h / 8) * (w / 8);
+#ifdef STAMPS
+  unsigned long long* dst;
+  CKH(hipMalloc(&dst, (size_t)nwin * 8 * 16 * 8));
+  CKH(hipMemset(dst, 0, (size_t)nwin * 8 * 16 * 8));
+  CKH(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dst, sizeof(dst)));
+#endif
+  hipStream_t st; CKH(hipStreamCreate(&st));
+  // a second buffer the size of the Infinity Cache is written between launches in "cold" mode
+  const bool cold = argc > 3 && atoi(argv[3]) != 0;
+  void* dflush = nullptr; const size_t flush_bytes = (size_t)512 << 20;
+  if (cold) CKH(hipMalloc(&dflush, flush_bytes));
+  auto launch = [&]() { return launch_window_attn_fused_fwd(dx, dwf, drel, drel + 5 * C, dqkv, dout, 16, 0, dres, 16, B, h, w, C, L, st); };
+  for (int i = 0; i < 5; ++i) if (launch()) return 1;
+  CKH(hipStreamSynchronize(st));
+  hipEvent_t e0, e1; CKH(hipEventCreate(&e0)); CKH(hipEventCreate(&e1));
+  const int N = 40;
+  std::vector<float> ts;
+  for (int i = 0; i < N; ++i) {
+    if (cold) CKH(hipMemsetAsync(dflush, i, flush_bytes, st));
+    CKH(hipEventRecord(e0, st));
+    if (launch()) return 1;
+    CKH(hipEventRecord(e1, st));
+    CKH(hipEventSynchronize(e1));
+    float ms; CKH(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms * 1e3f);
+  }
+  std::sort(ts.begin(), ts.end());
+  const double flop = (double)M * 2.0 * C * 3 * C + (double)nwin * 25600.0 * C;
+  printf("C=%d B=%d windows=%d %s: event-bracketed min %.2f us median %.2f us  -> %.1f TFLOP/s algorithmic (%.1f %% of 2.5 PF) at the median\n", C, B, nwin,
+         cold ? "cold" : "warm", ts[0], ts[N / 2], flop / ts[N / 2] * 1e-6, flop / ts[N / 2] * 1e-6 / 2500.0 * 100.0);
+#ifdef STAMPS
+  std::vector<unsigned long long> hs((size_t)nwin * 8 * 16);
+  CKH(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
+  const int NW = (C == 256) ? 8 : 4, NS = 9;
+  const char* names[NS - 1] = {"phase0 x->LDS + W loads", "phase1 K,Q proj", "barrier1", "phase2 S/softmax + V proj", "barrier2+V store", "barrier3+PV", "barrier4+epilogue", "-"};
+  for (int wsel : {0, NW - 1}) {
+    printf("wave %d: median cycles per segment over %d workgroups\n", wsel, nwin);
+    for (int s = 0; s + 1 < NS; ++s) {
+      std::vector<long long> d;
+      for (int b = 0; b < nwin; ++b) {
+        const unsigned long long a = hs[((size_t)b * 8 + wsel) * 16 + s], c = hs[((size_t)b * 8 + wsel) * 16 + s + 1];
+        if (a && c) d.push_back((long long)(c - a));
+      }
+      if (d.empty()) continue;
+      std::sort(d.begin(), d.end());
+      printf("  %-28s %8lld (min %lld max %lld)\n", names[s], d[d.size() / 2], d.front(), d.back());
+    }
+    std::vector<long long> d;
+    for (int b = 0; b < nwin; ++b) d.push_back((long long)(hs[((size_t)b * 8 + wsel) * 16 + 7] - hs[((size_t)b * 8 + wsel) * 16 + 0]));
+    std::sort(d.begin(), d.end());
+    printf("  total (stamp 0 -> 7) median %lld cycles (s_memtime ticks at 100 MHz?)\n", d[d.size() / 2]);
+  }
+#endif
+  return 0;
+}

@@ -405,3 +405,34 @@ def test_autograd_path_accepts_non_contiguous_and_half_inputs():
     for o in outs[1:]:
         for n in outs[0]:
             assert torch.equal(o[n], outs[0][n]), n
+
+
+def test_fused_qkv_attention_forward_matches_the_two_kernel_path():
+    """bf16: the fused qkv-projection + window-attention kernel (k_attn_fused.hip, default for the C = 64 / 256 branches)
+    against the GEMM + attention kernels it replaces, at a size with border, edge and interior windows in every branch
+    (2 x 3 windows at C = 256) and a reflect-padded input.  Same products and rounding points; the fused kernel sums the
+    softmax and P V over the keys in another order (own pixels first), so: saved q|k|v identical up to rare 1-ulp flips,
+    block outputs within bf16 noise (stated: rel-rms <= 2e-3 for the first block's tensors)."""
+    from m2trans_amd import _lib
+    from tests.gpu_util import ws_nchw
+    scale, nb, B, H0, W0 = 4, 2, 2, 60, 90            # padded to 64 x 96
+    x = O.closed_form_image(B, 3, H0, W0).cuda()
+    outs = []
+    for fused in (1, 0):
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(x)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_attn_fwd", fused), "m2t_set_option")
+        with torch.no_grad():
+            sr = model(x)
+        torch.cuda.synchronize()
+        H, W = plan.query("padded_h"), plan.query("padded_w")
+        t = {f"b0.qkv{i+1}": ws_nchw(plan, f"b0.qkv{i+1}", B, H >> l, W >> l, 3 * c) for i, (c, l) in enumerate(zip(BR_C, BR_L))}
+        t["b0.xc"] = ws_nchw(plan, "b0.xc", B, H, W, 64)
+        t["X1"] = ws_nchw(plan, "X1", B, H, W, 64)
+        t["sr"] = sr.cpu()
+        outs.append(t)
+    a, b = outs
+    assert torch.equal(a["b0.qkv1"], b["b0.qkv1"])                         # C = 16 branch: same kernels
+    for k in ("b0.qkv2", "b0.qkv3", "b0.qkv4", "b0.xc", "X1"):
+        assert rms_rel(a[k], b[k]) < 2e-3, (k, rms_rel(a[k], b[k]), rel(a[k], b[k]))
+    assert rms_rel(a["sr"], b["sr"]) < 5e-2
