@@ -80,7 +80,7 @@ int main(int argc, char** argv) {
   std::vector<unsigned long long> hs((size_t)nwin * 8 * 16);
   CKH(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
   const int NW = (C == 256) ? 8 : 4, NS = 9;
-  const char* names[NS - 1] = {"phase0 x->LDS + W loads", "phase1 K,Q proj", "barrier1", "phase2 S/softmax + V proj", "barrier2+V store", "barrier3+PV", "barrier4+epilogue", "-"};
+  const char* names[NS - 1] = {"phase0 x,rel->LDS", "phase1 k-step loop (q|k|v proj)", "res loads + K,Q epilogue + barrier", "V store + S + softmax", "barrier + PV", "barrier", "epilogue", "-"};
   for (int wsel : {0, NW - 1}) {
     printf("wave %d: median cycles per segment over %d workgroups\n", wsel, nwin);
     for (int s = 0; s + 1 < NS; ++s) {
