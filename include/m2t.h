@@ -65,6 +65,8 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "fused_attn_fwd"    [1] bf16, C = 64 / 256 branches: qkv projection + window attention + IWT / residual epilogue in one
  *                           kernel per window (k_attn_fused.hip) instead of a GEMM launch + an attention launch
  *   "persistent_conv"   [0] bf16: conv3x3 with LDS-resident weights (bit-identical, measured slower)
+ *   "conv_variant"      [1] bf16 conv3x3: 1 = the tap-pipelined kernel; 0 = weight slices register-resident, several tiles per
+ *                           workgroup with the next halo tile in flight under the taps (>= 1024 tiles; bit-identical, measured a tie)
  *   "side_cus"          [0] CU mask size of the side stream (0 = all CUs; masking measured slower); set before the
  *                           first m2t_backward, and only effective when the caller's stream is not the NULL stream
  *   "debug_skip_side"   [0] timing experiments only: skips every parameter-gradient kernel (results are WRONG) */

@@ -89,16 +89,6 @@ __device__ __forceinline__ Frag8<bf16_t> tr8z(const bf16_t* base, int ld, int ro
   return f;
 }
 
-// Workgroup barrier that orders LDS traffic ONLY.  __syncthreads() is a workgroup-scope fence + barrier, and the fence
-// waits vmcnt(0): every outstanding global STORE of the wave must be acknowledged first -- measured 8-10 k cycles per
-// barrier behind the q | k | v stores of this kernel.  Nothing here is handed over through global memory inside the
-// workgroup, so the LDS counter is the only one that has to drain.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
 __device__ __forceinline__ bf16x4 pack4(const f32x4& a) {
   bf16x4 r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3]};
   return r;

@@ -357,6 +357,147 @@ __global__ void __launch_bounds__(256, 4) conv3x3_c64_pipe_kernel(const T* __res
   }
 }
 // ---------------------------------------------------------------------------------------
+// Weights-in-registers variant (bf16): what bounded the two kernels above was found with the fused attention kernel
+// (k_attn_fused.hip): vmcnt retires IN ORDER, so
+//   * every tap's `wait for the next weight slice` (a load issued AFTER the next tile's halo prefetch) also waits for
+//     that prefetch: it never stayed in flight under more than one tap, and each of the nine taps paid an exposed L2
+//     round trip for its 8 KB weight slice (the "13 us of tap work ADDED to the 21 us memory phase" of DESIGN.md);
+//   * the residual loads of the epilogue, issued after the first output stores, waited for those stores' acknowledgements.
+// Here a workgroup walks `tiles_per_block` tiles and loads its share of ALL nine weight slices ONCE, into registers
+// (18 fragments = 72 registers per thread; occupancy 2 workgroups per CU instead of 4, paid for by the in-workgroup
+// prefetch): inside the tile loop the only loads left are the next tile's halo (issued right after the current tile is
+// staged, first waited for at the next tile) and the residuals (issued under the last tap, before any store).
+// Same tile, lane mapping and accumulation order as conv3x3_c64_kernel: identical bits.
+// MEASURED (same-box A/B, B = 16, 128x128): 32.0 / 29.6 us forward / data gradient against 31.7 / 29.9 for the
+// tap-pipelined kernel, step 5.73 vs 5.69 ms -- a tie: removing the exposed weight round trips and halving the
+// occupancy cancel.  Kept as option "conv_variant" = 0; what bounds this conv is still open (HBM floor ~21 us).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) conv3x3_c64_wreg_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                                   const float* __restrict__ bias, const bf16_t* __restrict__ res1,
+                                                                   const bf16_t* __restrict__ res2, bf16_t* __restrict__ y, int B, int H,
+                                                                   int W, int tiles_per_block, int xcd_order) {
+  using T = bf16_t;
+  __shared__ __attribute__((aligned(16))) T Xs[(C3_TH + 2) * (C3_TW + 2)][C3_LD];
+  __shared__ __attribute__((aligned(16))) T Ws[64][C3_LD];
+  constexpr int TOT = (C3_TH + 2) * (C3_TW + 2) * 8, ITEMS = (TOT + 255) / 256;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int tw = W / C3_TW, th = H / C3_TH;
+  const int ntiles = B * th * tw;
+  const long long npix = (long long)B * H * W;
+  int chunk = blockIdx.x;
+  if (xcd_order) chunk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int t0 = chunk * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
+  if (t0 >= t1) return;
+  Frag8<T> f[ITEMS];
+  unsigned fvalid = 0;                    // bit it: item `it` of f lies inside the image (else the halo is zero)
+  auto fetch = [&](int t) {               // branch-free: clamped address, validity applied at the LDS store
+    const int tx = t % tw, q = t / tw;
+    const int ty = q % th;
+    const long long pb = (long long)(q / th) * H * W;
+    const int x0 = tx * C3_TW, y0 = ty * C3_TH;
+    fvalid = 0;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * 256;
+      const int cv = idx & 7, p = min(idx >> 3, (C3_TH + 2) * (C3_TW + 2) - 1);
+      const int py = p / (C3_TW + 2), px = p - py * (C3_TW + 2);
+      const int gy = y0 + py - 1, gx = x0 + px - 1;
+      if (idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W) fvalid |= 1u << it;
+      const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+      f[it] = load8(x + p64(npix, pb + (long long)cy * W + cx, cv * 8));
+    }
+  };
+  fetch(t0);
+  Frag8<T> wreg[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = tid + it * 256;
+      wreg[tap][it] = load8(wp + ((long long)tap * 64 + (idx >> 3)) * 64 + (idx & 7) * 8);
+    }
+  float bv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bv[e] = bias ? bias[16 * g + e] : 0.f;
+  for (int t = t0; t < t1; ++t) {
+    const int tx = t % tw, q = t / tw;
+    const int ty = q % th;
+    const long long pb = (long long)(q / th) * H * W;
+    const int x0 = tx * C3_TW, y0 = ty * C3_TH;
+    if (t > t0) lds_barrier();            // every wave is done with the previous tile's Xs
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < TOT) store8(&Xs[idx >> 3][(idx & 7) * 8], ((fvalid >> it) & 1u) ? f[it] : frag_zero<T>());
+    }
+    if (t + 1 < t1) fetch(t + 1);         // in flight under this tile's 576 MFMAs: no younger load is waited for before the last tap
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    long long off[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) off[mt] = ((long long)g * npix + pb + (long long)(y0 + 2 * wv + mt) * W + x0 + lr) * 16;
+    Frag8<T> r1[2][2], r2[2][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      lds_barrier();
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = tid + it * 256;
+        store8(&Ws[idx >> 3][(idx & 7) * 8], wreg[tap][it]);
+      }
+      lds_barrier();
+      if (tap == 8) {
+        // residuals: under the last tap, and before the first output store
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          if (res1) { r1[mt][0] = load8(res1 + off[mt]); r1[mt][1] = load8(res1 + off[mt] + 8); }
+          if (res2) { r2[mt][0] = load8(res2 + off[mt]); r2[mt][1] = load8(res2 + off[mt] + 8); }
+        }
+      }
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        Frag8<T> xf[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          xf[mt] = load8(&Xs[(2 * wv + mt + ky) * (C3_TW + 2) + lr + kx][kc * 32 + g * 8]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int nl = 16 * (lr >> 2) + 4 * nt + (lr & 3);
+          const Frag8<T> wf = load8(&Ws[nl][kc * 32 + g * 8]);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wf, xf[mt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float v[16];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += bv[e];
+      }
+      if (res1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += r1[mt][e >> 3].get(e & 7);
+      }
+      if (res2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += r2[mt][e >> 3].get(e & 7);
+      }
+      store16f(y + off[mt], v);
+    }
+  }
+}
+// ---------------------------------------------------------------------------------------
 // Persistent variant (bf16): a workgroup keeps ALL nine tap slices of the packed weights in LDS (83 KB) and sweeps
 // a strip of tiles with the halo tile double-buffered: one barrier per tile instead of eighteen, the next tile's
 // global loads (halo + residuals) in flight under the current tile's 576 MFMAs.  Same tile / wave / lane mapping
@@ -481,9 +622,10 @@ __global__ void __launch_bounds__(512) conv3x3_c64_persistent_kernel(const bf16_
 
 // bf16 takes the pipelined kernel: at most this many workgroups (8 per CU: with more tiles a workgroup walks several)
 constexpr int C3_PIPE_MAX_BLOCKS = 2048;
+constexpr int C3_WREG_BLOCKS = 512;      // the register-resident-weights kernel: 2 workgroups per CU
 
 int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias, const void* res1, const void* res2,
-                       void* y, int B, int H, int W, hipStream_t st, bool persistent) {
+                       void* y, int B, int H, int W, hipStream_t st, bool persistent, int variant) {
   if (H % C3_TH || W % C3_TW) return m2t_set_error(-2, "conv3x3_c64: H%8 or W%16");
   const long long ntiles = (long long)B * (H / C3_TH) * (W / C3_TW);
   if (dt != M2T_F32 && persistent && ntiles >= 512) {
@@ -494,6 +636,16 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
     nblk = (int)ceil_divll(ntiles, tpb);
     M2T_LAUNCH_TIMED(conv3x3_c64_persistent_kernel, dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
                        (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, B, H, W, tpb);
+    M2T_LAUNCH_CHECK();
+    return 0;
+  }
+  if (dt != M2T_F32 && variant == 0 && ntiles >= 1024) {
+    // weights register-resident, two workgroups per CU, each walking >= 2 tiles
+    const int tpb = (int)ceil_divll(ntiles, C3_WREG_BLOCKS);
+    const int nblk = (int)ceil_divll(ntiles, tpb);
+    const int xcd_order = (nblk % 8 == 0 && (long long)nblk * tpb == ntiles) ? 1 : 0;
+    M2T_LAUNCH_TIMED(conv3x3_c64_wreg_kernel, dim3(nblk), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
+                     (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, B, H, W, tpb, xcd_order);
     M2T_LAUNCH_CHECK();
     return 0;
   }

@@ -122,6 +122,8 @@ struct m2t_plan {
   int side_conv_pos = 1;           // the block's conv weight gradient: 0 first at the gate, 1 after the gated branches (same-box A/B:
                                    // +1.9 % over 0: the 512-thread, LDS-heavy kernel then meets the C = 16 instead of the C = 64 attention), 2 after the last attention (+1.8 %)
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
+  int conv_variant = 1;                // bf16 conv3x3: 1 = tap-pipelined kernel, 0 = weight slices register-resident (conv3x3_c64_wreg_kernel:
+                                       // bit-identical; same-box A/B 5.73 vs 5.69 ms per step, i.e. no gain: kept as an option)
   bool use_fused_attn_fwd = true;      // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip)
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
   // region; the descriptor table is identical every step, so it is uploaded once
@@ -421,7 +423,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     // x = feed_forward(xc) + x (:164); the last block also folds in `res + x` (:70)
     { M2TProfScope ps(M2T_PROF_CONV3_FWD, st);
       CK(launch_conv3x3_c64(dt, xc, packed_ptr(p, workspace, k + "wf"), params + p->poff.at(pre + "feed_forward.0.bias"), X,
-                            (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st, p->use_persistent_conv)); }
+                            (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st, p->use_persistent_conv, p->conv_variant)); }
   }
   void* Y = WSP("X" + std::to_string(p->nb));
   const int r0 = (s == 4) ? 2 : s;
@@ -692,7 +694,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       CK(side_conv());
       conv_done = side_marker();
     }
-    { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st, p->use_persistent_conv)); }
+    { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st, p->use_persistent_conv, p->conv_variant)); }
     for (int i = 3; i >= 0; --i) {
       const int C = BR_C[i], L = BR_L[i];
       const int h = H >> L, w = W >> L;
@@ -805,6 +807,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
   if (std::string(key) == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
+  if (std::string(key) == "conv_variant") { if (value < 0 || value > 1) return m2t_set_error(M2T_ERR_ARG, "conv_variant: 0..1"); p->conv_variant = (int)value; return 0; }
   if (std::string(key) == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
   return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");
 }

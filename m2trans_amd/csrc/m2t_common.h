@@ -209,6 +209,15 @@ __device__ __forceinline__ Frag8<float> load8_tr(const float* p0, const float* p
   return f;
 }
 
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): for kernels whose waves exchange
+// data through LDS alone.  __syncthreads() is a workgroup-scope fence + barrier; the fence may add vmcnt(0) (it does
+// whenever LDS-DMA or stores are pending in hipcc's model), draining prefetches that were meant to stay in flight.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

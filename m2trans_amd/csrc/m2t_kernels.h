@@ -120,7 +120,8 @@ int launch_head_im2col(int dt, const float* x, void* cols, int B, int H0, int W0
 // 64->64 3x3, zero padding.  wp: packed [9][64 out][64 in] (T). y = conv(x) + bias + res1 + res2 (each optional)
 int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias, const void* res1, const void* res2,
                        void* y, int B, int H, int W, hipStream_t st,
-                       bool persistent = true);   // bf16: weights-resident persistent kernel when there are enough tiles
+                       bool persistent = true,    // bf16: weights-resident (LDS) persistent kernel when there are enough tiles
+                       int variant = 1);          // bf16: 1 = tap-pipelined kernel (default), 0 = weights in registers (>= 1024 tiles)
 int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, float* bias_slabs, int* nslab, int B, int H,
                              int W, hipStream_t st);   // bias_slabs [nslab][64]: column sums of gy
 // tail conv 64->3, reflect padding, input = the stored activation gelu(t); output NCHW fp32 [B][3][H][W]
