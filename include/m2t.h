@@ -62,6 +62,10 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "tail_wgrad_main"   [0] 1: tail weight gradients on the caller's stream instead of the side stream (0.5 % slower)
  *   "fused_tail_bwd"    [1] bf16 x4: one fused kernel for the high-resolution half of the tail backward
  *   "resident_attn_bwd" [1] bf16: whole-window-resident / wave-per-window attention backward kernels
+ *   "fused_tail_fwd"    [0] bf16 x4: tail.3 expansion + PixelShuffle + GELU + tail conv in one kernel (k_tail_fwd.hip); gelu(t2) and
+ *                           gelu'(t2) (1.07 GB at batch 16) are never stored, the fused tail backward recomputes them per tile.
+ *                           Bit-identical; measured 1 % SLOWER on the step (erf re-evaluation costs more than re-reading bf16).
+ *                           Needs "fused_tail_bwd"; m2t_plan_query("stores_t2") tells whether ws:t2act / ws:t2der are written
  *   "fused_attn_fwd"    [1] bf16, C = 64 / 256 branches: qkv projection + window attention + IWT / residual epilogue in one
  *                           kernel per window (k_attn_fused.hip) instead of a GEMM launch + an attention launch
  *   "persistent_conv"   [0] bf16: conv3x3 with LDS-resident weights (bit-identical, measured slower)

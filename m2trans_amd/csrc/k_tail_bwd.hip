@@ -34,6 +34,7 @@ struct TailBwdArgs {
   const bf16_t* a1;       // a1 = gelu(t1)   [B][H/2][W/2][64]
   const bf16_t* d1;       // gelu'(t1)       [B][H/2][W/2][64]
   const bf16_t* w3t;      // packed tail.3 weight^T [64 k][256 n'], n' = sub*64 + c
+  const float* b3;        // tail.3 bias fp32 [256] in torch order (c*4 + sub); used by the recomputing variant
   bf16_t* gt1;            // g(t1)           [B][H/2][W/2][64]
   float* slab_wf;         // [nblk][32][64]   ((tap*3+oc) x ic)
   float* slab_w3;         // [nblk][256][64]  (n' x k)
@@ -53,6 +54,12 @@ __device__ __forceinline__ Frag8<bf16_t> tr_rows(const bf16_t* lo, const bf16_t*
 // HR tile row of (mid pixel m = my*8 + mx, sub = i*2 + j)
 __device__ __forceinline__ int hr_row(int m, int sub) { return (2 * (m >> 3) + (sub >> 1)) * TB_T + 2 * (m & 7) + (sub & 1); }
 
+// RC (recompute): a2 = gelu(t2) and gelu'(t2) are NOT read from HBM (the forward then never stores them: 1.07 GB per
+// step at batch 16) but recomputed per tile from the a1 tile that is staged anyway: t2 = W3 a1 + b3 is 128 MFMAs per tile,
+// the two erf-based functions 32 elements per thread.  Same operand fragments, k order, bias add and gelu_erf_both as
+// tail_expand_kernel (k_gemm.hip), so the recomputed values are the bits the forward would have stored.  gelu'(t2) is
+// written where g(t2) goes (the product is formed in place), so the LDS footprint does not grow.
+template <bool RC>
 __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -110,11 +117,13 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
   auto fetchA = [&](long long t) {              // staged through LDS: a2 tile, a1 tile, g(sr) halo
     int b, y0, x0;
     tile_geom(t, b, y0, x0);
+    if constexpr (!RC) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = tid + it * 512;
-      const int p = idx >> 3, cv = idx & 7;
-      ra2[it] = load8(a.act + (((long long)b * H + y0 + (p >> 4)) * W + x0 + (p & 15)) * 64 + cv * 8);
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * 512;
+        const int p = idx >> 3, cv = idx & 7;
+        ra2[it] = load8(a.act + (((long long)b * H + y0 + (p >> 4)) * W + x0 + (p & 15)) * 64 + cv * 8);
+      }
     }
     {
       const int m = tid >> 3, cv = tid & 7;
@@ -137,10 +146,12 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
     tile_geom(t, b, y0, x0);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const int p = 16 * (2 * w8 + mt) + lr;
-      const T* dp = a.der + (((long long)b * H + y0 + (p >> 4)) * W + x0 + (p & 15)) * 64 + 16 * g;
-      rder[mt][0] = load8(dp);
-      rder[mt][1] = load8(dp + 8);
+      if constexpr (!RC) {
+        const int p = 16 * (2 * w8 + mt) + lr;
+        const T* dp = a.der + (((long long)b * H + y0 + (p >> 4)) * W + x0 + (p & 15)) * 64 + 16 * g;
+        rder[mt][0] = load8(dp);
+        rder[mt][1] = load8(dp + 8);
+      }
       const int m = 16 * (2 * mh + mt) + lr;
       rd1[mt] = *reinterpret_cast<const bf16x4*>(a.d1 + (((long long)b * Hm + y0 / 2 + (m >> 3)) * Wm + x0 / 2 + (m & 7)) * 64 + 16 * kt + 4 * g);
     }
@@ -151,10 +162,12 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
     int b, y0, x0;
     tile_geom(t, b, y0, x0);
     // ---- stage ----
+    if constexpr (!RC) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int idx = tid + it * 512;
-      store8(&A2[idx >> 3][(idx & 7) * 8], ra2[it]);
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + it * 512;
+        store8(&A2[idx >> 3][(idx & 7) * 8], ra2[it]);
+      }
     }
     store8(&A1[tid >> 3][(tid & 7) * 8], ra1);
 #pragma unroll
@@ -164,6 +177,35 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
     }
     __syncthreads();
     if (t + tstep < t1) fetchA(t + tstep);              // next tile's loads fly under this tile's products
+    if constexpr (RC) {
+      // ---- recompute t2^T [n'][m] = W3 [n'][k] a1^T [k][m] + b3: wave w8 owns n' tiles 2 w8, 2 w8 + 1 (one sub-pixel
+      // and channel tile each), all four mid-pixel tiles; a2 -> A2, gelu'(t2) -> Gz (g(t2) is formed in place there)
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const int nt = 2 * w8 + o, sub = nt >> 2, ct = nt & 3;
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          const Frag8<T> wf = load8_tr(&W3s[32 * kc + 8 * g][16 * nt], &W3s[32 * kc + 8 * g + 4][16 * nt], 264, lane);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) mma16(acc[mt], wf, load8(&A1[16 * mt + lr][32 * kc + 8 * g]));
+        }
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = a.b3[(16 * ct + 4 * g + r) * 4 + sub];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          float av[4], dv[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gelu_erf_both(acc[mt][r] + bv[r], av[r], dv[r]);
+          const int row = hr_row(16 * mt + lr, sub);
+          store4(&A2[row][16 * ct + 4 * g], av);
+          store4(&Gz[row][16 * ct + 4 * g], dv);
+        }
+      }
+    }
     // ---- Geff: one thread per tile pixel builds its 27 gathered taps (reflect ring folded in) ----
     // Only pixels in image rows / columns 1 and n-2 receive extra reads through the padding ring, so a tile that
     // does not touch the image border takes the branch-free path: tap (ky,kx) of pixel (ty,tx) is the halo
@@ -229,10 +271,19 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
         mma16(acc[nt], load8(&Wt[nl][8 * g]), xf);
       }
       float v[16];
+      if constexpr (RC) {
+        float d[16];
+        load16f(&Gz[16 * pt + lr][16 * g], d);       // gelu'(t2), written by the recompute phase (same barrier as Geff)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[nt][r] * rder[mt][nt >> 1].get(4 * (nt & 1) + r);
+          for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[nt][r] * d[4 * nt + r];
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[nt][r] * rder[mt][nt >> 1].get(4 * (nt & 1) + r);
+      }
       store16f(&Gz[16 * pt + lr][16 * g], v);
     }
     // ---- dWf += Geff^T a2 (contraction over the 256 tile pixels): wave -> ((tap,oc) tile w8 >> 2, ic tile w8 & 3) ----
@@ -330,17 +381,24 @@ int tail_bwd_fused_blocks(int B, int H, int W) {
 
 // bf16 only.  H, W: high-resolution size (multiples of 32).  nslab_out: slabs written (same count for the three sets).
 int launch_tail_bwd_fused(const float* gout, const float* wf, const void* act, const void* der, const void* a1, const void* d1,
-                          const void* w3t, void* gt1, float* slab_wf, float* slab_w3, float* slab_b3, int* nslab_out, int B, int H,
-                          int W, hipStream_t st) {
+                          const void* w3t, const float* b3, void* gt1, float* slab_wf, float* slab_w3, float* slab_b3, int* nslab_out,
+                          int B, int H, int W, hipStream_t st) {
+  // act == nullptr: the forward did not store gelu(t2) / gelu'(t2); they are recomputed per tile from a1, w3t and b3
   if (H % 32 || W % 32) return m2t_set_error(-2, "tail_bwd_fused: H, W must be multiples of 32");
   const long long ntiles = (long long)B * (H / TB_T) * (W / TB_T);
   (void)ntiles;
   const int nblk = tail_bwd_fused_blocks(B, H, W);
   const size_t sh = tail_bwd_smem();
-  if (int rc__ = m2t_ensure_dynamic_lds((const void*)tail_bwd_fused_kernel, (int)sh)) return rc__;
-  TailBwdArgs a{gout, wf, (const bf16_t*)act, (const bf16_t*)der, (const bf16_t*)a1, (const bf16_t*)d1, (const bf16_t*)w3t,
+  TailBwdArgs a{gout, wf, (const bf16_t*)act, (const bf16_t*)der, (const bf16_t*)a1, (const bf16_t*)d1, (const bf16_t*)w3t, b3,
                 (bf16_t*)gt1, slab_wf, slab_w3, slab_b3, B, H, W};
-  M2T_LAUNCH_TIMED(tail_bwd_fused_kernel, dim3(nblk), dim3(512), sh, st, a);
+  if (act == nullptr) {
+    if (!b3) return m2t_set_error(-2, "tail_bwd_fused: the recomputing variant needs the tail.3 bias");
+    if (int rc__ = m2t_ensure_dynamic_lds((const void*)tail_bwd_fused_kernel<true>, (int)sh)) return rc__;
+    M2T_LAUNCH_TIMED(tail_bwd_fused_kernel<true>, dim3(nblk), dim3(512), sh, st, a);
+  } else {
+    if (int rc__ = m2t_ensure_dynamic_lds((const void*)tail_bwd_fused_kernel<false>, (int)sh)) return rc__;
+    M2T_LAUNCH_TIMED(tail_bwd_fused_kernel<false>, dim3(nblk), dim3(512), sh, st, a);
+  }
   M2T_LAUNCH_CHECK();
   *nslab_out = nblk;
   return 0;

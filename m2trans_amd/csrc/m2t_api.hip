@@ -122,6 +122,11 @@ struct m2t_plan {
   int side_conv_pos = 1;           // the block's conv weight gradient: 0 first at the gate, 1 after the gated branches (same-box A/B:
                                    // +1.9 % over 0: the 512-thread, LDS-heavy kernel then meets the C = 16 instead of the C = 64 attention), 2 after the last attention (+1.8 %)
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
+  bool use_fused_tail_fwd = false;     // bf16 x4: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored;
+                                       // the fused tail backward then recomputes them (needs fused_tail_bwd).  Bit-identical and
+                                       // 1.6 GB less HBM traffic per step, but SLOWER (same-box A/B 5.73 vs 5.67 ms): the erf behind
+                                       // GELU is paid 1.56x (halo) in the forward and again in the backward (389 + 426 us against
+                                       // 280 + 170 + 340 us), and a stored bf16 is cheaper to re-read than an erf is to re-evaluate
   int conv_variant = 1;                // bf16 conv3x3: 1 = tap-pipelined kernel, 0 = weight slices register-resident (conv3x3_c64_wreg_kernel:
                                        // bit-identical; same-box A/B 5.73 vs 5.69 ms per step, i.e. no gain: kept as an option)
   bool use_fused_attn_fwd = true;      // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip)
@@ -349,6 +354,8 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
   if (k.rfind("ws:", 0) == 0) { auto it = p->ws.find(k.substr(3)); return it == p->ws.end() ? -1 : (long long)it->second.off; }
   if (k.rfind("wsn:", 0) == 0) { auto it = p->ws.find(k.substr(4)); return it == p->ws.end() ? -1 : (long long)it->second.n; }
   if (k.rfind("packed:", 0) == 0) { auto it = p->pk.find(k.substr(7)); return it == p->pk.end() ? -1 : it->second; }
+  // which stored tensors the current options leave unwritten (tests read the workspace by name)
+  if (k == "stores_t2") return (p->scale == 4 && !(p->dt != M2T_F32 && p->use_fused_tail_fwd && p->use_fused_tail_bwd)) ? 1 : 0;
   return -1;
 }
 
@@ -430,14 +437,20 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
   { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st);
     CK(launch_tail_expand(dt, Y, packed_ptr(p, workspace, "t0"), params + p->poff.at("tail.0.bias"), WSP("t1act"), WSP("t1der"), BP, H, W, r0, true, st)); }
   const void* last_act = WSP("t1act");
+  const float* wlast = params + p->poff.at(s == 4 ? "tail.6.weight" : "tail.3.weight");
+  if (s == 4 && dt != M2T_F32 && p->use_fused_tail_fwd && p->use_fused_tail_bwd) {
+    M2TProfScope ps(M2T_PROF_TAIL_FWD_FUSED, st);
+    CK(launch_tail_fwd_fused(WSP("t1act"), packed_ptr(p, workspace, "t3"), params + p->poff.at("tail.3.bias"), wlast, (float*)WSP("srpre"),
+                             B, p->Hsp, p->Wsp, st));
+  } else {
   if (s == 4) {
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st);
       CK(launch_tail_expand(dt, WSP("t1act"), packed_ptr(p, workspace, "t3"), params + p->poff.at("tail.3.bias"), WSP("t2act"), WSP("t2der"),
                             BP * 4, 2 * H, 2 * W, 2, false, st)); }
     last_act = WSP("t2act");
   }
-  const float* wlast = params + p->poff.at(s == 4 ? "tail.6.weight" : "tail.3.weight");
   { M2TProfScope ps(M2T_PROF_FINAL_FWD, st); CK(launch_final_conv_fwd(dt, last_act, wlast, (float*)WSP("srpre"), B, p->Hsp, p->Wsp, st)); }
+  }
   if (sr)
     CK(launch_clamp_l1((const float*)WSP("srpre"), nullptr, sr, nullptr, nullptr, nullptr, B, p->Hsp, p->Wsp, p->Hs,
                        p->Ws, rgb_range, 0.f, 0.f, st));
@@ -579,8 +592,10 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     ARENA(sw3, (size_t)nb * 256 * 64);
     ARENA(sb3, (size_t)nb * 256);
     { M2TProfScope ps(M2T_PROF_FINAL_DGRAD, st);
-      CK(launch_tail_bwd_fused(gpre, params + p->poff.at(wl), WSP("t2act"), WSP("t2der"), WSP("t1act"), WSP("t1der"),
-                               packed_ptr(p, workspace, "t3T"), WSP("g_t1pre"), swf, sw3, sb3, &ns, B, p->Hsp, p->Wsp, st)); }
+      const bool rc = p->use_fused_tail_fwd;       // the forward did not store gelu(t2) / gelu'(t2): recompute per tile
+      CK(launch_tail_bwd_fused(gpre, params + p->poff.at(wl), rc ? nullptr : WSP("t2act"), rc ? nullptr : WSP("t2der"), WSP("t1act"),
+                               WSP("t1der"), packed_ptr(p, workspace, "t3T"), params + p->poff.at("tail.3.bias"), WSP("g_t1pre"), swf, sw3,
+                               sb3, &ns, B, p->Hsp, p->Wsp, st)); }
     defer(swf, p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0);
     defer(sw3, p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64);
     defer(sb3, p->poff.at("tail.3.bias"), ns, 256, 2, 64, 4, 1);
@@ -807,6 +822,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
   if (std::string(key) == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
+  if (std::string(key) == "fused_tail_fwd") { p->use_fused_tail_fwd = (value != 0); p->have_acts = false; return 0; }
   if (std::string(key) == "conv_variant") { if (value < 0 || value > 1) return m2t_set_error(M2T_ERR_ARG, "conv_variant: 0..1"); p->conv_variant = (int)value; return 0; }
   if (std::string(key) == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
   return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");

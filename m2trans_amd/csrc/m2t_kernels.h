@@ -31,6 +31,7 @@ enum m2t_prof_cat {
   M2T_PROF_GEMM_QKV, M2T_PROF_GEMM_QKV_DGRAD, M2T_PROF_WGRAD_QKV,
   M2T_PROF_TAIL_GEMM, M2T_PROF_TAIL_WGRAD, M2T_PROF_FINAL_FWD, M2T_PROF_FINAL_DGRAD, M2T_PROF_FINAL_WGRAD,
   M2T_PROF_ATTN_FUSED_64, M2T_PROF_ATTN_FUSED_256,      // fused qkv projection + window attention forward (k_attn_fused.hip)
+  M2T_PROF_TAIL_FWD_FUSED,                              // tail.3 expansion + PixelShuffle + GELU + tail conv (k_tail_fwd.hip)
   M2T_PROF_NCAT
 };
 void m2t_prof_begin(int cat, hipStream_t st);
@@ -39,7 +40,7 @@ void m2t_prof_end(int cat, hipStream_t st);
 // (hipExtLaunchKernelGGL start / stop events = the dispatch's own begin / end timestamps, the quantity rocprofv3
 // reports) instead of bracketing it with marker packets, which add the ~5 us launch gap to every sample.
 #define M2T_PROF_DISPATCH_CATS ((1ull << M2T_PROF_GEMM_QKV) - 1ull | (1ull << M2T_PROF_FINAL_FWD) | (1ull << M2T_PROF_FINAL_DGRAD) | (1ull << M2T_PROF_FINAL_WGRAD) | \
-                                (1ull << M2T_PROF_ATTN_FUSED_64) | (1ull << M2T_PROF_ATTN_FUSED_256))
+                                (1ull << M2T_PROF_ATTN_FUSED_64) | (1ull << M2T_PROF_ATTN_FUSED_256) | (1ull << M2T_PROF_TAIL_FWD_FUSED))
 bool m2t_prof_take(hipEvent_t* a, hipEvent_t* b);
 #define M2T_LAUNCH_TIMED(kernel, grid, block, sh, st, ...)                                                       \
   do {                                                                                                           \
@@ -135,14 +136,20 @@ int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* 
 // one CFTM branch of the forward pass (prep + qkv projection + window attention + IWT/residual) per window;
 #define M2T_UNSUPPORTED (-1000)
 
+// ---- k_tail_fwd.hip ----------------------------------------------------------------------
+// x4 tail, bf16: tail.3 expansion + PixelShuffle + GELU + tail conv in one pass; gelu(t2) never reaches HBM.
+int launch_tail_fwd_fused(const void* a1, const void* w3p, const float* b3, const float* wf, float* out, int B, int H, int W,
+                          hipStream_t st);
+
 // ---- k_tail_bwd.hip ----------------------------------------------------------------------
 // x4 tail, bf16: tail conv data + weight gradient, GELU backward, tail.3 data + weight + bias gradient in one pass
 // over the stored activation / derivative tensors (g(t2) never reaches HBM).  Slabs: wf [n][32][64], w3 [n][256][64],
 // b3 [n][256]; n = *nslab_out <= tail_bwd_fused_blocks().
 int tail_bwd_fused_blocks(int B, int H, int W);
+// act == der == nullptr: gelu(t2) / gelu'(t2) are recomputed per tile from a1, w3t and the tail.3 bias b3 (torch order)
 int launch_tail_bwd_fused(const float* gout, const float* wf, const void* act, const void* der, const void* a1, const void* d1,
-                          const void* w3t, void* gt1, float* slab_wf, float* slab_w3, float* slab_b3, int* nslab_out, int B, int H,
-                          int W, hipStream_t st);
+                          const void* w3t, const float* b3, void* gt1, float* slab_wf, float* slab_w3, float* slab_b3,
+                          int* nslab_out, int B, int H, int W, hipStream_t st);
 
 // ---- k_attn.hip -------------------------------------------------------------------------
 // qkv [B][h][w][3C] (q | k | v), rel_h/rel_w fp32 [10][C/2];  out rows at ldo (+ optional residual rows at ldr)

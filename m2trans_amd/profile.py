@@ -25,7 +25,7 @@ from . import _lib
 CATS = ["attn_fwd_c16", "attn_fwd_c64", "attn_fwd_c256", "attn_bwd_c16", "attn_bwd_c64", "attn_bwd_c256",
         "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "gemm_qkv", "gemm_qkv_dgrad", "wgrad_qkv",
         "tail_gemm", "tail_wgrad", "final_conv_fwd", "final_conv_dgrad", "final_conv_wgrad",
-        "attn_fused_c64", "attn_fused_c256"]
+        "attn_fused_c64", "attn_fused_c256", "tail_fwd_fused"]
 KERNEL_OF = {
     "attn_fwd_c16": "window_attn_fwd_kernel<C=16>", "attn_fwd_c64": "window_attn_fwd_kernel<C=64>",
     "attn_fwd_c256": "window_attn_fwd_kernel<C=256>", "attn_bwd_c16": "window_attn_bwd_kernel<C=16>",
@@ -38,6 +38,7 @@ KERNEL_OF = {
     "final_conv_wgrad": "final_conv_wgrad_kernel",
     "attn_fused_c64": "window_attn_fused_fwd_kernel<C=64,L=1> (qkv projection + window attention + IWT/residual)",
     "attn_fused_c256": "window_attn_fused_fwd_kernel<C=256,L=2> (qkv projection + window attention + IWT^2/residual)",
+    "tail_fwd_fused": "tail_fwd_fused_kernel (tail.3 1x1 expansion + PixelShuffle + GELU + tail conv)",
 }
 KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these categories
     "attn_fwd_c16": "window_attn_fwd_c16_kernel (wave per window)",
@@ -115,7 +116,13 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         add("tail_wgrad", 2.0 * M * 64 * 64 * r2, M * (64 + 64 * r2) * es, 1)
         HR = r2 * B * P
     fin = 2.0 * HR * 64 * 27
-    add("final_conv_fwd", fin, HR * (64 * es + 12), 1)
+    if scale == 4 and dtype == "bf16":
+        # fused forward tail (k_tail_fwd.hip): reads gelu(t1) (HR/4 pixels x 64), writes the fp32 output; tail.3 expansion + tail conv
+        w["tail_fwd_fused"] = (fin + 2.0 * (HR // 4) * 64 * 256, (HR // 4) * 64 * es + HR * 12, 1)
+        f0, b0, n0 = w["tail_gemm"]
+        w["tail_gemm"] = (f0 - 2.0 * (HR // 4) * 64 * 256, b0 - (HR // 4) * (64 + 256) * es, n0 - 1)
+    else:
+        add("final_conv_fwd", fin, HR * (64 * es + 12), 1)
     if scale == 4 and dtype == "bf16":
         # fused tail backward (k_tail_bwd.hip): tail conv dgrad + wgrad, GELU', tail.3 dgrad + wgrad in one pass:
         # reads gelu(t2), gelu'(t2) (HR), gelu(t1), gelu'(t1) (HR/4), g(sr); writes g(t1) (HR/4)

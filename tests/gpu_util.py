@@ -71,7 +71,7 @@ def hip_forward_trace(plan, scale, n_blocks, B, H, W):
     r0 = 2 if scale == 4 else scale
     for nm in ("t1act", "t1der"):
         t[nm] = ws_nchw(plan, nm, B, H * r0, W * r0, 64)
-    if scale == 4:
+    if scale == 4 and plan.query("stores_t2") == 1:        # the fused forward tail keeps gelu(t2) / gelu'(t2) in LDS
         for nm in ("t2act", "t2der"):
             t[nm] = ws_nchw(plan, nm, B, H * 4, W * 4, 64)
     t["srpre"] = plan.ws_tensor("srpre", dtype=torch.float32).view(B, 3, H * scale, W * scale).cpu().clone()

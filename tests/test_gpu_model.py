@@ -458,3 +458,26 @@ def test_conv3x3_register_resident_weights_kernel_is_bit_identical():
             outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone()))
         assert torch.equal(outs[0][0], outs[1][0])
         assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():
+    """bf16 x4: tail.3 expansion + PixelShuffle + GELU + tail conv in one kernel (gelu(t2) / gelu'(t2) never stored) and the
+    fused tail backward that recomputes them per tile, against the kernels that store and re-read them.  Same operand
+    fragments, k order, bias add, erf evaluation and tap summation -> the output and EVERY gradient must agree bit for
+    bit.  Sizes: a reflect-padded 40x56 input (64x64 padded: border tiles only) and 128x96 (interior tiles too)."""
+    from m2trans_amd import _lib
+    for (B, H, W) in ((2, 40, 56), (3, 128, 96)):
+        scale, nb = 4, 1
+        x = O.closed_form_image(B, 3, H, W).cuda()
+        hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+        outs = []
+        for fused in (1, 0):
+            model, _ = build_model(scale, nb, "bf16")
+            plan = model._plan_for(x)
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_tail_fwd", fused), "m2t_set_option")
+            assert plan.query("stores_t2") == 1 - fused
+            sr = model(x)
+            torch.nn.L1Loss()(sr, hr).backward()
+            outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone()))
+        assert torch.equal(outs[0][0], outs[1][0]), (B, H, W)
+        assert torch.equal(outs[0][1], outs[1][1]), (B, H, W)
