@@ -115,6 +115,9 @@ int launch_head_im2col(int dt, const float* x, void* cols, int B, int H0, int W0
 // current tap's 64x64 weight slice.  Lane (pixel = lane&15, g = lane>>4) ends with 16
 // consecutive output channels at 16 g.
 // =======================================================================================
+#ifndef M2T_CONV_STAMP
+#define M2T_CONV_STAMP(i) do { } while (0)      // scratch/bench_conv.hip defines it to record s_memtime per phase
+#endif
 #define C3_TH 8
 #define C3_TW 16
 #define C3_LD 72   // 64 channels + 8 pad
@@ -271,6 +274,7 @@ __global__ void __launch_bounds__(256, 4) conv3x3_c64_pipe_kernel(const T* __res
       f[it] = load8(x + p64(npix, pb + (long long)cy * W + cx, cv * 8));
     }
   };
+  M2T_CONV_STAMP(0);
   if (t0 < t1) fetch(t0);
   for (int t = t0; t < t1; ++t) {
     const int tx = t % tw, q = t / tw;
@@ -283,6 +287,7 @@ __global__ void __launch_bounds__(256, 4) conv3x3_c64_pipe_kernel(const T* __res
       const int idx = tid + it * 256;
       if (idx < TOT) store8(&Xs[idx >> 3][(idx & 7) * 8], ((fvalid >> it) & 1u) ? f[it] : frag_zero<T>());
     }
+    M2T_CONV_STAMP(1);
     if (t + 1 < t1) fetch(t + 1);         // in flight under this tile's 576 MFMAs
     f32x4 acc[2][4];
 #pragma unroll
@@ -327,6 +332,7 @@ __global__ void __launch_bounds__(256, 4) conv3x3_c64_pipe_kernel(const T* __res
         }
       }
     }
+    M2T_CONV_STAMP(2);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int gy = y0 + 2 * wv + mt, gx = x0 + lr;
@@ -354,6 +360,7 @@ __global__ void __launch_bounds__(256, 4) conv3x3_c64_pipe_kernel(const T* __res
       }
       store16f(y + off, v);
     }
+    M2T_CONV_STAMP(3);
   }
 }
 // ---------------------------------------------------------------------------------------
@@ -526,25 +533,39 @@ __global__ void __launch_bounds__(512) conv3x3_c64_persistent_kernel(const bf16_
   const long long npix = (long long)B * H * W;                    // P64 feature maps
   const long long t0 = (long long)blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
   if (t0 >= t1) return;
-  for (int idx = threadIdx.x; idx < 9 * 64 * 8; idx += 512) store8(&Ws[0][idx >> 3][(idx & 7) * 8], load8(wp + (long long)(idx >> 3) * 64 + (idx & 7) * 8));
+  {
+    Frag8<T> wr[9];                       // every load first, then the LDS stores (a rolled load -> store loop pays nine L2 round trips)
+#pragma unroll
+    for (int it = 0; it < 9; ++it) { const int idx = threadIdx.x + it * 512; wr[it] = load8(wp + (long long)(idx >> 3) * 64 + (idx & 7) * 8); }
+#pragma unroll
+    for (int it = 0; it < 9; ++it) { const int idx = threadIdx.x + it * 512; store8(&Ws[0][idx >> 3][(idx & 7) * 8], wr[it]); }
+  }
   Frag8<T> f[ITEMS];
+  unsigned fvalid = 0;                    // bit it: item `it` of f lies inside the image (else the halo is zero)
+  // branch-free (clamped address + validity bit): a load under a lane-dependent branch makes hipcc wait vmcnt(0) per load
   auto fetch = [&](long long t) {
     const int tx = (int)(t % tw);
     const long long q = t / tw;
     const int ty = (int)(q % th);
     const long long pb = (q / th) * H * W;
     const int x0 = tx * C3_TW, y0 = ty * C3_TH;
+    fvalid = 0;
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
       const int idx = tid + it * 256;
-      const int cv = idx & 7, p = idx >> 3;
+      const int cv = idx & 7, p = min(idx >> 3, HP - 1);
       const int py = p / (C3_TW + 2), px = p - py * (C3_TW + 2);
       const int gy = y0 + py - 1, gx = x0 + px - 1;
-      f[it] = frag_zero<T>();
-      if (idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W) f[it] = load8(x + p64(npix, pb + (long long)gy * W + gx, cv * 8));
+      if (idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W) fvalid |= 1u << it;
+      const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+      f[it] = load8(x + p64(npix, pb + (long long)cy * W + cx, cv * 8));
     }
   };
-  if (t0 + grp < t1) fetch(t0 + grp);
+  M2T_CONV_STAMP(0);
+  if (t0 + grp < t1) fetch(min(t0 + grp, t1 - 1));
+  float bv[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bv[e] = bias ? bias[16 * g + e] : 0.f;
   for (long long tp = t0; tp < t1; tp += 2) {
     const long long t = tp + grp;
     const bool live = t < t1;
@@ -552,48 +573,54 @@ __global__ void __launch_bounds__(512) conv3x3_c64_persistent_kernel(const bf16_
 #pragma unroll
       for (int it = 0; it < ITEMS; ++it) {
         const int idx = tid + it * 256;
-        if (idx < TOT) store8(&Xs[grp][idx >> 3][(idx & 7) * 8], f[it]);
+        if (idx < TOT) store8(&Xs[grp][idx >> 3][(idx & 7) * 8], ((fvalid >> it) & 1u) ? f[it] : frag_zero<T>());
       }
     }
-    __syncthreads();
+    lds_barrier();
+    if (tp == t0 + 2) M2T_CONV_STAMP(1);
+    const long long tc = live ? t : t1 - 1;                 // (an idle group of the last pair recomputes a tile and discards it)
+    const int tx = (int)(tc % tw);
+    const long long q = tc / tw;
+    const int ty = (int)(q % th);
+    const long long pb = (q / th) * H * W;
+    const int x0 = tx * C3_TW, y0 = ty * C3_TH;
+    // vmcnt retires in order: the residuals (needed by the epilogue) are issued BEFORE the next pair's halo, so that the
+    // epilogue's wait leaves the halo loads in flight; the stores come last and nothing issued later is waited for before
+    // the next tile's halo, which is older than they are
+    Frag8<T> r1[2][2], r2[2][2];
+    long long off[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      off[mt] = ((long long)g * npix + pb + (long long)(y0 + 2 * wv + mt) * W + x0 + lr) * 16;
+      if (res1) { r1[mt][0] = load8(res1 + off[mt]); r1[mt][1] = load8(res1 + off[mt] + 8); }
+      if (res2) { r2[mt][0] = load8(res2 + off[mt]); r2[mt][1] = load8(res2 + off[mt] + 8); }
+    }
     if (t + 2 < t1) fetch(t + 2);
-    if (live) {
-      const int tx = (int)(t % tw);
-      const long long q = t / tw;
-      const int ty = (int)(q % th);
-      const long long pb = (q / th) * H * W;
-      const int x0 = tx * C3_TW, y0 = ty * C3_TH;
-      float r1[2][16], r2[2][16];
-      long long off[2];
+    f32x4 acc[2][4];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        off[mt] = ((long long)g * npix + pb + (long long)(y0 + 2 * wv + mt) * W + x0 + lr) * 16;
-        if (res1) load16f(res1 + off[mt], r1[mt]);
-        if (res2) load16f(res2 + off[mt], r2[mt]);
-      }
-      f32x4 acc[2][4];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - ky * 3;
+      for (int kc = 0; kc < 2; ++kc) {
+        Frag8<T> xf[2];
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-          Frag8<T> xf[2];
+        for (int mt = 0; mt < 2; ++mt)
+          xf[mt] = load8(&Xs[grp][(2 * wv + mt + ky) * (C3_TW + 2) + lr + kx][kc * 32 + g * 8]);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
-            xf[mt] = load8(&Xs[grp][(2 * wv + mt + ky) * (C3_TW + 2) + lr + kx][kc * 32 + g * 8]);
+        for (int nt = 0; nt < 4; ++nt) {
+          const int nl = 16 * (lr >> 2) + 4 * nt + (lr & 3);
+          const Frag8<T> wf = load8(&Ws[tap][nl][kc * 32 + g * 8]);
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const int nl = 16 * (lr >> 2) + 4 * nt + (lr & 3);
-            const Frag8<T> wf = load8(&Ws[tap][nl][kc * 32 + g * 8]);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wf, xf[mt]);
-          }
+          for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wf, xf[mt]);
         }
       }
+    }
+    if (tp == t0 + 2) M2T_CONV_STAMP(2);
+    if (live) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         float v[16];
@@ -603,20 +630,181 @@ __global__ void __launch_bounds__(512) conv3x3_c64_persistent_kernel(const bf16_
           for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
         if (bias) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += bias[16 * g + e];
+          for (int e = 0; e < 16; ++e) v[e] += bv[e];
         }
         if (res1) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += r1[mt][e];
+          for (int e = 0; e < 16; ++e) v[e] += r1[mt][e >> 3].get(e & 7);
         }
         if (res2) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += r2[mt][e];
+          for (int e = 0; e < 16; ++e) v[e] += r2[mt][e >> 3].get(e & 7);
         }
         store16f(y + off[mt], v);
       }
     }
-    __syncthreads();          // both halo buffers are free for the next pair
+    if (tp == t0 + 2) M2T_CONV_STAMP(3);
+    lds_barrier();            // both halo buffers are free for the next pair
+    if (tp == t0 + 2) M2T_CONV_STAMP(4);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// v2 (bf16): what the three kernels above have in common is their LDS operand traffic: a wave multiplies 2 pixel tiles
+// by 4 channel tiles per (tap, k-chunk), i.e. 6 fragment reads per 8 MFMAs, two thirds of them WEIGHT fragments that
+// every wave re-reads for every tile, and with the 144-byte rows the weight rows a lane group touches (16 apart) fall on
+// the same banks (2-way).  Per pair of tiles that is 864 KB of ds_read_b128 at ~1.7 cycles each: ~5.6 k cycles of LDS
+// against 4.6 k cycles of MFMA -- the taps phase measured 8.7 k cycles (scratch/bench_conv.hip), the kernel 30 us.
+// Here: 16 x 16-pixel tiles, a wave owns 4 pixel rows x all 64 channels = 4 x 4 tiles in 64 accumulators, so one
+// (tap, k-chunk) step reads 4 + 4 fragments for 16 MFMAs (2.25 instead of 3.4 KB of LDS reads per output pixel); rows
+// are 128 bytes with the 16-byte chunk index XOR-swizzled by ((row >> 1) & 7), which makes every fragment read
+// conflict-free (16 consecutive rows -> 16 distinct 16-byte slots of the 256-byte bank row), and the weight rows are
+// stored pre-permuted so that consecutive LDS rows are the rows a lane group needs.  All nine weight slices stay in LDS
+// for the whole launch (73.7 KB) beside two halo tiles (2 x 41.5 KB): one 8-wave workgroup per CU, two tiles in lockstep,
+// next pair's halo + this pair's residuals in flight under the taps (issue order chosen for the in-order vmcnt: residuals
+// first, halo prefetch second, stores last).  Same per-output accumulation order (tap-major, k-chunk inner) as
+// conv3x3_c64_kernel: identical bits.
+// ---------------------------------------------------------------------------------------
+#define C3V_T 16
+#define C3V_HP ((C3V_T + 2) * (C3V_T + 2))      // 324 halo pixels
+__device__ __forceinline__ int c3v_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }   // element offset
+
+template <int NRES>       // residual tensors added in the epilogue (0: data gradient, 1: forward, 2: forward of the last block)
+__global__ void __launch_bounds__(512) conv3x3_c64_v2_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                             const float* __restrict__ bias, const bf16_t* __restrict__ res1,
+                                                             const bf16_t* __restrict__ res2, bf16_t* __restrict__ y, int B, int H,
+                                                             int W, int tiles_per_block, int xcd_order) {
+  using T = bf16_t;
+  constexpr int TOT = C3V_HP * 8, ITEMS = (TOT + 255) / 256;      // 16-byte vectors of a halo tile: 11 per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T* Ws = reinterpret_cast<T*>(smem);                                          // [9][64 permuted rows][64], swizzled
+  T* Xg = reinterpret_cast<T*>(smem + sizeof(T) * 9 * 64 * 64);                // [2 groups][324][64], swizzled
+  float* Bs = reinterpret_cast<float*>(smem + sizeof(T) * 64 * (9 * 64 + 2 * C3V_HP));     // bias [64]
+  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  T* Xs = Xg + grp * (C3V_HP * 64);
+  const int tw = W / C3V_T, th = H / C3V_T;
+  const int ntiles = B * th * tw;
+  const long long npix = (long long)B * H * W;                    // P64 feature maps
+  int chunk = blockIdx.x;
+  if (xcd_order) chunk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int t0 = chunk * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
+  if (t0 >= t1) return;
+  Frag8<T> f[ITEMS];
+  unsigned fvalid = 0;
+  auto fetch = [&](int t) {               // branch-free: clamped address, validity applied at the LDS store
+    const int tx = t % tw, q = t / tw;
+    const int ty = q % th;
+    const long long pb = (long long)(q / th) * H * W;
+    const int x0 = tx * C3V_T, y0 = ty * C3V_T;
+    fvalid = 0;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * 256;
+      const int cv = idx & 7, p = min(idx >> 3, C3V_HP - 1);
+      const int py = p / (C3V_T + 2), px = p - py * (C3V_T + 2);
+      const int gy = y0 + py - 1, gx = x0 + px - 1;
+      if (idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W) fvalid |= 1u << it;
+      const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+      f[it] = load8(x + p64(npix, pb + (long long)cy * W + cx, cv * 8));
+    }
+  };
+  M2T_CONV_STAMP(0);
+  fetch(min(t0 + grp, t1 - 1));
+  // weights: LDS row 16 nt + i of a slice holds packed row 16 (i >> 2) + 4 nt + (i & 3): the 16 rows an A-operand tile reads
+  // are then consecutive, and lane (i, g) still ends with output channels 16 g + 4 nt + r of its pixel
+  // (every load first, then the LDS stores: as a rolled load -> store loop each of the nine trips paid its own L2 round
+  //  trip and the prologue took 23 k cycles -- 40 % of the kernel)
+  {
+    Frag8<T> wr[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int idx = threadIdx.x + tap * 512;                  // one 64 x 64 slice per trip: 512 vectors
+      const int cv = idx & 7, rho = (idx >> 3) & 63;
+      const int i = rho & 15, nt = rho >> 4;
+      const int nl = 16 * (i >> 2) + 4 * nt + (i & 3);
+      wr[tap] = load8(wp + ((long long)tap * 64 + nl) * 64 + cv * 8);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int idx = threadIdx.x + tap * 512;
+      store8(Ws + tap * 4096 + c3v_off((idx >> 3) & 63, idx & 7), wr[tap]);
+    }
+  }
+  if (threadIdx.x < 64) Bs[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  for (int tp = t0; tp < t1; tp += 2) {
+    const int t = tp + grp;
+    const bool live = t < t1;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < TOT) store8(Xs + c3v_off(idx >> 3, idx & 7), ((fvalid >> it) & 1u) ? f[it] : frag_zero<T>());
+    }
+    lds_barrier();
+    if (tp == t0 + 2) M2T_CONV_STAMP(1);
+    const int tc = live ? t : t1 - 1;                       // (an idle group of the last pair recomputes a tile and discards it)
+    const int tx = tc % tw, q = tc / tw;
+    const int ty = q % th;
+    const long long pb = (long long)(q / th) * H * W;
+    const int x0 = tx * C3V_T, y0 = ty * C3V_T;
+    Frag8<T> r1[NRES >= 1 ? 4 : 1][2], r2[NRES >= 2 ? 4 : 1][2];
+    const long long off0 = ((long long)g * npix + pb + (long long)(y0 + 4 * wv) * W + x0 + lr) * 16;
+    const long long offs = (long long)W * 16;               // one tile row further
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if constexpr (NRES >= 1) { r1[mt][0] = load8(res1 + off0 + mt * offs); r1[mt][1] = load8(res1 + off0 + mt * offs + 8); }
+      if constexpr (NRES >= 2) { r2[mt][0] = load8(res2 + off0 + mt * offs); r2[mt][1] = load8(res2 + off0 + mt * offs + 8); }
+    }
+    if (t + 2 < t1) fetch(t + 2);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (one tap per trip: fully unrolled, hipcc hoists the 144 fragment reads and spills)
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        Frag8<T> xf[4], wf[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xf[mt] = load8(Xs + c3v_off((4 * wv + mt + ky) * (C3V_T + 2) + lr + kx, kc * 4 + g));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = load8(Ws + tap * 4096 + c3v_off(16 * nt + lr, kc * 4 + g));
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) mma16(acc[mt][nt], wf[nt], xf[mt]);
+      }
+    }
+    if (tp == t0 + 2) M2T_CONV_STAMP(2);
+    if (live) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float v[16];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
+        if (bias) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += Bs[16 * g + e];
+        }
+        if constexpr (NRES >= 1) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += r1[mt][e >> 3].get(e & 7);
+        }
+        if constexpr (NRES >= 2) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += r2[mt][e >> 3].get(e & 7);
+        }
+        store16f(y + off0 + mt * offs, v);
+      }
+    }
+    if (tp == t0 + 2) M2T_CONV_STAMP(3);
+    lds_barrier();            // both halo buffers are free for the next pair
+    if (tp == t0 + 2) M2T_CONV_STAMP(4);
   }
 }
 
@@ -636,6 +824,26 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
     nblk = (int)ceil_divll(ntiles, tpb);
     M2T_LAUNCH_TIMED(conv3x3_c64_persistent_kernel, dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
                        (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, B, H, W, tpb);
+    M2T_LAUNCH_CHECK();
+    return 0;
+  }
+  if (dt != M2T_F32 && variant == 2 && H % C3V_T == 0 && W % C3V_T == 0 && (long long)B * (H / C3V_T) * (W / C3V_T) >= 512) {
+    // v2: 16 x 16 tiles, 4 x 4 register blocking, swizzled LDS, weights resident; one 8-wave workgroup per CU
+    const int nt16 = B * (H / C3V_T) * (W / C3V_T);
+    int tpb = ceil_div(nt16, 256);
+    tpb += tpb & 1;                                          // whole pairs
+    const int nblk = ceil_div(nt16, tpb);
+    const int xcd_order = (nblk % 8 == 0 && nblk * tpb == nt16) ? 1 : 0;
+    const size_t sh = sizeof(bf16_t) * 64 * (9 * 64 + 2 * C3V_HP) + 64 * sizeof(float);
+    if (res2 && !res1) return m2t_set_error(-2, "conv3x3_c64: res2 without res1");
+#define GO_V2(N_)                                                                                                          \
+    {                                                                                                                      \
+      if (int rc__ = m2t_ensure_dynamic_lds((const void*)conv3x3_c64_v2_kernel<N_>, (int)sh)) return rc__;                 \
+      M2T_LAUNCH_TIMED(conv3x3_c64_v2_kernel<N_>, dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias, \
+                       (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, B, H, W, tpb, xcd_order);                     \
+    }
+    if (res2) GO_V2(2) else if (res1) GO_V2(1) else GO_V2(0)
+#undef GO_V2
     M2T_LAUNCH_CHECK();
     return 0;
   }

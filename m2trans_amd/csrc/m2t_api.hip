@@ -823,7 +823,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
   if (std::string(key) == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
   if (std::string(key) == "fused_tail_fwd") { p->use_fused_tail_fwd = (value != 0); p->have_acts = false; return 0; }
-  if (std::string(key) == "conv_variant") { if (value < 0 || value > 1) return m2t_set_error(M2T_ERR_ARG, "conv_variant: 0..1"); p->conv_variant = (int)value; return 0; }
+  if (std::string(key) == "conv_variant") { if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "conv_variant: 0..2"); p->conv_variant = (int)value; return 0; }
   if (std::string(key) == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
   return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");
 }

@@ -442,22 +442,24 @@ def test_conv3x3_register_resident_weights_kernel_is_bit_identical():
     """bf16 3x3 conv: the default kernel (weight slices register-resident, several tiles per workgroup, next halo tile in
     flight under the taps) keeps the tile / lane mapping and the accumulation order of the tap-pipelined kernel, so the
     whole step -- forward through eight of them, backward through eight data gradients -- must agree bit for bit.  Sizes:
-    128x128 batch 8 (1024 tiles: 2 per workgroup, XCD-aware order) and 96x160 batch 9 (1080 tiles: ragged last workgroup)."""
+    128x128 batch 8 (1024 tiles: 2 per workgroup, XCD-aware order) and 96x160 batch 9 (1080 tiles: ragged last workgroup;
+    540 16x16 tiles for variant 2: an odd number per workgroup, so the last pair has an idle group)."""
     from m2trans_amd import _lib
     for (B, H, W) in ((8, 128, 128), (9, 96, 160)):
         scale, nb = 4, 2
         x = O.closed_form_image(B, 3, H, W).cuda()
         hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
         outs = []
-        for variant in (0, 1):
+        for variant in (0, 1, 2):          # 2 = 16x16 tiles, swizzled LDS, resident weights (k_conv.hip conv3x3_c64_v2_kernel)
             model, _ = build_model(scale, nb, "bf16")
             plan = model._plan_for(x)
             _lib.check(_lib.load().m2t_set_option(plan.handle, b"conv_variant", variant), "m2t_set_option")
             sr = model(x)
             torch.nn.L1Loss()(sr, hr).backward()
             outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone()))
-        assert torch.equal(outs[0][0], outs[1][0])
-        assert torch.equal(outs[0][1], outs[1][1])
+        for o in outs[1:]:
+            assert torch.equal(outs[0][0], o[0])
+            assert torch.equal(outs[0][1], o[1])
 
 
 def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():
