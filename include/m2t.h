@@ -68,9 +68,13 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           Needs "fused_tail_bwd"; m2t_plan_query("stores_t2") tells whether ws:t2act / ws:t2der are written
  *   "fused_attn_fwd"    [1] bf16, C = 64 / 256 branches: qkv projection + window attention + IWT / residual epilogue in one
  *                           kernel per window (k_attn_fused.hip) instead of a GEMM launch + an attention launch
+ *   "fused_c16_fwd"     [1] bf16, C = 16 branch: InstanceNorm apply of chunk 0 + qkv projection + window attention + residual in
+ *                           one wave-per-window kernel (k_attn_c16.hip) instead of branch_prep + GEMM + attention launches
  *   "persistent_conv"   [0] bf16: conv3x3 with LDS-resident weights (bit-identical, measured slower)
  *   "conv_variant"      [1] bf16 conv3x3: 1 = the tap-pipelined kernel; 0 = weight slices register-resident, several tiles per
- *                           workgroup with the next halo tile in flight under the taps (>= 1024 tiles; bit-identical, measured a tie)
+ *                           workgroup with the next halo tile in flight under the taps (>= 1024 tiles; bit-identical, measured a tie);
+ *                           2 = 16x16-pixel tiles, XOR-swizzled 128-byte LDS rows, a wave owns 4 pixel rows x 64 channels
+ *                           (bit-identical; a tie stand-alone, 1.5 % slower on the step)
  *   "side_cus"          [0] CU mask size of the side stream (0 = all CUs; masking measured slower); set before the
  *                           first m2t_backward, and only effective when the caller's stream is not the NULL stream
  *   "debug_skip_side"   [0] timing experiments only: skips every parameter-gradient kernel (results are WRONG) */

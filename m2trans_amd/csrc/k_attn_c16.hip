@@ -348,6 +348,145 @@ __global__ void __launch_bounds__(256, 4) window_attn_fwd_c16_kernel(const bf16_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// fused forward of the whole C = 16 branch (models/M2Trans_network.py:135-139,281,307-332): InstanceNorm apply of
+// chunk 0, the 16 -> 48 qkv projection, the window attention and the residual, one wave per window.  The unfused
+// sequence is three launches (branch_prep<0>, the K = 16 GEMM, the kernel above) that move d1 and qkv through HBM
+// between them.  Here a wave loads the raw x rows of its 100 keys and 64 queries in MFMA operand layout (4 channels
+// per lane), normalises them in registers, and gets k, v (7 key tiles) and q (4 query tiles) with one
+// v_mfma_f32_16x16x16_bf16 each: the accumulator layout of out^T = W x^T (lane = pixel, 4 consecutive output channels)
+// IS the operand layout the attention part reads from HBM in the unfused kernel.  d1 (= the residual) and qkv of the
+// window's own pixels are still written: the backward pass reads them.  Out-of-image halo keys are the zero padding of
+// the normalised map (x^ = 0 -> k = v = 0, key = rel-pos alone).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                                           const float* __restrict__ rstd, const bf16_t* __restrict__ wqkv,
+                                                                           const float* __restrict__ rel_h, const float* __restrict__ rel_w,
+                                                                           bf16_t* __restrict__ d, bf16_t* __restrict__ qkv,
+                                                                           bf16_t* __restrict__ out, int ldo, int oc0, int h, int w, int nwin) {
+  __shared__ __attribute__((aligned(16))) bf16_t VsAll[4][112][16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wi = xcd_block_index() * 4 + wv;
+  if (wi >= nwin) return;
+  bf16_t(*Vs)[16] = VsAll[wv];
+  const int lr = lane & 15, g = lane >> 4;
+  const int nw = w / 8, nh = h / 8;
+  const int wx = wi % nw, wy = (wi / nw) % nh, b = wi / (nw * nh);
+  const long long img = (long long)b * h * w;
+  // ---- every global load of the window up front, branch-free (clamped address + select) ----
+  bf16x4 xq[4], xk[WA_KT];
+  bool inb[WA_KT];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int q = 16 * qt + lr;
+    xq[qt] = ld4(x + (img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7)) * C16 + 4 * g);
+  }
+  f32x4 rel[WA_KT];
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) {
+    const int key = min(16 * t + lr, WA_NK - 1);
+    const int kr = key / 10, kc = key - kr * 10;
+    const int y = 8 * wy + kr - 1, xx = 8 * wx + kc - 1;
+    inb[t] = (16 * t + lr < WA_NK) && y >= 0 && y < h && xx >= 0 && xx < w;
+    const int yc = min(max(y, 0), h - 1), xc = min(max(xx, 0), w - 1);
+    xk[t] = ld4(x + (img + (long long)yc * w + xc) * C16 + 4 * g);
+    const float* rp = (g < 2) ? (rel_h + kr * (C16 / 2) + 4 * g) : (rel_w + kc * (C16 / 2) + 4 * g - C16 / 2);
+    rel[t] = *reinterpret_cast<const f32x4*>(rp);
+  }
+  bf16x4 wA[3];                                  // rows 16 n + lr of [q | k | v], input channels 4g ..
+#pragma unroll
+  for (int n = 0; n < 3; ++n) wA[n] = ld4(wqkv + (16 * n + lr) * C16 + 4 * g);
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + b * 64 + 4 * g);
+  const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + b * 64 + 4 * g);
+  // ---- InstanceNorm apply (the arithmetic of branch_prep_kernel<T, 0>): x^ = bf16((x - mean) * rstd) ----
+  auto normalise = [&](bf16x4 v) {
+    return pack4(((float)v[0] - mu[0]) * rs[0], ((float)v[1] - mu[1]) * rs[1], ((float)v[2] - mu[2]) * rs[2], ((float)v[3] - mu[3]) * rs[3]);
+  };
+  bf16x4 qraw[4];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int q = 16 * qt + lr;
+    const long long qpix = img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
+    xq[qt] = normalise(xq[qt]);
+    st4(d + qpix * C16 + 4 * g, xq[qt]);
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mma4(a, wA[0], xq[qt]);
+    qraw[qt] = pack4(a[0], a[1], a[2], a[3]);
+    st4(qkv + qpix * (3 * C16) + 4 * g, qraw[qt]);
+  }
+  bf16x4 kA[WA_KT];
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) {
+    const bf16x4 xn = inb[t] ? normalise(xk[t]) : zero4();
+    f32x4 ak = (f32x4){0.f, 0.f, 0.f, 0.f}, av = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mma4(ak, wA[1], xn);
+    mma4(av, wA[2], xn);
+    const bf16x4 kraw = pack4(ak[0], ak[1], ak[2], ak[3]), vraw = pack4(av[0], av[1], av[2], av[3]);
+    const int key = 16 * t + lr;
+    const int kr = key / 10, kc = key - kr * 10;
+    if (key < WA_NK && kr >= 1 && kr <= 8 && kc >= 1 && kc <= 8) {          // the window's own pixels: saved for the backward pass
+      bf16_t* pk = qkv + (img + (long long)(8 * wy + kr - 1) * w + 8 * wx + kc - 1) * (3 * C16) + 4 * g;
+      st4(pk + C16, kraw);
+      st4(pk + 2 * C16, vraw);
+    }
+    kA[t] = (key < WA_NK) ? pack4((float)kraw[0] + rel[t][0], (float)kraw[1] + rel[t][1], (float)kraw[2] + rel[t][2], (float)kraw[3] + rel[t][3])
+                          : zero4();
+    st4(&Vs[16 * t + lr][4 * g], (key < WA_NK) ? vraw : zero4());
+  }
+  wave_sync();
+  bf16x4 vT[WA_KT];                               // rows = channel lr, contraction = keys 16 t + 4g ..
+#pragma unroll
+  for (int t = 0; t < WA_KT; ++t) vT[t] = tr4(&Vs[16 * t + 4 * g + (lr >> 2)][4 * (lr & 3)]);
+  const f32x4 L2E = (f32x4){1.4426950408889634f, 1.4426950408889634f, 1.4426950408889634f, 1.4426950408889634f};
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int q = 16 * qt + lr;
+    const long long qpix = img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
+    const bf16x4 qv = qraw[qt];
+    const bf16x4 qB = pack4(0.25f * (float)qv[0], 0.25f * (float)qv[1], 0.25f * (float)qv[2], 0.25f * (float)qv[3]);   // C^-1/2, exact
+    f32x4 s[WA_KT];
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      mma4(s[t], kA[t], qB);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * g + r >= 4) s[6][r] = -3.0e38f;                  // keys 100..111
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float nml = -mx * 1.4426950408889634f;
+    const f32x4 NM = (f32x4){nml, nml, nml, nml};
+    f32x4 sum4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const f32x4 e = s[t] * L2E + NM;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(e[r]);
+      sum4 += s[t];
+    }
+    float sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    const f32x4 INV = (f32x4){inv, inv, inv, inv};
+    f32x4 o = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const f32x4 pv = s[t] * INV;
+      mma4(o, vT[t], pack4(pv[0], pv[1], pv[2], pv[3]));
+    }
+    const bf16x4 rv = xq[qt];                                  // residual = the normalised input itself (:139)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] += (float)rv[r];
+    st4(out + qpix * ldo + oc0 + 4 * g, pack4(o[0], o[1], o[2], o[3]));
+  }
+}
+
 }  // namespace
 
 int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
@@ -366,6 +505,20 @@ int launch_window_attn_fwd_c16(const void* qkv, const float* rel_h, const float*
   const int nwin = B * (h / 8) * (w / 8);
   M2T_LAUNCH_TIMED(window_attn_fwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), 0, st, (const bf16_t*)qkv, rel_h, rel_w,
                      (bf16_t*)out, ldo, oc0, (const bf16_t*)res, ldr, h, w, nwin);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// x: the P64 plane of chunk 0 of the block input [B*h*w][16]; mean / rstd [B][64]; wqkv [48][16] bf16 (M2T_PACK_COPY);
+// d [B*h*w][16] and qkv [B*h*w][48] are written for the backward pass; out: chunk plane of the concat buffer.
+int launch_window_attn_fused_c16_fwd(const void* x, const float* mean, const float* rstd, const void* wqkv, const float* rel_h,
+                                     const float* rel_w, void* d, void* qkv, void* out, int ldo, int oc0, int B, int h, int w,
+                                     hipStream_t st) {
+  if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn_fused_c16_fwd: h, w must be multiples of 8");
+  const int nwin = B * (h / 8) * (w / 8);
+  M2TProfScope ps(M2T_PROF_ATTN_FUSED_16, st);
+  M2T_LAUNCH_TIMED(window_attn_fused_c16_fwd_kernel, dim3((nwin + 3) / 4), dim3(256), 0, st, (const bf16_t*)x, mean, rstd,
+                   (const bf16_t*)wqkv, rel_h, rel_w, (bf16_t*)d, (bf16_t*)qkv, (bf16_t*)out, ldo, oc0, h, w, nwin);
   M2T_LAUNCH_CHECK();
   return 0;
 }

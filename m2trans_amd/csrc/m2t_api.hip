@@ -129,6 +129,7 @@ struct m2t_plan {
                                        // 280 + 170 + 340 us), and a stored bf16 is cheaper to re-read than an erf is to re-evaluate
   int conv_variant = 1;                // bf16 conv3x3: 1 = tap-pipelined kernel, 0 = weight slices register-resident (conv3x3_c64_wreg_kernel:
                                        // bit-identical; same-box A/B 5.73 vs 5.69 ms per step, i.e. no gain: kept as an option)
+  bool use_fused_c16_fwd = true;       // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip)
   bool use_fused_attn_fwd = true;      // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip)
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
   // region; the descriptor table is identical every step, so it is uploaded once
@@ -407,6 +408,11 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
       const float* rw = params + p->poff.at(an + "rel_w");
       {
         void* xc_i = (char*)xc + (size_t)i * BP * 16 * p->esz;       // chunk i of the P64 concat buffer: a dense plane
+        if (dt != M2T_F32 && p->use_fused_c16_fwd && i == 0) {
+          // x1 = attn1(norm(x)[chunk 0]) + norm(x)[chunk 0] (:135-139): one launch, d1 and qkv1 written for the backward
+          CK(launch_window_attn_fused_c16_fwd(X, mean, rstd, packed_ptr(p, workspace, k + "w1"), rh, rw, d, qkv, xc_i, 16, 0, B, h, w, st));
+          continue;
+        }
         CK(launch_branch_prep(dt, L, X, mean, rstd, xc, i, WSP("xin"), d, B, H, W, st));
         if (dt != M2T_F32 && p->use_fused_attn_fwd && C >= 64) {
           // qkv projection + window attention + IWT^L / residual in one kernel; qkv is still written (the backward reads it)
@@ -821,6 +827,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "gated_side") { p->use_gated_side = (value != 0); return 0; }
   if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
+  if (std::string(key) == "fused_c16_fwd") { p->use_fused_c16_fwd = (value != 0); return 0; }
   if (std::string(key) == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
   if (std::string(key) == "fused_tail_fwd") { p->use_fused_tail_fwd = (value != 0); p->have_acts = false; return 0; }
   if (std::string(key) == "conv_variant") { if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "conv_variant: 0..2"); p->conv_variant = (int)value; return 0; }

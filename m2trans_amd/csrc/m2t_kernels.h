@@ -32,6 +32,7 @@ enum m2t_prof_cat {
   M2T_PROF_TAIL_GEMM, M2T_PROF_TAIL_WGRAD, M2T_PROF_FINAL_FWD, M2T_PROF_FINAL_DGRAD, M2T_PROF_FINAL_WGRAD,
   M2T_PROF_ATTN_FUSED_64, M2T_PROF_ATTN_FUSED_256,      // fused qkv projection + window attention forward (k_attn_fused.hip)
   M2T_PROF_TAIL_FWD_FUSED,                              // tail.3 expansion + PixelShuffle + GELU + tail conv (k_tail_fwd.hip)
+  M2T_PROF_ATTN_FUSED_16,                               // InstanceNorm apply + qkv projection + window attention, C = 16 (k_attn_c16.hip)
   M2T_PROF_NCAT
 };
 void m2t_prof_begin(int cat, hipStream_t st);
@@ -40,7 +41,7 @@ void m2t_prof_end(int cat, hipStream_t st);
 // (hipExtLaunchKernelGGL start / stop events = the dispatch's own begin / end timestamps, the quantity rocprofv3
 // reports) instead of bracketing it with marker packets, which add the ~5 us launch gap to every sample.
 #define M2T_PROF_DISPATCH_CATS ((1ull << M2T_PROF_GEMM_QKV) - 1ull | (1ull << M2T_PROF_FINAL_FWD) | (1ull << M2T_PROF_FINAL_DGRAD) | (1ull << M2T_PROF_FINAL_WGRAD) | \
-                                (1ull << M2T_PROF_ATTN_FUSED_64) | (1ull << M2T_PROF_ATTN_FUSED_256) | (1ull << M2T_PROF_TAIL_FWD_FUSED))
+                                (1ull << M2T_PROF_ATTN_FUSED_64) | (1ull << M2T_PROF_ATTN_FUSED_256) | (1ull << M2T_PROF_TAIL_FWD_FUSED) | (1ull << M2T_PROF_ATTN_FUSED_16))
 bool m2t_prof_take(hipEvent_t* a, hipEvent_t* b);
 #define M2T_LAUNCH_TIMED(kernel, grid, block, sh, st, ...)                                                       \
   do {                                                                                                           \
@@ -176,6 +177,11 @@ int launch_window_attn_fwd_resident(const void* qkv, const float* rel_h, const f
 // the resident kernel alone (bf16); M2T_UNSUPPORTED when (C, dwt_levels) has no instantiation
 int launch_window_attn_bwd_resident(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
                                     void* gqkv, void* win, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st);
+// k_attn_c16.hip: the whole C = 16 branch forward (InstanceNorm apply of chunk 0 + qkv projection + attention + residual), bf16.
+// x = chunk-0 plane of the block input; wqkv [48][16] (M2T_PACK_COPY); d [B*h*w][16] and qkv [B*h*w][48] are WRITTEN
+int launch_window_attn_fused_c16_fwd(const void* x, const float* mean, const float* rstd, const void* wqkv, const float* rel_h,
+                                     const float* rel_w, void* d, void* qkv, void* out, int ldo, int oc0, int B, int h, int w,
+                                     hipStream_t st);
 // k_attn_fused.hip: qkv projection + window attention + IWT / residual epilogue in one kernel (bf16, C = 64 / 256).
 // x [B][h][w][C]; wfrag = the [3C][C] qkv weight in M2T_PACK_FRAG16 order; qkv [B][h][w][3C] is WRITTEN (saved for the backward)
 int launch_window_attn_fused_fwd(const void* x, const void* wfrag, const float* rel_h, const float* rel_w, void* qkv, void* out,

@@ -25,7 +25,7 @@ from . import _lib
 CATS = ["attn_fwd_c16", "attn_fwd_c64", "attn_fwd_c256", "attn_bwd_c16", "attn_bwd_c64", "attn_bwd_c256",
         "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "gemm_qkv", "gemm_qkv_dgrad", "wgrad_qkv",
         "tail_gemm", "tail_wgrad", "final_conv_fwd", "final_conv_dgrad", "final_conv_wgrad",
-        "attn_fused_c64", "attn_fused_c256", "tail_fwd_fused"]
+        "attn_fused_c64", "attn_fused_c256", "tail_fwd_fused", "attn_fused_c16"]
 KERNEL_OF = {
     "attn_fwd_c16": "window_attn_fwd_kernel<C=16>", "attn_fwd_c64": "window_attn_fwd_kernel<C=64>",
     "attn_fwd_c256": "window_attn_fwd_kernel<C=256>", "attn_bwd_c16": "window_attn_bwd_kernel<C=16>",
@@ -38,6 +38,7 @@ KERNEL_OF = {
     "final_conv_wgrad": "final_conv_wgrad_kernel",
     "attn_fused_c64": "window_attn_fused_fwd_kernel<C=64,L=1> (qkv projection + window attention + IWT/residual)",
     "attn_fused_c256": "window_attn_fused_fwd_kernel<C=256,L=2> (qkv projection + window attention + IWT^2/residual)",
+    "attn_fused_c16": "window_attn_fused_c16_fwd_kernel (InstanceNorm apply + qkv projection + window attention + residual, wave per window)",
     "tail_fwd_fused": "tail_fwd_fused_kernel (tail.3 1x1 expansion + PixelShuffle + GELU + tail conv)",
 }
 KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these categories
@@ -71,10 +72,12 @@ def read_all():
     return out
 
 
-def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8, fused_attn_fwd: bool | None = None):
+def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8, fused_attn_fwd: bool | None = None,
+                     fused_tail_fwd: bool = False):
     """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr.
     fused_attn_fwd (default: bf16 mode): the C = 64 / 256 branches run qkv projection + attention as one kernel, so
-    the forward `gemm_qkv` / `attn_fwd_c64|c256` categories see only what is left (the C = 16 branch)."""
+    the forward `gemm_qkv` / `attn_fwd_*` categories are then empty (the C = 16 branch runs InstanceNorm apply +
+    projection + attention as `attn_fused_c16`).  fused_tail_fwd: option "fused_tail_fwd" of the plan (default off)."""
     if fused_attn_fwd is None:
         fused_attn_fwd = dtype == "bf16"
     es = 2 if dtype == "bf16" else 4
@@ -92,7 +95,8 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         M = B * P // (4 ** L)
         win = M // 64
         add(f"attn_bwd_c{C_}", nb * win * 64000.0 * C_, nb * M * 7 * C_ * es, nb)
-        if C_ >= 64 and fused_attn_fwd:
+        if fused_attn_fwd:
+            # reads x (+ the residual rows for C >= 64; for C = 16 the residual IS x), writes qkv + out (+ d1 for C = 16)
             add(f"attn_fused_c{C_}", nb * (win * 25600.0 * C_ + 2.0 * M * C_ * 3 * C_), nb * M * 6 * C_ * es, nb)
         else:
             add(f"attn_fwd_c{C_}", nb * win * 25600.0 * C_, nb * M * (4 * C_ + (C_ if C_ == 16 else 0)) * es, nb)
@@ -116,7 +120,7 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         add("tail_wgrad", 2.0 * M * 64 * 64 * r2, M * (64 + 64 * r2) * es, 1)
         HR = r2 * B * P
     fin = 2.0 * HR * 64 * 27
-    if scale == 4 and dtype == "bf16":
+    if scale == 4 and dtype == "bf16" and fused_tail_fwd:
         # fused forward tail (k_tail_fwd.hip): reads gelu(t1) (HR/4 pixels x 64), writes the fp32 output; tail.3 expansion + tail conv
         w["tail_fwd_fused"] = (fin + 2.0 * (HR // 4) * 64 * 256, (HR // 4) * 64 * es + HR * 12, 1)
         f0, b0, n0 = w["tail_gemm"]

@@ -438,6 +438,38 @@ def test_fused_qkv_attention_forward_matches_the_two_kernel_path():
     assert rms_rel(a["sr"], b["sr"]) < 5e-2
 
 
+def test_fused_c16_branch_forward_matches_the_three_kernel_path():
+    """bf16: InstanceNorm apply + qkv projection + window attention + residual of the C = 16 branch in one
+    wave-per-window kernel (k_attn_c16.hip, option fused_c16_fwd, default) against branch_prep + GEMM + attention.
+    d1 (the normalised chunk) must be identical; q|k|v come from a 16-deep MFMA instead of a zero-padded 32-deep one
+    (same 16 products, the hardware's summation may round differently: <= 1 bf16 ulp on rare elements), the block's
+    tensors stay within bf16 noise.  Reflect-padded input, border / edge / interior windows."""
+    from m2trans_amd import _lib
+    from tests.gpu_util import ws_nchw
+    scale, nb, B, H0, W0 = 4, 2, 2, 60, 90
+    x = O.closed_form_image(B, 3, H0, W0).cuda()
+    outs = []
+    for fused in (1, 0):
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(x)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_c16_fwd", fused), "m2t_set_option")
+        with torch.no_grad():
+            sr = model(x)
+        torch.cuda.synchronize()
+        H, W = plan.query("padded_h"), plan.query("padded_w")
+        t = {"b0.d1": ws_nchw(plan, "b0.d1", B, H, W, 16), "b0.qkv1": ws_nchw(plan, "b0.qkv1", B, H, W, 48),
+             "b1.d1": ws_nchw(plan, "b1.d1", B, H, W, 16),
+             "b0.xc": ws_nchw(plan, "b0.xc", B, H, W, 64), "X1": ws_nchw(plan, "X1", B, H, W, 64), "sr": sr.cpu()}
+        outs.append(t)
+    a, b = outs
+    assert torch.equal(a["b0.d1"], b["b0.d1"])
+    d = (a["b0.qkv1"].float() - b["b0.qkv1"].float()).abs()
+    assert float((d > 0).float().mean()) < 2e-2 and rel(a["b0.qkv1"], b["b0.qkv1"]) < 8e-3, (float((d > 0).float().mean()), rel(a["b0.qkv1"], b["b0.qkv1"]))
+    for k in ("b0.xc", "X1", "b1.d1"):
+        assert rms_rel(a[k], b[k]) < 2e-3, (k, rms_rel(a[k], b[k]), rel(a[k], b[k]))
+    assert rms_rel(a["sr"], b["sr"]) < 5e-2
+
+
 def test_conv3x3_register_resident_weights_kernel_is_bit_identical():
     """bf16 3x3 conv: the default kernel (weight slices register-resident, several tiles per workgroup, next halo tile in
     flight under the taps) keeps the tile / lane mapping and the accumulation order of the tap-pipelined kernel, so the
