@@ -68,6 +68,9 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           Needs "fused_tail_bwd"; m2t_plan_query("stores_t2") tells whether ws:t2act / ws:t2der are written
  *   "fused_attn_fwd"    [1] bf16, C = 64 / 256 branches: qkv projection + window attention + IWT / residual epilogue in one
  *                           kernel per window (k_attn_fused.hip) instead of a GEMM launch + an attention launch
+ *   "norm_single_stage" [0] InstanceNorm reductions by ONE 512-thread workgroup per (image, 16-channel chunk plane), no partials and
+ *                           no fold launch: bit 0 = forward statistics, bit 1 = backward sums.  Measured slower at batch 16
+ *                           (+15 / +21 us per launch: 64 workgroups cannot stream the map as fast as 512)
  *   "fused_c16_fwd"     [1] bf16, C = 16 branch: InstanceNorm apply of chunk 0 + qkv projection + window attention + residual in
  *                           one wave-per-window kernel (k_attn_c16.hip) instead of branch_prep + GEMM + attention launches
  *   "persistent_conv"   [0] bf16: conv3x3 with LDS-resident weights (bit-identical, measured slower)

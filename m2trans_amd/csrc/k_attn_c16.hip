@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256, 4) window_attn_fwd_c16_kernel(const bf16_
 // window's own pixels are still written: the backward pass reads them.  Out-of-image halo keys are the zero padding of
 // the normalised map (x^ = 0 -> k = v = 0, key = rel-pos alone).
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
+__global__ void __launch_bounds__(256, 3) window_attn_fused_c16_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                                            const float* __restrict__ rstd, const bf16_t* __restrict__ wqkv,
                                                                            const float* __restrict__ rel_h, const float* __restrict__ rel_w,
                                                                            bf16_t* __restrict__ d, bf16_t* __restrict__ qkv,

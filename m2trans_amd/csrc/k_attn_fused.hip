@@ -476,9 +476,7 @@ int launch_window_attn_fused_fwd(const void* x_, const void* wfrag_, const float
   int rc = M2T_UNSUPPORTED;
   M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_FUSED_64 : M2T_PROF_ATTN_FUSED_256, st);
   if (C == 256 && post_levels == 2) rc = go_fused<256, 2, 8>(x, wfrag, rel_h, rel_w, qkv, out, ldo, oc0, res, ldr, nwin, h, w, st);
-  else if (C == 256 && post_levels == 0) rc = go_fused<256, 0, 8>(x, wfrag, rel_h, rel_w, qkv, out, ldo, oc0, res, ldr, nwin, h, w, st);
   else if (C == 64 && post_levels == 1) rc = go_fused<64, 1, 4>(x, wfrag, rel_h, rel_w, qkv, out, ldo, oc0, res, ldr, nwin, h, w, st);
-  else if (C == 64 && post_levels == 0) rc = go_fused<64, 0, 4>(x, wfrag, rel_h, rel_w, qkv, out, ldo, oc0, res, ldr, nwin, h, w, st);
   if (rc != 0) return rc;
   M2T_LAUNCH_CHECK();
   return 0;

@@ -129,6 +129,7 @@ struct m2t_plan {
                                        // 280 + 170 + 340 us), and a stored bf16 is cheaper to re-read than an erf is to re-evaluate
   int conv_variant = 1;                // bf16 conv3x3: 1 = tap-pipelined kernel, 0 = weight slices register-resident (conv3x3_c64_wreg_kernel:
                                        // bit-identical; same-box A/B 5.73 vs 5.69 ms per step, i.e. no gain: kept as an option)
+  int norm_single_stage = 0;           // InstanceNorm reductions: bit 0 / bit 1 = forward statistics / backward sums by one workgroup per (image, chunk)
   bool use_fused_c16_fwd = true;       // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip)
   bool use_fused_attn_fwd = true;      // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip)
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
@@ -396,7 +397,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     float* mean = (float*)WSP(k + "mean");
     float* rstd = (float*)WSP(k + "rstd");
     void* xc = WSP(k + "xc");
-    CK(launch_instnorm_stats(dt, X, mean, rstd, (float*)WSP("norm_part"), B, (int)p->P, st));
+    CK(launch_instnorm_stats(dt, X, mean, rstd, (float*)WSP("norm_part"), B, (int)p->P, st, p->norm_single_stage));
     for (int i = 0; i < 4; ++i) {
       const int C = BR_C[i], L = BR_L[i];
       const int h = H >> L, w = W >> L;
@@ -764,7 +765,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     void* gx = gnext[b & 1];
     // gx's buffer was the gy of block b+1: its conv-wgrad / colsum on the side stream must be done
     main_wait(conv_done_prev);
-    CK(launch_instnorm_bwd(dt, gn, X, mean, rstd, gy, gx, (float*)WSP("norm_part"), (float*)WSP("norm_s"), B, (int)p->P, st));
+    CK(launch_instnorm_bwd(dt, gn, X, mean, rstd, gy, gx, (float*)WSP("norm_part"), (float*)WSP("norm_s"), B, (int)p->P, st, p->norm_single_stage));
     conv_done_prev = conv_done;
     gy = gx;
     if ((b & 1) == 0) { CK(flush()); mark_bucket(); }
@@ -827,6 +828,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "gated_side") { p->use_gated_side = (value != 0); return 0; }
   if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
+  if (std::string(key) == "norm_single_stage") { p->norm_single_stage = (int)value; return 0; }
   if (std::string(key) == "fused_c16_fwd") { p->use_fused_c16_fwd = (value != 0); return 0; }
   if (std::string(key) == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
   if (std::string(key) == "fused_tail_fwd") { p->use_fused_tail_fwd = (value != 0); p->have_acts = false; return 0; }

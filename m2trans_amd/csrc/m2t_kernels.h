@@ -59,14 +59,15 @@ struct M2TProfScope {
 int launch_dwt(int dt, int L, const void* src, int lds_, int c0, void* dst, int ldd, int d0, int B, int H, int W,
                int C, bool inverse, hipStream_t st);
 int launch_pixel_shuffle_nchw(const float* in, float* out, int B, int C, int H, int W, int r, int inverse, hipStream_t st);
-int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float* part, int B, int P, hipStream_t st);
+// single_stage: -1 / 0 two-stage; bit 0 = statistics, bit 1 = backward sums by one workgroup per (image, chunk plane)
+int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float* part, int B, int P, hipStream_t st, int single_stage = -1);
 int launch_branch_prep(int dt, int L, const void* x, const float* mean, const float* rstd, const void* xc, int k,
                        void* xin, void* d, int B, int H, int W, hipStream_t st);
 int launch_branch_post(int dt, int L, const void* a, const void* xin, void* xc, int k, int B, int H, int W, hipStream_t st);
 int launch_branch_post_bwd(int dt, int L, const void* gxc, int k, void* ga, int B, int H, int W, hipStream_t st);
 int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, int k, int B, int H, int W, hipStream_t st);
 int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean, const float* rstd, const void* gres,
-                        void* gx, float* part, float* s, int B, int P, hipStream_t st);
+                        void* gx, float* part, float* s, int B, int P, hipStream_t st, int single_stage = -1);
 int launch_add(int dt, const void* a, const void* b, void* o, long long n, hipStream_t st);
 int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* part, int max_part_blocks, float* out,
                   int accumulate, hipStream_t st, int unshuf = 0, int gH = 0, int gW = 0, int gr = 1, int gC = 64,

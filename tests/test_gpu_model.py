@@ -470,6 +470,31 @@ def test_fused_c16_branch_forward_matches_the_three_kernel_path():
     assert rms_rel(a["sr"], b["sr"]) < 5e-2
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_single_stage_instance_norm_reductions_match_the_two_stage_path(dtype):
+    """Option norm_single_stage: one workgroup per (image, chunk plane) computes mean / rstd (forward) and the two
+    backward sums directly, instead of partials + a fold kernel (the default from batch 16 on).  Same two-pass batches,
+    another merge tree: statistics agree to fp32 rounding (1e-6 relative), and so do the step's outputs."""
+    from m2trans_amd import _lib
+    from tests.test_gpu_baseline_configs import fwd_bwd
+    scale, nb, B, H0, W0 = 4, 2, 2, 60, 90
+    x = O.closed_form_image(B, 3, H0, W0).cuda()
+    hr = O.closed_form_image(B, 3, H0 * scale, W0 * scale, phase=0.7).cuda()
+    outs = []
+    for single in (3, 0):
+        model, _ = build_model(scale, nb, dtype)
+        plan = model._plan_for(x)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"norm_single_stage", single), "m2t_set_option")
+        sr, _, grads = fwd_bwd(model, x, hr, hr.numel())
+        t = {"mean0": plan.ws_tensor("b0.mean", dtype=torch.float32).cpu().clone(),
+             "rstd1": plan.ws_tensor("b0.rstd", dtype=torch.float32).cpu().clone(), "sr": sr.cpu(), "grad": grads.cpu()}
+        outs.append(t)
+    a, b = outs
+    assert rel(a["mean0"], b["mean0"]) < 1e-5 and rel(a["rstd1"], b["rstd1"]) < 1e-5, (rel(a["mean0"], b["mean0"]), rel(a["rstd1"], b["rstd1"]))
+    tol = 1e-4 if dtype == "fp32" else 3e-2          # bf16: a 1e-7 change of a statistic flips roundings downstream
+    assert rms_rel(a["sr"], b["sr"]) < tol and rms_rel(a["grad"], b["grad"]) < tol, (rms_rel(a["sr"], b["sr"]), rms_rel(a["grad"], b["grad"]))
+
+
 def test_conv3x3_register_resident_weights_kernel_is_bit_identical():
     """bf16 3x3 conv: the default kernel (weight slices register-resident, several tiles per workgroup, next halo tile in
     flight under the taps) keeps the tile / lane mapping and the accumulation order of the tap-pipelined kernel, so the
