@@ -553,8 +553,9 @@ __global__ void __launch_bounds__(256) window_attn_bwd_kernel(const T* __restric
 // (<= 3) neighbouring windows whose 10x10 neighbourhood covers it; interior pixels are final as written.
 template <typename T>
 __global__ void __launch_bounds__(256) halo_gather_kernel(const T* __restrict__ win, T* __restrict__ gqkv, int B, int h,
-                                                          int w, int C) {
-  const int nv = 2 * C / 8;
+                                                          int w, int rw, int ld, int coff) {
+  // rw = elements per ring row (2C for dK|dV, C for the fused data gradient); destination rows [pixel][ld], columns coff..
+  const int nv = rw / 8;
   const int nh = h / 8, nw = w / 8;
   const int total = B * nh * nw * 28 * nv;       // 28 border pixels per window; < 2^31 (checked by the launcher):
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {   // 32-bit index math --
@@ -579,7 +580,7 @@ __global__ void __launch_bounds__(256) halo_gather_kernel(const T* __restrict__ 
     if (px == 0 && wx0 > 0) { wxs[1] = wx0 - 1; kcs[1] = 9; nx = 2; }
     else if (px == 7 && wx0 < nw - 1) { wxs[1] = wx0 + 1; kcs[1] = 0; nx = 2; }
     if (ny * nx == 1) continue;                                   // image corner / edge with no neighbour
-    T* dst = gqkv + (((long long)b * h + y) * w + x) * (3 * C) + C + cv * 8;
+    T* dst = gqkv + (((long long)b * h + y) * w + x) * ld + coff + cv * 8;
     float acc[8];
     load8f(dst, acc);
     for (int a = 0; a < ny; ++a)
@@ -587,7 +588,7 @@ __global__ void __launch_bounds__(256) halo_gather_kernel(const T* __restrict__ 
         if (a == 0 && c == 0) continue;                           // the own window wrote straight to gqkv
         const long long wi = ((long long)b * nh + wys[a]) * nw + wxs[c];
         float v[8];
-        load8f(win + (wi * WA_RING + ring_index(krs[a], kcs[c])) * (2 * C) + cv * 8, v);
+        load8f(win + (wi * WA_RING + ring_index(krs[a], kcs[c])) * rw + cv * 8, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] += v[e];
       }
@@ -660,7 +661,7 @@ static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const floa
     res_rc = launch_window_attn_bwd_c16(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, B, h, w, st);
     if (res_rc != 0) return res_rc;
   } else if (resident && sizeof(T) == 2) {
-    res_rc = launch_window_attn_bwd_resident(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, B, h, w, C, dwt_levels, st);
+    res_rc = launch_window_attn_bwd_resident(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, B, h, w, C, dwt_levels, st, nullptr, nullptr, nullptr);
     if (res_rc != 0 && res_rc != M2T_UNSUPPORTED) return res_rc;
   }
   if (res_rc == 0) {}
@@ -674,9 +675,20 @@ static int launch_window_attn_bwd_t(const T* qkv, const float* rel_h, const floa
     const long long total = (long long)B * (h / 8) * (w / 8) * 28 * (2 * C / 8);
     if (total >= (1LL << 31)) return m2t_set_error(-2, "halo_gather: too many border vectors for 32-bit indexing");
     const int g = (int)std::min<long long>(ceil_divll(total, 256), 4096);
-    hipLaunchKernelGGL(halo_gather_kernel<T>, dim3(g), dim3(256), 0, st, win, gqkv, B, h, w, C);
+    hipLaunchKernelGGL(halo_gather_kernel<T>, dim3(g), dim3(256), 0, st, win, gqkv, B, h, w, 2 * C, 3 * C, C);
     M2T_LAUNCH_CHECK();
   }
+  return 0;
+}
+// the overlap-add alone: ring rows `win` [window][36][rw] are added to columns coff .. coff + rw of the border pixels' rows
+// of dst [pixel][ld]
+int launch_halo_gather(int dt, const void* win, void* dst, int B, int h, int w, int rw, int ld, int coff, hipStream_t st) {
+  const long long total = (long long)B * (h / 8) * (w / 8) * 28 * (rw / 8);
+  if (total >= (1LL << 31)) return m2t_set_error(-2, "halo_gather: too many border vectors for 32-bit indexing");
+  const int g = (int)std::min<long long>(ceil_divll(total, 256), 4096);
+  if (dt == M2T_F32) hipLaunchKernelGGL(halo_gather_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)win, (float*)dst, B, h, w, rw, ld, coff);
+  else hipLaunchKernelGGL(halo_gather_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)win, (bf16_t*)dst, B, h, w, rw, ld, coff);
+  M2T_LAUNCH_CHECK();
   return 0;
 }
 int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int* nsplit_out, hipStream_t st) {

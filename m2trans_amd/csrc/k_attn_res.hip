@@ -106,11 +106,20 @@ __device__ __forceinline__ void stage_go_all(bf16_t (*dst)[C + 8], const bf16_t*
   }
 }
 
-template <int C, int L, int NW>
+// DG: the data gradient of the qkv projection, g_d = g_q Wq + g_k Wk + g_v Wv (autograd of models/M2Trans_network.py:281,
+// 307), is taken in the same launch.  The product is linear in g_k | g_v, so the window multiplies ITS OWN contributions
+// to all 100 keys -- they sit complete in LDS at the end of phase 2 -- and the overlap-add over neighbouring windows
+// moves from dK|dV (2C wide, before a separate GEMM launch) to g_d (C wide): own pixels -> gd [pixel][C], ring keys ->
+// gdwin [window][36][C].  The weight arrives as pre-packed MFMA A-fragments of Wqkv^T (M2T_PACK_FRAG16_T) straight from
+// L2 through a register ring, the B operand is a plain row read of the dq / dK^ / dV rows (dq rows gathered in key order;
+// ring keys read a zero row).  gqkv / win are still written: the weight-gradient GEMM (side stream) reads them.
+template <int C, int L, int NW, bool DG>
 __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                                       const float* __restrict__ rel_w, const bf16_t* __restrict__ go,
                                                                       int ldg, int gc0, bf16_t* __restrict__ gqkv,
-                                                                      bf16_t* __restrict__ win, float* __restrict__ relw, int h, int w) {
+                                                                      bf16_t* __restrict__ win, float* __restrict__ relw, int h, int w,
+                                                                      const bf16_t* __restrict__ wdfrag, bf16_t* __restrict__ gd,
+                                                                      bf16_t* __restrict__ gdwin) {
   using T = bf16_t;
   using Cfg = ResCfg<C>;
   constexpr int LD = Cfg::LD, PLD = Cfg::PLD, DLD = Cfg::DLD, NTHR = NW * 64, VEC = C / 8, NT = C / 16, KH = NW / 4, TPW = NT / NW, NKC = C / 32;
@@ -392,6 +401,64 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
       float v[4] = {o[m][t][0], o[m][t][1], o[m][t][2], o[m][t][3]};
       store4(&QOUT[16 * t + lr][16 * (mt0 + m) + 4 * g], v);
     }
+  if constexpr (DG) {
+    constexpr int NK3 = 3 * C / 32, DEPTH = (NK3 < 8) ? NK3 : 8;   // 8 fragments per tile in flight: the L2 stream is latency-bound
+    // the dq row block has no row for ring keys: row 64 (the first row of the dead region behind it) is zeroed
+    if (tid < VEC) store8(&QOUT[64][tid * 8], frag_zero<T>());
+    Frag8<T> wb[TPW][DEPTH];
+    auto wfetch = [&](int ks, int slot) {
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) wb[m][slot] = load8(wdfrag + (((long long)(mt0 + m) * NK3 + ks) * 64 + lane) * 8);
+    };
+#pragma unroll
+    for (int ks = 0; ks < DEPTH; ++ks) wfetch(ks, ks);
+    __builtin_amdgcn_sched_barrier(0);
+    int krow[WA_KT], qrow[WA_KT];
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const int key = 16 * t + lr;
+      const int kr = key / 10, kc = key - kr * 10;
+      krow[t] = min(key, ZR);
+      qrow[t] = (key < WA_NK && kr >= 1 && kr <= 8 && kc >= 1 && kc <= 8) ? (kr - 1) * 8 + (kc - 1) : 64;
+    }
+    f32x4 ad[TPW][WA_KT];
+#pragma unroll
+    for (int m = 0; m < TPW; ++m)
+#pragma unroll
+      for (int t = 0; t < WA_KT; ++t) ad[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    lds_barrier();                        // dq, dK^, dV rows are complete in LDS
+#pragma unroll
+    for (int ks = 0; ks < NK3; ++ks) {
+      const int part = ks / NKC, kk = ks - part * NKC;
+      Frag8<T> a[TPW];
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) a[m] = wb[m][ks % DEPTH];
+      if (ks + DEPTH < NK3) wfetch(ks + DEPTH, ks % DEPTH);
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch HERE: hipcc otherwise sinks it to just before its use
+#pragma unroll
+      for (int t = 0; t < WA_KT; ++t) {
+        const T* rp = (part == 0) ? &QOUT[qrow[t]][0] : ((part == 1) ? &KOUT[krow[t]][0] : &VOUT[krow[t]][0]);
+        const Frag8<T> bfr = load8(rp + 32 * kk + 8 * g);
+#pragma unroll
+        for (int m = 0; m < TPW; ++m) mma16(ad[m][t], a[m], bfr);
+      }
+    }
+    // lane (key 16 t + lr, g) holds channels 16 (mt0 + m) + 4 g .. + 3 of g_d for that key
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const int key = 16 * t + lr;
+      long long pix;
+      if (key < WA_NK && gm.key_pixel(key, pix)) {
+        const int kr = key / 10, kc = key - kr * 10;
+        T* dst = (qrow[t] != 64) ? gd + pix * C : gdwin + ((long long)gm.wi * WA_RING + ring_index(kr, kc)) * C;
+#pragma unroll
+        for (int m = 0; m < TPW; ++m) {
+          float v[4] = {ad[m][t][0], ad[m][t][1], ad[m][t][2], ad[m][t][3]};
+          store4(dst + 16 * (mt0 + m) + 4 * g, v);
+        }
+      }
+    }
+  }
   for (int idx = tid; idx < WA_NK * VEC; idx += NTHR) {
     const int key = idx / VEC, cv = idx % VEC;
     store8(dkv_row(gqkv, win, (long long)gm.wi, gm.b, gm.wy, gm.wx, h, w, C, key) + C + cv * 8, load8(&VOUT[key][cv * 8]));
@@ -574,13 +641,14 @@ int go_fwd_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, bf16_t
   return 0;
 }
 
-template <int C, int L, int NW>
+template <int C, int L, int NW, bool DG = false>
 int go_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, const bf16_t* gout, int ldg, int gc0, bf16_t* gqkv,
-           bf16_t* win, float* relw, int nwin, int h, int w, hipStream_t st) {
+           bf16_t* win, float* relw, int nwin, int h, int w, hipStream_t st, const bf16_t* wdfrag = nullptr, bf16_t* gd = nullptr,
+           bf16_t* gdwin = nullptr) {
   const size_t sh = ResCfg<C>::total;
-  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_bwd_res_kernel<C, L, NW>, (int)sh)) return rc__;
-  M2T_LAUNCH_TIMED((window_attn_bwd_res_kernel<C, L, NW>), dim3(nwin), dim3(NW * 64), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0,
-                     gqkv, win, relw, h, w);
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_bwd_res_kernel<C, L, NW, DG>, (int)sh)) return rc__;
+  M2T_LAUNCH_TIMED((window_attn_bwd_res_kernel<C, L, NW, DG>), dim3(nwin), dim3(NW * 64), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0,
+                     gqkv, win, relw, h, w, wdfrag, gd, gdwin);
   return 0;
 }
 
@@ -588,13 +656,24 @@ int go_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, const bf16
 
 // bf16, C in {64, 256}, dwt_levels in {0, L(C)}; returns M2T_UNSUPPORTED otherwise (the caller then uses the chunked kernel)
 int launch_window_attn_bwd_resident(const void* qkv_, const float* rel_h, const float* rel_w, const void* gout_, int ldg, int gc0,
-                                    void* gqkv_, void* win_, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st) {
+                                    void* gqkv_, void* win_, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st,
+                                    const void* wdfrag, void* gd, void* gdwin) {
   const bf16_t* qkv = (const bf16_t*)qkv_;
   const bf16_t* gout = (const bf16_t*)gout_;
   bf16_t* gqkv = (bf16_t*)gqkv_;
   bf16_t* win = (bf16_t*)win_;
   const int nwin = B * (h / 8) * (w / 8);
   int rc = M2T_UNSUPPORTED;
+  if (wdfrag) {      // fused projection data gradient: the two shapes of the model
+    if (!gd || !gdwin) return m2t_set_error(-2, "window_attn_bwd_resident: fused data gradient needs gd and gdwin");
+    if (C == 256 && dwt_levels == 2)
+      rc = go_res<256, 2, 8, true>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st, (const bf16_t*)wdfrag, (bf16_t*)gd, (bf16_t*)gdwin);
+    else if (C == 64 && dwt_levels == 1)
+      rc = go_res<64, 1, 4, true>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st, (const bf16_t*)wdfrag, (bf16_t*)gd, (bf16_t*)gdwin);
+    if (rc != 0) return rc;
+    M2T_LAUNCH_CHECK();
+    return 0;
+  }
   if (C == 256 && dwt_levels == 2) rc = go_res<256, 2, 8>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st);
   else if (C == 256 && dwt_levels == 0) rc = go_res<256, 0, 8>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st);
   else if (C == 64 && dwt_levels == 1) rc = go_res<64, 1, 4>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st);

@@ -13,6 +13,7 @@
 //   clamp, crop, L1 ......... models/M2Trans_network.py:74-76, train.py:76,199
 //   Adam .................... train.py:81,210
 #include "m2t_kernels.h"
+#include "m2t_window.h"
 #include "m2t_gemm_load.h"
 #include "m2t_haar.h"
 
@@ -617,9 +618,13 @@ int launch_branch_post_bwd(int dt, int L, const void* gxc, int k, void* ga, int 
 // and for k = 0 (L = 0):   g_n[chunk 0] = g_d + g_xc[chunk 0]
 // g_n, g_xc: P64 ([4][B*H*W][16])
 // =======================================================================================
+// gdwin != nullptr: g_d holds only the own-window products of the fused projection data gradient (k_attn_res.hip); the
+// ring rows of the neighbouring windows ([window][36][16 N]) are added to the border pixels while the row is loaded
+// (same fp32 adds in the same order and one rounding to T, as halo_gather + a plain load would give)
 template <typename T, int L, int CH>
 __global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restrict__ gd, T* __restrict__ gxc,
-                                                              T* __restrict__ gn, int k, int B, int H, int W) {
+                                                              T* __restrict__ gn, int k, int B, int H, int W,
+                                                              const T* __restrict__ gdwin) {
   constexpr int S = Haar<L>::S, N = Haar<L>::N, G = 16 / CH;
   const int hb = H / S, wb = W / S;
   const long long npix = (long long)B * H * W;          // gxc, gn are P64
@@ -632,10 +637,24 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restric
     const int b = r / hb;
     float o[CH][N];
     const T* sp = gd + (((long long)b * hb + i) * wb + j) * (16 * N) + g * CH;
+    long long hoff[3];
+    const int nsrc = gdwin ? halo_sources(b, i, j, hb / 8, wb / 8, 16 * N, hoff) : 0;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       float q[CH];
       load_ch<CH>(sp + n * 16, q);
+      if (nsrc) {
+        for (int a = 0; a < nsrc; ++a) {
+          float rr[CH];
+          load_ch<CH>(gdwin + hoff[a] + n * 16 + g * CH, rr);
+#pragma unroll
+          for (int c = 0; c < CH; ++c) q[c] += rr[c];
+        }
+        if (sizeof(T) == 2) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) q[c] = to_f(from_f<T>(q[c]));
+        }
+      }
 #pragma unroll
       for (int c = 0; c < CH; ++c) o[c][n] = q[c];
     }
@@ -670,7 +689,8 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restric
 // read-modify-writes with consecutive lanes on consecutive 16 bytes.
 template <int TX>
 __global__ void __launch_bounds__(256) branch_prep_bwd_l2_tiled_kernel(const bf16_t* __restrict__ gd, bf16_t* __restrict__ gxc,
-                                                                       bf16_t* __restrict__ gn, int k, int B, int H, int W) {
+                                                                       bf16_t* __restrict__ gn, int k, int B, int H, int W,
+                                                                       const bf16_t* __restrict__ gdwin) {
   constexpr int NB = TX / 4, NV = 4 * TX * 2;
   __shared__ __attribute__((aligned(16))) bf16_t D[NB][256];
   __shared__ __attribute__((aligned(16))) float V[4][TX][16];
@@ -681,7 +701,24 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_l2_tiled_kernel(const bf1
   const long long npix = (long long)B * H * W;
   const int x0 = tc * TX;
   const bf16_t* sp = gd + (((long long)b * (H / 4) + i) * (W / 4) + x0 / 4) * 256;
-  for (int v = tid; v < NB * 32; v += 256) store8(&D[0][0] + v * 8, load8(sp + v * 8));
+  if (!gdwin) {
+    for (int v = tid; v < NB * 32; v += 256) store8(&D[0][0] + v * 8, load8(sp + v * 8));
+  } else {
+    for (int v = tid; v < NB * 32; v += 256) {
+      const int blk = v >> 5, cv = v & 31;
+      float q[8];
+      load8f(sp + v * 8, q);
+      long long hoff[3];
+      const int nsrc = halo_sources(b, i, x0 / 4 + blk, H / 32, W / 32, 256, hoff);
+      for (int a = 0; a < nsrc; ++a) {
+        float rr[8];
+        load8f(gdwin + hoff[a] + cv * 8, rr);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) q[c] += rr[c];
+      }
+      store8f(&D[0][0] + v * 8, q);
+    }
+  }
   __syncthreads();
   for (int it = tid; it < NB * 16; it += 256) {
     const int blk = it >> 4, ch = it & 15;
@@ -713,20 +750,20 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_l2_tiled_kernel(const bf1
 }
 
 int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, int k, int B, int H, int W,
-                           hipStream_t st) {
+                           hipStream_t st, const void* gdwin) {
   if ((long long)B * H * W * 4 >= (1LL << 31)) return m2t_set_error(-2, "branch_prep_bwd: B*H*W too large for 32-bit indexing");
   if (dt != M2T_F32 && L == 2 && k >= 1 && W % 32 == 0 && H % 4 == 0) {
     if (W % 64 == 0) hipLaunchKernelGGL(branch_prep_bwd_l2_tiled_kernel<64>, dim3(B * (H / 4) * (W / 64)), dim3(256), 0, st, (const bf16_t*)gd,
-                                        (bf16_t*)gxc, (bf16_t*)gn, k, B, H, W);
+                                        (bf16_t*)gxc, (bf16_t*)gn, k, B, H, W, (const bf16_t*)gdwin);
     else hipLaunchKernelGGL(branch_prep_bwd_l2_tiled_kernel<32>, dim3(B * (H / 4) * (W / 32)), dim3(256), 0, st, (const bf16_t*)gd, (bf16_t*)gxc,
-                            (bf16_t*)gn, k, B, H, W);
+                            (bf16_t*)gn, k, B, H, W, (const bf16_t*)gdwin);
     M2T_LAUNCH_CHECK();
     return 0;
   }
   const int S = 1 << L;
   const int CH = dt == M2T_F32 ? 4 : 8;
   const int g = grid_for((long long)B * (H / S) * (W / S) * (16 / CH));
-#define BP(T_, L_, CH_) hipLaunchKernelGGL((branch_prep_bwd_kernel<T_, L_, CH_>), dim3(g), dim3(256), 0, st, (const T_*)gd, (T_*)gxc, (T_*)gn, k, B, H, W)
+#define BP(T_, L_, CH_) hipLaunchKernelGGL((branch_prep_bwd_kernel<T_, L_, CH_>), dim3(g), dim3(256), 0, st, (const T_*)gd, (T_*)gxc, (T_*)gn, k, B, H, W, (const T_*)gdwin)
   if (dt == M2T_F32) { if (L == 0) BP(float, 0, 4); else if (L == 1) BP(float, 1, 4); else BP(float, 2, 4); }
   else { if (L == 0) BP(bf16_t, 0, 8); else if (L == 1) BP(bf16_t, 1, 8); else BP(bf16_t, 2, 8); }
 #undef BP
@@ -1308,6 +1345,12 @@ __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ mas
         const int nks = d.d1 >> 5;
         const int ks = f % nks, tile = f / nks;
         si = (long long)(16 * tile + (l & 15)) * d.d1 + 32 * ks + 8 * (l >> 4) + j;
+      } break;
+      case M2T_PACK_FRAG16_T: {         // src [K=d1][N=d0] -> fragments of the transpose [N/16][K/32][64][8]
+        const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
+        const int nks = d.d1 >> 5;
+        const int ks = f % nks, tile = f / nks;
+        si = (long long)(32 * ks + 8 * (l >> 4) + j) * d.d0 + 16 * tile + (l & 15);
       } break;
     }
     o[e] = from_f<T>(s[si]);

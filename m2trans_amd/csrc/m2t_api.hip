@@ -130,6 +130,8 @@ struct m2t_plan {
   int conv_variant = 1;                // bf16 conv3x3: 1 = tap-pipelined kernel, 0 = weight slices register-resident (conv3x3_c64_wreg_kernel:
                                        // bit-identical; same-box A/B 5.73 vs 5.69 ms per step, i.e. no gain: kept as an option)
   int norm_single_stage = 0;           // InstanceNorm reductions: bit 0 / bit 1 = forward statistics / backward sums by one workgroup per (image, chunk)
+  bool fused_dgrad_gather_in_prep = true;   // ring rows of the fused data gradient added by branch_prep_bwd on load (0: separate gather launch)
+  bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside the attention backward kernel (k_attn_res.hip)
   bool use_fused_c16_fwd = true;       // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip)
   bool use_fused_attn_fwd = true;      // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip)
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
@@ -243,6 +245,7 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
       p->add_pack(k, pre + "qkv_conv.weight", M2T_PACK_COPY, 3LL * C * C, 0, 0, 0);
       p->add_pack(k + "T", pre + "qkv_conv.weight", M2T_PACK_TRANSPOSE, 3LL * C * C, 3 * C, C, 0);
       if (C >= 64) p->add_pack(k + "F", pre + "qkv_conv.weight", M2T_PACK_FRAG16, 3LL * C * C, 3 * C, C, 0);   // k_attn_fused.hip
+      if (C >= 64) p->add_pack(k + "TF", pre + "qkv_conv.weight", M2T_PACK_FRAG16_T, 3LL * C * C, C, 3 * C, 0);  // Wqkv^T fragments: fused data gradient (k_attn_res.hip)
     }
     const std::string pre = "body." + std::to_string(b) + ".feed_forward.0.weight";
     p->add_pack("b" + std::to_string(b) + ".wf", pre, M2T_PACK_CONV3, 64 * 64 * 9, 64, 64, 0);
@@ -295,6 +298,7 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("gn", BP * 64, es);
   p->add_ws("ga", BP * 16, es);
   p->add_ws("gd", BP * 16, es);
+  p->add_ws("gdwin", BP * 9, es);      // ring rows of the fused projection data gradient: [windows][36][C], windows * C = BP / 4
   p->add_ws("head_cols", BP * 32, es);
   for (int i = 0; i < 4; ++i) {     // one set per branch: the side stream may lag the main chain by a whole block
     p->add_ws("gqkv" + std::to_string(i), BP * 48, es);
@@ -692,6 +696,9 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       defer(colp, p->poff.at(pre + "feed_forward.0.bias"), ns, 64, 0, 0, 0, 0);     // bias gradient rode along
       return 0;
     };
+    auto fused_dgrad = [&](int i) -> bool {    // projection data gradient inside the attention backward kernel (k_attn_res.hip)
+      return dt != M2T_F32 && p->use_fused_qkv_dgrad && p->use_resident_attn_bwd && BR_C[i] >= 64;
+    };
     auto side_branch = [&](int i) -> int {     // qkv weight gradient + rel-pos partial reduction of branch i
       if (skip) return 0;
       const int C = BR_C[i], L = BR_L[i];
@@ -699,6 +706,8 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       const long long M = (long long)B * h * w;
       const std::string an = pre + "attn" + std::to_string(i + 1) + ".";
       ARENA(slabs, (size_t)wgrad_slab_count(M, 3 * C, C) * 3 * C * C);
+      // fused data gradient: the main chain never reads gqkv, so the overlap-add of dK|dV happens here, off the critical path
+      if (fused_dgrad(i)) CK(launch_halo_gather(dt, win_buf[i], gqkv_buf[i], B, h, w, 2 * C, 3 * C, C, sd));
       m2t_wgrad_args wa{};
       wa.G = gqkv_buf[i]; wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = WSP(k + "d" + std::to_string(i + 1)); wa.ldx = C; wa.xmode = M2T_A_PLAIN;
       wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = h; wa.Wd = w; wa.r = 1; wa.C = C; wa.halo_win = win_buf[i];
@@ -735,7 +744,13 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       // (gathering inside the TILED GEMM / wgrad loaders, M2T_A_HALO, was measured slower: the gather is then
       //  repeated once per column-block.)
       const void* gxc_i = (const char*)gxc + (size_t)i * BP * 16 * p->esz;       // chunk i of the P64 gradient: a dense plane
-      CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, st, L, true, p->use_resident_attn_bwd));
+      if (fused_dgrad(i)) {
+        M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256, st);
+        CK(launch_window_attn_bwd_resident(qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, L, st,
+                                           packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "TF"), WSP("gd"), WSP("gdwin")));
+      } else {
+        CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, st, L, true, p->use_resident_attn_bwd));
+      }
       if (!gated) {
         fork();
         CK(side_branch(i));
@@ -754,7 +769,15 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         branch_done[i] = side_marker();
         if (p->side_conv_pos == 2 && i == 0) { CK(side_conv()); conv_done = side_marker(); }
       }
-      {
+      if (fused_dgrad(i)) {
+        // own-window products are in gd; add the ring rows of the (<= 3) neighbouring windows to the border pixels
+        if (p->fused_dgrad_gather_in_prep) {
+          CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st, WSP("gdwin")));
+        } else {
+          CK(launch_halo_gather(dt, WSP("gdwin"), WSP("gd"), B, h, w, C, C, 0, st));
+          CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st));
+        }
+      } else {
         m2t_gemm_args ga{};
         ga.A = gqkv; ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
         ga.Y = WSP("gd"); ga.ldy = C; ga.M = M; ga.N = C; ga.K = 3 * C; ga.H = h; ga.Wd = w; ga.r = 1; ga.C = C; ga.halo_win = win;
@@ -829,6 +852,8 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
   if (std::string(key) == "norm_single_stage") { p->norm_single_stage = (int)value; return 0; }
+  if (std::string(key) == "dgrad_gather_in_prep") { p->fused_dgrad_gather_in_prep = (value != 0); return 0; }
+  if (std::string(key) == "fused_qkv_dgrad") { p->use_fused_qkv_dgrad = (value != 0); return 0; }
   if (std::string(key) == "fused_c16_fwd") { p->use_fused_c16_fwd = (value != 0); return 0; }
   if (std::string(key) == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
   if (std::string(key) == "fused_tail_fwd") { p->use_fused_tail_fwd = (value != 0); p->have_acts = false; return 0; }

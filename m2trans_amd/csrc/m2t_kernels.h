@@ -11,8 +11,9 @@
 enum m2t_pack_kind {
   M2T_PACK_COPY = 0, M2T_PACK_TRANSPOSE = 1, M2T_PACK_CONV3 = 2, M2T_PACK_CONV3_T = 3,
   M2T_PACK_SHUF_ROWS = 4, M2T_PACK_SHUF_ROWS_T = 5,
-  M2T_PACK_FRAG16 = 6     // src [N = d0][K = d1] -> MFMA A-operand fragment order [N/16][K/32][64 lanes][8]: element j of lane l of
+  M2T_PACK_FRAG16 = 6,    // src [N = d0][K = d1] -> MFMA A-operand fragment order [N/16][K/32][64 lanes][8]: element j of lane l of
                           // fragment (tile, ks) is src[16 tile + (l & 15)][32 ks + 8 (l >> 4) + j]; one wave load = 1 KB contiguous
+  M2T_PACK_FRAG16_T = 7   // the same fragments of the TRANSPOSE: src is [K = d1][N = d0] (element = src[32 ks + 8 (l >> 4) + j][16 tile + (l & 15)])
 };
 struct m2t_red_desc {      // one deferred slab reduction: grads[dst_off + perm(e)] = sum_s arena[src_off + s*n + e]
   long long src_off, dst_off, n;
@@ -65,7 +66,9 @@ int launch_branch_prep(int dt, int L, const void* x, const float* mean, const fl
                        void* xin, void* d, int B, int H, int W, hipStream_t st);
 int launch_branch_post(int dt, int L, const void* a, const void* xin, void* xc, int k, int B, int H, int W, hipStream_t st);
 int launch_branch_post_bwd(int dt, int L, const void* gxc, int k, void* ga, int B, int H, int W, hipStream_t st);
-int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, int k, int B, int H, int W, hipStream_t st);
+// gdwin != nullptr: ring rows [window][36][16 * 4^L] of the fused projection data gradient, added to the border pixels on load
+int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, int k, int B, int H, int W, hipStream_t st,
+                           const void* gdwin = nullptr);
 int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean, const float* rstd, const void* gres,
                         void* gx, float* part, float* s, int B, int P, hipStream_t st, int single_stage = -1);
 int launch_add(int dt, const void* a, const void* b, void* o, long long n, hipStream_t st);
@@ -176,8 +179,13 @@ int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float*
 int launch_window_attn_fwd_resident(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0,
                                     const void* res, int ldr, int B, int h, int w, int C, int post_levels, hipStream_t st);
 // the resident kernel alone (bf16); M2T_UNSUPPORTED when (C, dwt_levels) has no instantiation
+// wdfrag != nullptr ((C, dwt_levels) = (256, 2) or (64, 1)): the data gradient of the qkv projection is taken in the same
+// launch -- wdfrag = Wqkv^T as MFMA fragments (M2T_PACK_FRAG16_T); own pixels' rows -> gd [pixel][C], the 36 ring keys'
+// rows -> gdwin [window][36][C] (added to the border pixels by launch_halo_gather(gdwin, gd, .., C, C, 0))
 int launch_window_attn_bwd_resident(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
-                                    void* gqkv, void* win, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st);
+                                    void* gqkv, void* win, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st,
+                                    const void* wdfrag, void* gd, void* gdwin);
+int launch_halo_gather(int dt, const void* win, void* dst, int B, int h, int w, int rw, int ld, int coff, hipStream_t st);
 // k_attn_c16.hip: the whole C = 16 branch forward (InstanceNorm apply of chunk 0 + qkv projection + attention + residual), bf16.
 // x = chunk-0 plane of the block input; wqkv [48][16] (M2T_PACK_COPY); d [B*h*w][16] and qkv [B*h*w][48] are WRITTEN
 int launch_window_attn_fused_c16_fwd(const void* x, const float* mean, const float* rstd, const void* wqkv, const float* rel_h,

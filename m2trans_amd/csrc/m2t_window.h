@@ -39,6 +39,27 @@ __device__ __forceinline__ T* dkv_row(T* gqkv, T* win, long long wi, int b, int 
   return win + (wi * WA_RING + ring_index(kr, kc)) * (2 * C);
 }
 
+// The (<= 3) neighbouring windows whose 10x10 neighbourhood covers pixel (y, x) of image b, as element offsets of their
+// ring rows in a [window][36][rw] scratch (same order as halo_gather_kernel adds them: row-neighbour column first).
+__device__ __forceinline__ int halo_sources(int b, int y, int x, int nh, int nw, int rw, long long (&off)[3]) {
+  const int wy0 = y >> 3, wx0 = x >> 3, py = y & 7, px = x & 7;
+  int wys[2], krs[2], ny = 1, wxs[2], kcs[2], nx = 1;
+  wys[0] = wy0; krs[0] = py + 1;
+  if (py == 0 && wy0 > 0) { wys[1] = wy0 - 1; krs[1] = 9; ny = 2; }
+  else if (py == 7 && wy0 < nh - 1) { wys[1] = wy0 + 1; krs[1] = 0; ny = 2; }
+  wxs[0] = wx0; kcs[0] = px + 1;
+  if (px == 0 && wx0 > 0) { wxs[1] = wx0 - 1; kcs[1] = 9; nx = 2; }
+  else if (px == 7 && wx0 < nw - 1) { wxs[1] = wx0 + 1; kcs[1] = 0; nx = 2; }
+  int n = 0;
+  for (int a = 0; a < ny; ++a)
+    for (int c = 0; c < nx; ++c) {
+      if (a == 0 && c == 0) continue;
+      const long long wi = ((long long)b * nh + wys[a]) * nw + wxs[c];
+      off[n++] = (wi * WA_RING + ring_index(krs[a], kcs[c])) * rw;
+    }
+  return n;
+}
+
 __device__ __forceinline__ WinGeom make_geom(int h, int w) {
   WinGeom g;
   g.h = h; g.w = w; g.nw = w / 8; g.nh = h / 8;
