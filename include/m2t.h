@@ -71,6 +71,14 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "norm_single_stage" [0] InstanceNorm reductions by ONE 512-thread workgroup per (image, 16-channel chunk plane), no partials and
  *                           no fold launch: bit 0 = forward statistics, bit 1 = backward sums.  Measured slower at batch 16
  *                           (+15 / +21 us per launch: 64 workgroups cannot stream the map as fast as 512)
+ *   "fused_qkv_dgrad"   [1] bf16, C = 64 / 256 branches: the data gradient of the qkv projection is taken inside the attention
+ *                           backward kernel (k_attn_res.hip): the window multiplies its own dq | dK | dV rows by Wqkv^T, the
+ *                           overlap-add over neighbouring windows moves to the C-wide product.  Removes the halo gather and
+ *                           the GEMM launch from the main chain (+2.3 % at batch 16, neutral at batch 32)
+ *   "fused_c16_dgrad"   [0] the same inside the wave-per-window C = 16 backward kernel (measured a tie / -0.3 %); needs
+ *                           "fused_qkv_dgrad"
+ *   "dgrad_gather_in_prep" [1] with "fused_qkv_dgrad": branch_prep_bwd adds the ring rows of the neighbouring windows while it
+ *                           loads the row (0: a separate gather launch; bit-identical)
  *   "fused_c16_fwd"     [1] bf16, C = 16 branch: InstanceNorm apply of chunk 0 + qkv projection + window attention + residual in
  *                           one wave-per-window kernel (k_attn_c16.hip) instead of branch_prep + GEMM + attention launches
  *   "persistent_conv"   [0] bf16: conv3x3 with LDS-resident weights (bit-identical, measured slower)

@@ -131,6 +131,7 @@ struct m2t_plan {
                                        // bit-identical; same-box A/B 5.73 vs 5.69 ms per step, i.e. no gain: kept as an option)
   int norm_single_stage = 0;           // InstanceNorm reductions: bit 0 / bit 1 = forward statistics / backward sums by one workgroup per (image, chunk)
   bool fused_dgrad_gather_in_prep = true;   // ring rows of the fused data gradient added by branch_prep_bwd on load (0: separate gather launch)
+  bool use_fused_c16_dgrad = false;    // ... and inside the wave-per-window C = 16 backward kernel (k_attn_c16.hip): a tie at batch 16, -0.3 % at batch 32
   bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside the attention backward kernel (k_attn_res.hip)
   bool use_fused_c16_fwd = true;       // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip)
   bool use_fused_attn_fwd = true;      // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip)
@@ -697,7 +698,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       return 0;
     };
     auto fused_dgrad = [&](int i) -> bool {    // projection data gradient inside the attention backward kernel (k_attn_res.hip)
-      return dt != M2T_F32 && p->use_fused_qkv_dgrad && p->use_resident_attn_bwd && BR_C[i] >= 64;
+      return dt != M2T_F32 && p->use_fused_qkv_dgrad && p->use_resident_attn_bwd && (BR_C[i] >= 64 || p->use_fused_c16_dgrad);
     };
     auto side_branch = [&](int i) -> int {     // qkv weight gradient + rel-pos partial reduction of branch i
       if (skip) return 0;
@@ -744,7 +745,11 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       // (gathering inside the TILED GEMM / wgrad loaders, M2T_A_HALO, was measured slower: the gather is then
       //  repeated once per column-block.)
       const void* gxc_i = (const char*)gxc + (size_t)i * BP * 16 * p->esz;       // chunk i of the P64 gradient: a dense plane
-      if (fused_dgrad(i)) {
+      if (fused_dgrad(i) && C == 16) {
+        M2TProfScope ps(M2T_PROF_ATTN_BWD_16, st);
+        CK(launch_window_attn_bwd_c16(qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, st, packed_ptr(p, workspace, k + "w1T"),
+                                      WSP("gd"), WSP("gdwin")));
+      } else if (fused_dgrad(i)) {
         M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256, st);
         CK(launch_window_attn_bwd_resident(qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, L, st,
                                            packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "TF"), WSP("gd"), WSP("gdwin")));
@@ -853,6 +858,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
   if (std::string(key) == "norm_single_stage") { p->norm_single_stage = (int)value; return 0; }
   if (std::string(key) == "dgrad_gather_in_prep") { p->fused_dgrad_gather_in_prep = (value != 0); return 0; }
+  if (std::string(key) == "fused_c16_dgrad") { p->use_fused_c16_dgrad = (value != 0); return 0; }
   if (std::string(key) == "fused_qkv_dgrad") { p->use_fused_qkv_dgrad = (value != 0); return 0; }
   if (std::string(key) == "fused_c16_fwd") { p->use_fused_c16_fwd = (value != 0); return 0; }
   if (std::string(key) == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }

@@ -174,8 +174,11 @@ int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const fl
 // C = 16, bf16, no fused DWT: one wave per window (k_attn_c16.hip)
 int launch_window_attn_fwd_c16(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0, const void* res,
                                int ldr, int B, int h, int w, hipStream_t st);
+// wT != nullptr: Wqkv^T [16][48] bf16 (M2T_PACK_TRANSPOSE); the projection data gradient is taken in the same launch:
+// own pixels -> gd [pixel][16], ring keys -> gdwin [window][36][16]
 int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
-                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st);
+                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st, const void* wT = nullptr,
+                               void* gd = nullptr, void* gdwin = nullptr);
 int launch_window_attn_fwd_resident(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0,
                                     const void* res, int ldr, int B, int h, int w, int C, int post_levels, hipStream_t st);
 // the resident kernel alone (bf16); M2T_UNSUPPORTED when (C, dwt_levels) has no instantiation

@@ -512,6 +512,7 @@ def test_fused_projection_data_gradient_matches_the_gemm_path():
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_qkv_dgrad", fused), "m2t_set_option")
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_c16_dgrad", 1), "m2t_set_option")     # default off: covered here
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"dgrad_gather_in_prep", in_prep), "m2t_set_option")
         sr, loss, grads = fwd_bwd(model, x, hr, hr.numel())
         outs.append((sr.cpu(), grads.cpu(), model.param_offsets()))
