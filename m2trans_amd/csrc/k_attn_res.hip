@@ -427,21 +427,31 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
 #pragma unroll
       for (int t = 0; t < WA_KT; ++t) ad[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     lds_barrier();                        // dq, dK^, dV rows are complete in LDS
+    // B operands (7 row reads per k-step, each feeding only TPW MFMAs) are read one k-step ahead, so the LDS round
+    // trip of step ks + 1 runs under the MFMAs of step ks
+    auto bfetch = [&](int ks, Frag8<T> (&bf)[WA_KT]) {
+      const int part = ks / NKC, kk = ks - part * NKC;
+#pragma unroll
+      for (int t = 0; t < WA_KT; ++t) {
+        const T* rp = (part == 0) ? &QOUT[qrow[t]][0] : ((part == 1) ? &KOUT[krow[t]][0] : &VOUT[krow[t]][0]);
+        bf[t] = load8(rp + 32 * kk + 8 * g);
+      }
+    };
+    Frag8<T> bq[2][WA_KT];
+    bfetch(0, bq[0]);
 #pragma unroll
     for (int ks = 0; ks < NK3; ++ks) {
-      const int part = ks / NKC, kk = ks - part * NKC;
       Frag8<T> a[TPW];
 #pragma unroll
       for (int m = 0; m < TPW; ++m) a[m] = wb[m][ks % DEPTH];
       if (ks + DEPTH < NK3) wfetch(ks + DEPTH, ks % DEPTH);
-      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch HERE: hipcc otherwise sinks it to just before its use
+      if (ks + 1 < NK3) bfetch(ks + 1, bq[(ks + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetches HERE: hipcc otherwise sinks them to just before their use
 #pragma unroll
-      for (int t = 0; t < WA_KT; ++t) {
-        const T* rp = (part == 0) ? &QOUT[qrow[t]][0] : ((part == 1) ? &KOUT[krow[t]][0] : &VOUT[krow[t]][0]);
-        const Frag8<T> bfr = load8(rp + 32 * kk + 8 * g);
+      for (int t = 0; t < WA_KT; ++t)
 #pragma unroll
-        for (int m = 0; m < TPW; ++m) mma16(ad[m][t], a[m], bfr);
-      }
+        for (int m = 0; m < TPW; ++m) mma16(ad[m][t], a[m], bq[ks & 1][t]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // lane (key 16 t + lr, g) holds channels 16 (mt0 + m) + 4 g .. + 3 of g_d for that key
 #pragma unroll
