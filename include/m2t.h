@@ -55,8 +55,8 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  * tests/test_gpu_model.py).  Defaults in brackets.
  *   "side_stream"       [1] parameter-gradient kernels of m2t_backward on a plan-owned second stream
  *   "gated_side"        [1] release a block's side-stream work only after its LDS-hungry attention launches
- *   "gate_branch"       [2] branch index (3..0) after whose attention launch the gate opens (2 = behind the two
- *                           C = 256 launches: measured 1.2 % faster than 0 = behind all four, 2.7 % faster than 3)
+ *   "gate_branch"       [1] branch index (3..0) after whose attention launch the gate opens (1 = behind the two C = 256 launches
+ *                           and the C = 64 one: 2 % faster than 2, 3 % faster than 0 = behind all four or ungated)
  *   "side_conv_pos"     [1] where the block's conv weight gradient enters the side stream: 0 first at the gate, 1 after the
  *                           gated qkv weight gradients (1.9 % faster than 0), 2 after the block's last attention launch
  *   "tail_wgrad_main"   [0] 1: tail weight gradients on the caller's stream instead of the side stream (0.5 % slower)

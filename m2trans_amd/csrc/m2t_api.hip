@@ -116,8 +116,10 @@ struct m2t_plan {
   bool use_persistent_conv = false;  // bf16 conv3x3 with LDS-resident weights: bit-identical, measured a tie (see k_conv.hip)
   bool use_fused_tail_bwd = true;  // x4 bf16: k_tail_bwd.hip instead of four HR kernels
   bool tail_wgrad_main = false;    // tail weight gradients on the side stream (same-box A/B: +0.5 % over the main stream)
-  int gate_branch = 2;             // 2: after the two C = 256 attention launches of the block (same-box A/B, 6 alternating
-                                   // runs: 6.17 ms against 6.24 for 0 = after all four, 6.34 for 3, 6.23 ungated)
+  int gate_branch = 1;             // 1: after the C = 256, C = 256 and C = 64 attention launches of the block.  Round 1 (GEMM + halo gather on
+                                   // the main chain): 2 was best (6.17 ms against 6.24 for 0, 6.34 for 3, 6.23 ungated); with the projection
+                                   // data gradient inside the (longer, LDS-filling) attention kernels: 1 = 5.49 ms, 2 = 5.60, 3 = 5.62, 0 = 5.68,
+                                   // ungated 5.64 (config 1; +1 % at batch 32 as well)
   bool use_gated_side = true;      // see the side-stream schedule in m2t_backward
   int side_conv_pos = 1;           // the block's conv weight gradient: 0 first at the gate, 1 after the gated branches (same-box A/B:
                                    // +1.9 % over 0: the 512-thread, LDS-heavy kernel then meets the C = 16 instead of the C = 64 attention), 2 after the last attention (+1.8 %)
