@@ -70,7 +70,8 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           kernel per window (k_attn_fused.hip) instead of a GEMM launch + an attention launch
  *   "norm_single_stage" [0] InstanceNorm reductions by ONE 512-thread workgroup per (image, 16-channel chunk plane), no partials and
  *                           no fold launch: bit 0 = forward statistics, bit 1 = backward sums.  Measured slower at batch 16
- *                           (+15 / +21 us per launch: 64 workgroups cannot stream the map as fast as 512)
+ *                           (+15 / +21 us per launch: 64 workgroups cannot stream the map as fast as 512); bit 2 = the fold of the
+ *                           backward partials inside the apply kernel instead of a separate launch (bit-identical, 1.5 % slower)
  *   "fused_qkv_dgrad"   [1] bf16, C = 64 / 256 branches: the data gradient of the qkv projection is taken inside the attention
  *                           backward kernel (k_attn_res.hip): the window multiplies its own dq | dK | dV rows by Wqkv^T, the
  *                           overlap-add over neighbouring windows moves to the C-wide product.  Removes the halo gather and

@@ -865,6 +865,53 @@ __global__ void __launch_bounds__(256) instnorm_bwd_apply_kernel(const T* __rest
     store8f(gx + o64, r);
   }
 }
+// apply with the second reduction stage folded in: every workgroup of image b first folds the 32 partials of the 64
+// channels itself (64 threads, all loads in flight at once, the SAME fixed tree as instnorm_bwd_red2_kernel -> identical
+// bits) and keeps mean / rstd / s in LDS; saves the 5 us fold launch and its gap on the critical path of every block.
+template <typename T>
+__global__ void __launch_bounds__(256) instnorm_bwd_apply_fold_kernel(const T* __restrict__ gn, const T* __restrict__ x,
+                                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                      const float* __restrict__ part, const T* __restrict__ gres,
+                                                                      T* __restrict__ gx, int B, int P, int nsplit, float invP) {
+  static_assert(M2T_NORM_SPLIT == 32, "the fixed tree below is written for 32 partials");
+  __shared__ float cs[64][4];                     // mean, rstd, s1, s2
+  const int b = blockIdx.y;
+  if (threadIdx.x < 64) {
+    const int ch = threadIdx.x;
+    const float* o = part + ((long long)b * nsplit * 64 + ch) * 2;
+    float2 v[M2T_NORM_SPLIT];
+#pragma unroll
+    for (int q = 0; q < M2T_NORM_SPLIT; ++q)
+      v[q] = (q < nsplit) ? *reinterpret_cast<const float2*>(o + (long long)q * 128) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int st = 1; st < M2T_NORM_SPLIT; st <<= 1)
+#pragma unroll
+      for (int q = 0; q < M2T_NORM_SPLIT; q += 2 * st) { v[q].x += v[q + st].x; v[q].y += v[q + st].y; }
+    cs[ch][0] = mean[b * 64 + ch];
+    cs[ch][1] = rstd[b * 64 + ch];
+    cs[ch][2] = v[0].x * invP;
+    cs[ch][3] = v[0].y * invP;
+  }
+  __syncthreads();
+  const long long npix = (long long)B * P;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < P * 8; t += gridDim.x * blockDim.x) {
+    const int cgp = t & 7;
+    const int pix = b * P + (t >> 3);
+    float g[8], v[8], r[8];
+    const long long o64 = p64(npix, pix, cgp * 8);
+    load8f(gn + o64, g);
+    load8f(x + o64, v);
+    load8f(gres + o64, r);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float* k4 = cs[cgp * 8 + c];
+      const float rs = k4[1];
+      const float xh = (v[c] - k4[0]) * rs;
+      r[c] += rs * (g[c] - k4[2] - xh * k4[3]);
+    }
+    store8f(gx + o64, r);
+  }
+}
 // single-stage reduction (see instnorm_stats_whole_kernel): one 512-thread workgroup per (image, chunk plane) sums
 // g_n and g_n * xhat over the P pixels and writes s = (mean_p g_n, mean_p g_n xhat) directly
 template <typename T>
@@ -935,6 +982,15 @@ int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean
   if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_red1_kernel<float>, dim3(nsplit, B), dim3(256), 0, st, (const float*)gn, (const float*)x, mean, rstd, part, P, nsplit);
   else hipLaunchKernelGGL(instnorm_bwd_red1_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, part, P, nsplit);
   M2T_LAUNCH_CHECK();
+  if (single_stage >= 0 && (single_stage & 4)) {
+    // option bit 2: the fold rides in the apply kernel.  Measured SLOWER (5.64 vs 5.56 ms per step): the 1024-workgroup
+    // apply with its 16 KB prologue per workgroup loses more than the 5 us launch it saves; default is the separate fold.
+    const int gx_ = std::max(1, std::min(ceil_div(P * 8, 256), std::max(1024 / std::max(B, 1), 8)));   // ~1024 workgroups: the prologue re-reads 16 KB of partials each
+    if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_apply_fold_kernel<float>, dim3(gx_, B), dim3(256), 0, st, (const float*)gn, (const float*)x, mean, rstd, part, (const float*)gres, (float*)gx, B, P, nsplit, 1.0f / (float)P);
+    else hipLaunchKernelGGL(instnorm_bwd_apply_fold_kernel<bf16_t>, dim3(gx_, B), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, part, (const bf16_t*)gres, (bf16_t*)gx, B, P, nsplit, 1.0f / (float)P);
+    M2T_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(instnorm_bwd_red2_kernel, dim3(B), dim3(64), 0, st, part, s, nsplit, 1.0f / (float)P);
   M2T_LAUNCH_CHECK();
   }
