@@ -73,13 +73,15 @@ def read_all():
 
 
 def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8, fused_attn_fwd: bool | None = None,
-                     fused_tail_fwd: bool = False):
+                     fused_tail_fwd: bool = False, fused_qkv_dgrad: bool | None = None):
     """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr.
     fused_attn_fwd (default: bf16 mode): the C = 64 / 256 branches run qkv projection + attention as one kernel, so
     the forward `gemm_qkv` / `attn_fwd_*` categories are then empty (the C = 16 branch runs InstanceNorm apply +
     projection + attention as `attn_fused_c16`).  fused_tail_fwd: option "fused_tail_fwd" of the plan (default off)."""
     if fused_attn_fwd is None:
         fused_attn_fwd = dtype == "bf16"
+    if fused_qkv_dgrad is None:          # plan option "fused_qkv_dgrad" (default on in bf16 mode): C = 64 / 256 branches
+        fused_qkv_dgrad = dtype == "bf16"
     es = 2 if dtype == "bf16" else 4
     H = W = (lr + 31) // 32 * 32
     P = H * W
@@ -94,14 +96,18 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
     for C_, L in br:
         M = B * P // (4 ** L)
         win = M // 64
-        add(f"attn_bwd_c{C_}", nb * win * 64000.0 * C_, nb * M * 7 * C_ * es, nb)
+        dg = fused_qkv_dgrad and C_ >= 64
+        # reads q|k|v (3C) and the output gradient (C), writes dq|dK|dV (3C); with the projection data gradient inside the
+        # kernel also g_d (C) and 2 M 3C C more FLOPs
+        add(f"attn_bwd_c{C_}", nb * (win * 64000.0 * C_ + (2.0 * M * C_ * 3 * C_ if dg else 0.0)), nb * M * (8 if dg else 7) * C_ * es, nb)
         if fused_attn_fwd:
             # reads x (+ the residual rows for C >= 64; for C = 16 the residual IS x), writes qkv + out (+ d1 for C = 16)
             add(f"attn_fused_c{C_}", nb * (win * 25600.0 * C_ + 2.0 * M * C_ * 3 * C_), nb * M * 6 * C_ * es, nb)
         else:
             add(f"attn_fwd_c{C_}", nb * win * 25600.0 * C_, nb * M * (4 * C_ + (C_ if C_ == 16 else 0)) * es, nb)
             add("gemm_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
-        add("gemm_qkv_dgrad", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
+        if not dg:
+            add("gemm_qkv_dgrad", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
         add("wgrad_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
     conv_fl = 2.0 * B * P * 64 * 576
     add("conv3x3_fwd", nb * conv_fl, nb * B * P * 64 * es * 3, nb)
