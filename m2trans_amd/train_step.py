@@ -38,8 +38,11 @@ class TrainStep:
     def __init__(self, model: M2Trans, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  lambda_l1: float = 1.0, process_group=None, world_size: Optional[int] = None,
                  grad_bucket_dtype: torch.dtype = torch.float32, semantic_loss=None, lambda_clip: float = 0.0,
-                 overlap_comm: bool = True, force_comm_path: bool = False):
+                 overlap_comm: bool = True, force_comm_path: bool = False, overlap_semantic: bool = True):
         self.model = model
+        # the SemanticLoss forward needs only sr (final after m2t_forward): it runs on its own stream under the backward pass
+        self.overlap_semantic = bool(overlap_semantic)
+        self.sem_stream = None
         self.lr = float(lr)
         self.betas = (float(betas[0]), float(betas[1]))
         self.eps = float(eps)
@@ -97,11 +100,23 @@ class TrainStep:
                                        float(m.rgb_range), 1, ws, st), "m2t_forward")
             _lib.check(lib.m2t_l1_loss(plan.handle, _lib.ptr(hr_img), self.lambda_l1, divisor, float(m.rgb_range),
                                        _lib.ptr(self.l1_loss), ws, st), "m2t_l1_loss")
+            fwd_done = torch.cuda.current_stream(lr_img.device).record_event() if (use_clip and self.overlap_semantic) else None
             _lib.check(lib.m2t_backward(plan.handle, _lib.ptr(m.flat_params), _lib.ptr(lr_img), _lib.ptr(self.grads),
                                         ws, st), "m2t_backward")
         if use_clip:
             # clip_loss += loss_clip(sr[i], hr[i], caption_i) * lambda_clip  (train.py:203-205); no gradient
-            self.clip_loss = self.semantic_loss.batch(sr, hr_img, captions) * self.lambda_clip
+            if self.overlap_semantic:
+                # the backward pass is already enqueued on the caller's stream; the encoder (which synchronises its own
+                # stream once for the crop table) follows the forward pass on a second stream and is joined afterwards
+                main = torch.cuda.current_stream(lr_img.device)
+                if self.sem_stream is None:
+                    self.sem_stream = torch.cuda.Stream(device=lr_img.device)
+                self.sem_stream.wait_event(fwd_done)
+                with torch.cuda.stream(self.sem_stream):
+                    self.clip_loss = self.semantic_loss.batch(sr, hr_img, captions) * self.lambda_clip
+                main.wait_stream(self.sem_stream)
+            else:
+                self.clip_loss = self.semantic_loss.batch(sr, hr_img, captions) * self.lambda_clip
             self.loss = self.l1_loss + self.clip_loss
         else:
             self.loss = self.l1_loss
