@@ -76,6 +76,9 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           backward kernel (k_attn_res.hip): the window multiplies its own dq | dK | dV rows by Wqkv^T, the
  *                           overlap-add over neighbouring windows moves to the C-wide product.  Removes the halo gather and
  *                           the GEMM launch from the main chain (+2.3 % at batch 16, neutral at batch 32)
+ *   "merged_rel_reduce" [0] first stage of the rel-pos gradient reduction for a block's four branches in one launch instead of four
+ *                           (bit-identical; 0.7 % / 1.8 % slower at batch 16 / 32: the merged launch sits at the end of the block's
+ *                           side work and meets the next block's conv data gradient)
  *   "fused_c16_dgrad"   [0] the same inside the wave-per-window C = 16 backward kernel (measured a tie / -0.3 %); needs
  *                           "fused_qkv_dgrad"
  *   "dgrad_gather_in_prep" [1] with "fused_qkv_dgrad": branch_prep_bwd adds the ring rows of the neighbouring windows while it

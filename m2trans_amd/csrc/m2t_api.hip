@@ -133,6 +133,7 @@ struct m2t_plan {
                                        // bit-identical; same-box A/B 5.73 vs 5.69 ms per step, i.e. no gain: kept as an option)
   int norm_single_stage = 0;           // InstanceNorm reductions: bit 0 / bit 1 = forward statistics / backward sums by one workgroup per (image, chunk)
   bool fused_dgrad_gather_in_prep = true;   // ring rows of the fused data gradient added by branch_prep_bwd on load (0: separate gather launch)
+  bool merged_rel_reduce = false;      // the rel-pos partial reductions of a block's four branches in one launch: measured SLOWER (5.48 vs 5.44 ms; batch 32: 10.03 vs 9.85)
   bool use_fused_c16_dgrad = false;    // ... and inside the wave-per-window C = 16 backward kernel (k_attn_c16.hip): a tie at batch 16, -0.3 % at batch 32
   bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside the attention backward kernel (k_attn_res.hip)
   bool use_fused_c16_fwd = true;       // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip)
@@ -307,6 +308,7 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
     p->add_ws("gqkv" + std::to_string(i), BP * 48, es);
     p->add_ws("win" + std::to_string(i), BP * 50, es);
     p->add_ws("relw" + std::to_string(i), (size_t)(BP / 64) * 10 * 16, 4);
+    p->add_ws("relwB" + std::to_string(i), (size_t)(BP / 64) * 10 * 16, 4);   // odd blocks: the merged rel-pos reduction of a block may lag into the next one
   }
   p->add_ws("rel_part", 32 * 10 * 256, 4);
   {
@@ -666,7 +668,9 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   void* gy = WSP("gT");
   void* gnext[2] = {WSP("gA"), WSP("gB")};
   void* gqkv_buf[4] = {WSP("gqkv0"), WSP("gqkv1"), WSP("gqkv2"), WSP("gqkv3")};
-  float* relw_buf[4] = {(float*)WSP("relw0"), (float*)WSP("relw1"), (float*)WSP("relw2"), (float*)WSP("relw3")};
+  float* relw_set[2][4] = {{(float*)WSP("relw0"), (float*)WSP("relw1"), (float*)WSP("relw2"), (float*)WSP("relw3")},
+                           {(float*)WSP("relwB0"), (float*)WSP("relwB1"), (float*)WSP("relwB2"), (float*)WSP("relwB3")}};
+  hipEvent_t rel_done[2] = {nullptr, nullptr};      // the merged rel-pos reduction that last read relw_set[parity] has run
   void* win_buf[4] = {WSP("win0"), WSP("win1"), WSP("win2"), WSP("win3")};
   hipEvent_t branch_done[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t conv_done_prev = nullptr;      // side finished reading gy of the previously processed block
@@ -689,6 +693,9 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     void* gxc = WSP("gxc");
     void* gn = WSP("gn");
     void* gy_blk = gy;
+    float** relw_buf = relw_set[b & 1];
+    const bool merged_rel = p->merged_rel_reduce;
+    m2t_rel_desc4 rel_descs{};
     // feed_forward conv: weight / bias gradients on the side stream, data gradient on the main one
     auto side_conv = [&]() -> int {
       if (skip) return 0;
@@ -718,7 +725,15 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       defer(slabs, p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0);
       ARENA(relp, (size_t)32 * 10 * C);
       int nsp = 0;
-      CK(launch_rel_reduce1(relw_buf[i], relp, (int)(M / 64), C, &nsp, sd));
+      if (merged_rel) {
+        // one launch for the block's four branches, issued with the last one (i = 0); each block parity has its own relw set
+        m2t_rel_desc& rd = rel_descs.d[i];
+        rel_reduce1_plan((int)(M / 64), C, &rd);
+        rd.relw = relw_buf[i]; rd.part = relp; nsp = rd.nsplit;
+        if (i == 0) { CK(launch_rel_reduce1_multi(rel_descs, 4, sd)); rel_done[b & 1] = side_marker(); }
+      } else {
+        CK(launch_rel_reduce1(relw_buf[i], relp, (int)(M / 64), C, &nsp, sd));
+      }
       defer(relp, p->poff.at(an + "rel_h"), nsp, 10LL * C, 4, C, 0, 0);     // rel_h then rel_w are adjacent parameters
       return 0;
     };
@@ -741,6 +756,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       void* win = win_buf[i];
       float* relw = relw_buf[i];
       main_wait(branch_done[i]);             // the side consumers of this branch's buffers (previous block) are done
+      if (merged_rel && i == 3) { main_wait(rel_done[b & 1]); rel_done[b & 1] = nullptr; }   // ... and of this parity's relw set (two blocks ago)
       // gradient of IWT^L is DWT^L: applied while the kernel loads g_xc[chunk i]
       // dK|dV stay window-major in `win`; the fused tail kernel gathers them once per row, writes them back
       // into gqkv for the weight-gradient GEMM, multiplies by Wqkv and applies IWT / branch mixing.
@@ -860,6 +876,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
   if (std::string(key) == "norm_single_stage") { p->norm_single_stage = (int)value; return 0; }
   if (std::string(key) == "dgrad_gather_in_prep") { p->fused_dgrad_gather_in_prep = (value != 0); return 0; }
+  if (std::string(key) == "merged_rel_reduce") { p->merged_rel_reduce = (value != 0); return 0; }
   if (std::string(key) == "fused_c16_dgrad") { p->use_fused_c16_dgrad = (value != 0); return 0; }
   if (std::string(key) == "fused_qkv_dgrad") { p->use_fused_qkv_dgrad = (value != 0); return 0; }
   if (std::string(key) == "fused_c16_fwd") { p->use_fused_c16_fwd = (value != 0); return 0; }

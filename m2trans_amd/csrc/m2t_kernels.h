@@ -202,6 +202,11 @@ int launch_window_attn_fused_fwd(const void* x, const void* wfrag, const float* 
 // relw [nwin][10][C] per-window partials -> grel_h / grel_w (torch layouts)
 int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st);
 int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int* nsplit_out, hipStream_t st);
+// the first stage of up to four branches in one launch; rel_reduce1_plan fills nwin / ncol / wps / nsplit (same split rule)
+struct m2t_rel_desc { const float* relw; float* part; int nwin, ncol, wps, nsplit; };
+struct m2t_rel_desc4 { m2t_rel_desc d[4]; };
+void rel_reduce1_plan(int nwin, int C, m2t_rel_desc* d);
+int launch_rel_reduce1_multi(const m2t_rel_desc4& a, int n, hipStream_t st);
 
 // ---- k_swin.hip (MedCLIP image tower = Swin-T forward, losses.py:68-69) --------------------
 int launch_swin_patchify(int dt, const float* src, int Hs, int Ws, const int* crops, int n, void* out, hipStream_t st);
