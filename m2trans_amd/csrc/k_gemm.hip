@@ -142,10 +142,10 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __r
 // the next stage's global loads in registers while the current one is multiplied: 32 (BM = 128) or 16 (BM = 64)
 // MFMAs per wave per barrier instead of 8.
 // ---------------------------------------------------------------------------------------
-template <typename T, int BM>
+template <typename T, int BM, int EMODE>
 __global__ void __launch_bounds__(256)
 gemm_nt_wide_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __restrict__ Y, int ldy, long long M, int N,
-                    int K) {
+                    int K, const float* __restrict__ bias, const T* __restrict__ aux, int ldaux) {
   constexpr int BN = 128, BK = 64, LD = BK + 8, MT = BM / 64, NA = BM / 32, NW = 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T(*As)[BM][LD] = reinterpret_cast<T(*)[BM][LD]>(smem);
@@ -216,29 +216,50 @@ gemm_nt_wide_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][4 * h + nt][r];
-      store16f(Y + m * ldy + n0 + 64 * h + 16 * g, v);
+      const int nn = n0 + 64 * h + 16 * g;
+      if constexpr (EMODE == M2T_E_BIAS) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += bias[nn + e];
+      } else if constexpr (EMODE == M2T_E_BIAS_GELU) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = gelu_erf(v[e] + bias[nn + e]);
+      } else if constexpr (EMODE == M2T_E_BIAS_RESID) {
+        float p[16];
+        load16f(aux + m * ldaux + nn, p);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += (bias ? bias[nn + e] : 0.f) + p[e];
+      }
+      store16f(Y + m * ldy + nn, v);
     }
   }
 }
-template <typename T, int BM>
+template <typename T, int BM, int EMODE>
 static int launch_gemm_nt_wide(const m2t_gemm_args& a, hipStream_t st) {
   const size_t sh = sizeof(T) * 2 * (BM + 128) * 72;
-  if (int rc__ = m2t_ensure_dynamic_lds((const void*)gemm_nt_wide_kernel<T, BM>, (int)sh)) return rc__;
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)gemm_nt_wide_kernel<T, BM, EMODE>, (int)sh)) return rc__;
   dim3 grid((unsigned)(ceil_divll(a.M, BM) * (a.N / 128)));
-  hipLaunchKernelGGL((gemm_nt_wide_kernel<T, BM>), grid, dim3(256), sh, st, (const T*)a.A, a.lda, (const T*)a.W, (T*)a.Y, a.ldy,
-                     a.M, a.N, a.K);
+  hipLaunchKernelGGL((gemm_nt_wide_kernel<T, BM, EMODE>), grid, dim3(256), sh, st, (const T*)a.A, a.lda, (const T*)a.W, (T*)a.Y, a.ldy,
+                     a.M, a.N, a.K, a.bias, (const T*)a.aux, a.ldaux);
   M2T_LAUNCH_CHECK();
   return 0;
+}
+template <typename T, int EMODE>
+static int launch_gemm_nt_wide_bm(const m2t_gemm_args& a, hipStream_t st) {
+  // enough 128-column blocks to fill the chip with BM = 128?  otherwise halve the row tile
+  const long long blocks128 = ceil_divll(a.M, 128) * (a.N / 128);
+  if (sizeof(T) == 2 && blocks128 >= 512) return launch_gemm_nt_wide<T, 128, EMODE>(a, st);
+  return launch_gemm_nt_wide<T, 64, EMODE>(a, st);
 }
 
 template <typename T>
 static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStream_t st) {
   if (a.K % 8 || a.N % 16) return m2t_set_error(-2, "gemm_nt: K must be a multiple of 8 and N of 16");
-  if (amode == M2T_A_PLAIN && emode == M2T_E_PLAIN && a.N % 128 == 0 && a.K % 64 == 0 && a.K >= 128) {
-    // enough 128-column blocks to fill the chip with BM = 128?  otherwise halve the row tile
-    const long long blocks128 = ceil_divll(a.M, 128) * (a.N / 128);
-    if (sizeof(T) == 2 && blocks128 >= 512) return launch_gemm_nt_wide<T, 128>(a, st);
-    return launch_gemm_nt_wide<T, 64>(a, st);
+  if (amode == M2T_A_PLAIN && a.N % 128 == 0 && a.K % 64 == 0 && a.K >= 128 && a.ldy != M2T_LD_P64) {
+    if (emode == M2T_E_PLAIN) return launch_gemm_nt_wide_bm<T, M2T_E_PLAIN>(a, st);
+    // the Swin-T GEMMs of stages 3 / 4 (and fc1 of stage 2): bias, bias + GELU, bias + residual epilogues
+    if (sizeof(T) == 2 && emode == M2T_E_BIAS) return launch_gemm_nt_wide_bm<T, M2T_E_BIAS>(a, st);
+    if (sizeof(T) == 2 && emode == M2T_E_BIAS_GELU) return launch_gemm_nt_wide_bm<T, M2T_E_BIAS_GELU>(a, st);
+    if (sizeof(T) == 2 && emode == M2T_E_BIAS_RESID) return launch_gemm_nt_wide_bm<T, M2T_E_BIAS_RESID>(a, st);
   }
   dim3 grid((unsigned)(ceil_divll(a.M, GEMM_BM) * ceil_div(a.N, GEMM_BN)));
   ShufGeom sg{a.H, a.Wd, a.r, a.C, a.halo_win, a.M};
