@@ -178,6 +178,17 @@ int m2t_semantic_loss(const float* emb, const float* text, int B, int n_patches,
 /* F.interpolate(mode='bicubic', align_corners=True) (losses.py:53-54): src [NC,Hin,Win] -> dst [NC,Hout,Wout]. */
 int m2t_bicubic_resize(const float* src, float* dst, int NC, int Hin, int Win, int Hout, int Wout, void* stream);
 
+/* ---- util/rlutrans.py TransBlock (dead code in the reference: nothing imports it) --------------------
+ * TransBlock.forward (util/rlutrans.py:82-87) for dim = 64, 8 heads: x + EffAttention(LayerNorm(x)) (:30-67: reduce,
+ * qkv, softmax attention inside token chunks of length N // 16, proj), then x + Mlp(LayerNorm(x)) (:11-27: 64 -> 16,
+ * ReLU, 16 -> 64).  Forward only.  params: the 22 928 float32 values of TransBlock(n_feat=64, dim=64).state_dict() in
+ * state_dict order (atten.reduce.weight, atten.qkv.weight, atten.proj.weight, atten.proj.bias, norm1.weight,
+ * norm1.bias, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias, norm2.weight, norm2.bias); x, y [B,N,64]
+ * float32 on the device (y may alias x); dtype = compute element type (0 fp32, 1 bf16); N >= 16. */
+size_t m2t_transblock_workspace_bytes(int B, int N, int dtype);
+int m2t_transblock_forward(const float* params, const float* x, float* y, int B, int N, int dtype, void* workspace,
+                           void* stream);
+
 /* ---- evaluation metrics of the reference's test loop ------------------------------------------
  * test.py:101-113 / train.py:299-312: Y channel of utils.rgb_to_ycbcr (utils.py:121-146), `crop` (= scale) border
  * pixels removed, x255 when rgb_range == 1; then utils.calc_psnr (utils.py:179-184) and utils.calc_ssim

@@ -40,6 +40,8 @@ SIGNATURES = {
     "m2t_swin_encode": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i), _i, _vp, _vp, _vp]),
     "m2t_semantic_loss": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "m2t_bicubic_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "m2t_transblock_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
+    "m2t_transblock_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "m2t_eval_metrics_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "m2t_eval_metrics": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "m2t_crop_patches": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -120,6 +120,10 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = gelu_erf(v[e] + bias[nn + e]);
       store16f(Y + m * ldy + nn, v);
+    } else if (EMODE == M2T_E_BIAS_RELU) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e] + bias[nn + e], 0.f);
+      store16f(Y + m * ldy + nn, v);
     } else if (EMODE == M2T_E_BIAS_RESID) {
       float p[16];
       load16f(aux + m * ldaux + nn, p);
@@ -271,6 +275,7 @@ static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStr
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_SHUF) GO(M2T_A_PLAIN, M2T_E_BIAS_SHUF);
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_GELU) GO(M2T_A_PLAIN, M2T_E_BIAS_GELU);
   else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_RESID) GO(M2T_A_PLAIN, M2T_E_BIAS_RESID);
+  else if (amode == M2T_A_PLAIN && emode == M2T_E_BIAS_RELU) GO(M2T_A_PLAIN, M2T_E_BIAS_RELU);
   else if (amode == M2T_A_UNSHUF && emode == M2T_E_PLAIN) GO(M2T_A_UNSHUF, M2T_E_PLAIN);
   else if (amode == M2T_A_UNSHUF && emode == M2T_E_GELU_GRAD) GO(M2T_A_UNSHUF, M2T_E_GELU_GRAD);
   else return m2t_set_error(-2, "gemm_nt: unsupported (A mode, epilogue) combination");

@@ -89,7 +89,8 @@ int launch_layout(int dt, const float* nchw, void* nhwc, float* nchw_out, int B,
 // leading dimension sentinel: the operand / output is a P64 feature map ([4][M][16], m2t_common.h) with M rows
 #define M2T_LD_P64 (-64)
 enum m2t_gemm_a { M2T_A_PLAIN = 0, M2T_A_GELU = 1, M2T_A_UNSHUF = 2 };
-enum m2t_gemm_epi { M2T_E_PLAIN = 0, M2T_E_BIAS = 1, M2T_E_BIAS_SHUF = 2, M2T_E_GELU_GRAD = 3, M2T_E_BIAS_GELU = 4, M2T_E_BIAS_RESID = 5 };
+enum m2t_gemm_epi { M2T_E_PLAIN = 0, M2T_E_BIAS = 1, M2T_E_BIAS_SHUF = 2, M2T_E_GELU_GRAD = 3, M2T_E_BIAS_GELU = 4, M2T_E_BIAS_RESID = 5,
+                    M2T_E_BIAS_RELU = 6 };   // (+ bias, ReLU: Mlp of util/rlutrans.py:22-23)
 struct m2t_gemm_args {
   const void* A; int lda;       // A rows (or, UNSHUF: the [B][H*r][W*r][C] tensor)
   const void* W;                // [N][K] element type T

@@ -291,6 +291,36 @@ def main():
     report.append(f"checkpoint manifest of the reference (DataParallel + Adam + CosineAnnealingLR, epoch 2): "
                   f"{len(ck['model_state_dict'])} model keys, {len(st)} Adam states, last_epoch 1 -> tests/golden/checkpoint_manifest.json")
 
+    # ---- 11. util/rlutrans.py TransBlock (dead code in the reference, restated in oracle/rlutrans_oracle.py) ----
+    # The real module is imported, given seed-33 default-initialised weights, and run on seeded token maps whose lengths
+    # cover both chunk rules of :53-55 (N a multiple of 16, and N = 16 q + r with a 17th, shorter chunk).
+    sys.path.insert(0, REF)
+    from util.rlutrans import TransBlock                                       # noqa: E402
+    from oracle import rlutrans_oracle as RO
+    torch.manual_seed(33)
+    tb = TransBlock(n_feat=64, dim=64).eval()
+    tb_state = {k: v.detach().clone() for k, v in tb.state_dict().items()}
+    gold = {"names": np.array(list(tb_state.keys()))}
+    for k, v in tb_state.items():
+        gold["p:" + k] = v.numpy()
+    worst = 0.0
+    for tag, (Bt, Nt) in {"n256": (2, 256), "n87": (3, 87)}.items():
+        g = torch.Generator().manual_seed(33 + Nt)
+        xt = torch.randn(Bt, Nt, 64, generator=g)
+        with torch.no_grad():
+            want = tb(xt)
+            got = RO.trans_block(xt, tb_state)
+            got64 = RO.trans_block(xt.double(), {k: v.double() for k, v in tb_state.items()})
+        e32, e64 = relerr(got, want), relerr(got64.float(), want)
+        assert e32 < 1e-6 and e64 < 2e-6, (tag, e32, e64)
+        worst = max(worst, e32)
+        gold["x:" + tag] = xt.numpy()
+        gold["y:" + tag] = want.numpy()
+    assert sum(v.numel() for v in tb_state.values()) == 22928
+    np.savez_compressed(os.path.join(out_dir, "transblock.npz"), **gold)
+    report.append(f"util/rlutrans.py TransBlock(dim=64) forward, N = 256 and N = 87 (17 chunks): oracle vs reference rel {worst:.2e}; "
+                  f"22 928 parameters -> tests/golden/transblock.npz")
+
     with open(os.path.join(HERE, "PINNING.txt"), "w") as f:
         f.write("oracle/m2trans_oracle.py checked against /root/reference "
                 "(models/M2Trans_network.py, utils.py, datas/us1k.py, datas/benchmark.py) by oracle/pin_against_reference.py\n")
