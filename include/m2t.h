@@ -215,6 +215,14 @@ int m2t_crop_patches(const unsigned char* lr_pool, const unsigned char* hr_pool,
 /* datas/benchmark.py:62-72 (`Benchmark.__getitem__`): top-left h x w crop of a uint8 HWC image [img_h,img_w,channels]
  * resident in device memory -> float32 [channels,h,w] / 255, bit-identical to ndarray2tensor(...)/255. */
 int m2t_image_to_tensor(const unsigned char* img, int img_h, int img_w, int channels, int h, int w, float* out, void* stream);
+/* train.py:177-181: utils.cutmix (utils.py:16-71) and utils.cut_out (utils.py:74-108) on a device batch.  The random
+ * draws stay with the caller (m2trans_amd/augment.py mirrors the reference's order); table_dev: int[B][1 + 5 * max_boxes]
+ * on the device = { n, then n x (x1, y1, x2, y2, source sample) } in the order the reference applies the boxes.
+ * mode 0 = cutmix: a pixel takes the value of the LAST covering box's source sample in the ORIGINAL tensor;
+ * mode 1 = cut_out: a covered pixel is multiplied by 0.  mult scales the boxes (1 for LR, `scale` for HR, utils.py:49).
+ * src, dst: float32 [B,C,H,W], distinct buffers.  Bit-identical to the reference's tensors. */
+int m2t_box_mix(const float* src, float* dst, int B, int C, int H, int W, const int* table_dev, int max_boxes, int mode,
+                int mult, void* stream);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,7 @@ SIGNATURES = {
     "m2t_eval_metrics": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "m2t_crop_patches": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m2t_image_to_tensor": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "m2t_box_mix": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "m2t_dwt": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "m2t_iwt": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "m2t_pixel_shuffle": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

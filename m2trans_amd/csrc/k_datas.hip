@@ -94,3 +94,47 @@ extern "C" int m2t_image_to_tensor(const unsigned char* img, int img_h, int img_
   M2T_LAUNCH_CHECK();
   return 0;
 }
+
+// =======================================================================================
+// On-device batch augmentations of train.py:177-181 (utils.py:16-108): cutmix and cut_out as ONE box-table kernel.
+// The random draws stay with the host (reference order, m2trans_amd/augment.py); the table holds per sample up to
+// `maxb` boxes (x1, y1, x2, y2, source sample) in the order the reference applies them:
+//   mode 0 (cutmix, utils.py:36-51): a pixel takes the value of the LAST box that covers it, read from the source sample of
+//          that box in the ORIGINAL tensor (every patch copies from the original, later patches overwrite);
+//   mode 1 (cut_out, utils.py:74-92): a pixel covered by any box is multiplied by 0 (img * mask).
+// `mult` scales the box (1 for the LR tensor, `scale` for the HR tensor, utils.py:49).
+// =======================================================================================
+__global__ void __launch_bounds__(256) box_mix_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W,
+                                                      const int* __restrict__ table, int maxb, int mode, int mult) {
+  const long long total = (long long)B * C * H * W;
+  const int rowlen = 1 + 5 * maxb;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(t % W);
+    long long r = t / W;
+    const int y = (int)(r % H); r /= H;
+    const int c = (int)(r % C);
+    const int b = (int)(r / C);
+    const int* row = table + (long long)b * rowlen;
+    const int n = row[0];
+    float v = src[t];
+    for (int i = n - 1; i >= 0; --i) {
+      const int* q = row + 1 + 5 * i;
+      if (x >= q[0] * mult && x < q[2] * mult && y >= q[1] * mult && y < q[3] * mult) {
+        v = (mode == 0) ? src[(((long long)q[4] * C + c) * H + y) * W + x] : v * 0.0f;
+        break;
+      }
+    }
+    dst[t] = v;
+  }
+}
+extern "C" int m2t_box_mix(const float* src, float* dst, int B, int C, int H, int W, const int* table_dev, int max_boxes, int mode,
+                           int mult, void* stream) {
+  if (!src || !dst || !table_dev || B < 1 || C < 1 || H < 1 || W < 1 || max_boxes < 1 || mult < 1 || (mode != 0 && mode != 1))
+    return m2t_set_error(M2T_ERR_ARG, "m2t_box_mix: bad argument");
+  if (src == dst) return m2t_set_error(M2T_ERR_ARG, "m2t_box_mix: in-place is not supported (boxes read other samples of the original)");
+  const long long total = (long long)B * C * H * W;
+  hipLaunchKernelGGL(box_mix_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     B, C, H, W, table_dev, max_boxes, mode, mult);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}

@@ -321,6 +321,32 @@ def main():
     report.append(f"util/rlutrans.py TransBlock(dim=64) forward, N = 256 and N = 87 (17 chunks): oracle vs reference rel {worst:.2e}; "
                   f"22 928 parameters -> tests/golden/transblock.npz")
 
+    # ---- 12. utils.cutmix / utils.cut_out (train.py:177-181; switched off in every shipped config) ----
+    from oracle import augment_oracle as AO
+    gold = {}
+    ncm = nco = 0
+    for seed in range(33, 33 + 12):
+        Bt = 5 if seed % 2 else 4                 # odd batch: torch.chunk gives halves of 3 and 2
+        g = torch.Generator().manual_seed(seed)
+        lr_t = torch.rand(Bt, 3, 12, 12, generator=g)
+        hr_t = torch.rand(Bt, 3, 24, 24, generator=g)
+        n_patch, n_holes, length = 1 + seed % 4, 1 + seed % 9, 3
+        AO.seed_all(seed)
+        w_lr, w_hr = U.cutmix(lr_t, hr_t, alpha=1.0, n_patch=n_patch, scale=2)
+        w_co = U.cut_out(lr_t, n_holes=n_holes, length=length)
+        AO.seed_all(seed)
+        o_lr, o_hr = AO.cutmix(lr_t, hr_t, alpha=1.0, n_patch=n_patch, scale=2)
+        o_co = AO.cut_out(lr_t, n_holes=n_holes, length=length)
+        assert torch.equal(o_lr, w_lr) and torch.equal(o_hr, w_hr) and torch.equal(o_co, w_co), seed
+        ncm += int(not torch.equal(w_lr, lr_t))
+        nco += int(not torch.equal(w_co, lr_t))
+        gold[f"lr:{seed}"] = lr_t.numpy(); gold[f"hr:{seed}"] = hr_t.numpy()
+        gold[f"cm_lr:{seed}"] = w_lr.numpy(); gold[f"cm_hr:{seed}"] = w_hr.numpy(); gold[f"co:{seed}"] = w_co.numpy()
+        gold[f"args:{seed}"] = np.array([n_patch, n_holes, length])
+    assert ncm >= 3 and nco >= 3, (ncm, nco)      # both coin outcomes are covered
+    np.savez_compressed(os.path.join(out_dir, "augment.npz"), **gold)
+    report.append(f"utils.cutmix / utils.cut_out: 12 seeded calls bit-equal to utils.py ({ncm} / {nco} of them modify the batch) -> tests/golden/augment.npz")
+
     with open(os.path.join(HERE, "PINNING.txt"), "w") as f:
         f.write("oracle/m2trans_oracle.py checked against /root/reference "
                 "(models/M2Trans_network.py, utils.py, datas/us1k.py, datas/benchmark.py) by oracle/pin_against_reference.py\n")
