@@ -171,6 +171,10 @@ int m2t_swin_load_weights(m2t_swin* p, const float* weights, void* workspace, vo
  * -> emb [n,512] float32, unit L2 norm. */
 int m2t_swin_encode(m2t_swin* p, const float* src, int n_src, int Hs, int Ws, const int* crops_host, int n,
                     float* emb, void* workspace, void* stream);
+/* the same with the source images in two tensors (source index < n_a: src_a, else src_b[index - n_a]): the SR and HR
+ * batches of one training step (train.py:203-205) are encoded together without a torch.cat of 2 x B x 3 x Hs x Ws floats */
+int m2t_swin_encode_pair(m2t_swin* p, const float* src_a, int n_a, const float* src_b, int n_b, int Hs, int Ws,
+                         const int* crops_host, int n, float* emb, void* workspace, void* stream);
 /* losses.py:71-79 for a batch: emb [2B,512] (SR embeddings then HR embeddings), text [B,512] (any norm)
  * -> per_sample[B] = |sr.t - hr.t| / n_patches, total[1] = their sum. */
 int m2t_semantic_loss(const float* emb, const float* text, int B, int n_patches, float* per_sample, float* total,

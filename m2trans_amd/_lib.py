@@ -38,6 +38,7 @@ SIGNATURES = {
     "m2t_swin_param_name": (C.c_char_p, [_vp, _i]),
     "m2t_swin_load_weights": (_i, [_vp, _vp, _vp, _vp]),
     "m2t_swin_encode": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_i), _i, _vp, _vp, _vp]),
+    "m2t_swin_encode_pair": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, C.POINTER(_i), _i, _vp, _vp, _vp]),
     "m2t_semantic_loss": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "m2t_bicubic_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "m2t_transblock_workspace_bytes": (C.c_size_t, [_i, _i, _i]),

@@ -11,28 +11,31 @@
 // crops: int [n][3] = (source image index, y0, x0), device memory
 // ---------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) swin_patchify_kernel(const float* __restrict__ src, int Hs, int Ws,
-                                                            const int* __restrict__ crops, int n, T* __restrict__ out) {
+__global__ void __launch_bounds__(256) swin_patchify_kernel(const float* __restrict__ src, const float* __restrict__ src_b, int n_a,
+                                                            int Hs, int Ws, const int* __restrict__ crops, int n, T* __restrict__ out) {
+  // source images 0 .. n_a - 1 live in `src`, the rest in `src_b` (the SR batch and the HR batch need not be concatenated)
   const long long total = (long long)n * 3136 * 6;     // 6 vectors of 8 per patch row (48)
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const int v = (int)(t % 6);
     const long long row = t / 6;
     const int pw = (int)(row % 56), ph = (int)((row / 56) % 56), im = (int)(row / 3136);
     const int si = crops[im * 3], y0 = crops[im * 3 + 1], x0 = crops[im * 3 + 2];
+    const float* base = (si < n_a) ? src + (long long)si * 3 * Hs * Ws : src_b + (long long)(si - n_a) * 3 * Hs * Ws;
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = v * 8 + e, c = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
-      o[e] = src[(((long long)si * 3 + c) * Hs + y0 + 4 * ph + ky) * Ws + x0 + 4 * pw + kx];
+      o[e] = base[((long long)c * Hs + y0 + 4 * ph + ky) * Ws + x0 + 4 * pw + kx];
     }
     store8f(out + row * 48 + v * 8, o);
   }
 }
-int launch_swin_patchify(int dt, const float* src, int Hs, int Ws, const int* crops, int n, void* out, hipStream_t st) {
+int launch_swin_patchify(int dt, const float* src, const float* src_b, int n_a, int Hs, int Ws, const int* crops, int n, void* out,
+                         hipStream_t st) {
   const long long total = (long long)n * 3136 * 6;
   const int g = (int)std::min<long long>(ceil_divll(total, 256), 4096);
-  if (dt == M2T_F32) hipLaunchKernelGGL(swin_patchify_kernel<float>, dim3(g), dim3(256), 0, st, src, Hs, Ws, crops, n, (float*)out);
-  else hipLaunchKernelGGL(swin_patchify_kernel<bf16_t>, dim3(g), dim3(256), 0, st, src, Hs, Ws, crops, n, (bf16_t*)out);
+  if (dt == M2T_F32) hipLaunchKernelGGL(swin_patchify_kernel<float>, dim3(g), dim3(256), 0, st, src, src_b, n_a, Hs, Ws, crops, n, (float*)out);
+  else hipLaunchKernelGGL(swin_patchify_kernel<bf16_t>, dim3(g), dim3(256), 0, st, src, src_b, n_a, Hs, Ws, crops, n, (bf16_t*)out);
   M2T_LAUNCH_CHECK();
   return 0;
 }

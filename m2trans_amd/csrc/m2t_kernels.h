@@ -210,7 +210,8 @@ void rel_reduce1_plan(int nwin, int C, m2t_rel_desc* d);
 int launch_rel_reduce1_multi(const m2t_rel_desc4& a, int n, hipStream_t st);
 
 // ---- k_swin.hip (MedCLIP image tower = Swin-T forward, losses.py:68-69) --------------------
-int launch_swin_patchify(int dt, const float* src, int Hs, int Ws, const int* crops, int n, void* out, hipStream_t st);
+int launch_swin_patchify(int dt, const float* src, const float* src_b, int n_a, int Hs, int Ws, const int* crops, int n, void* out,
+                         hipStream_t st);
 int launch_layernorm(int dt, const void* x, const float* gamma, const float* beta, void* y, long long M, int C, hipStream_t st);
 int launch_swin_attn(int dt, const void* qkv, const float* bias_table, void* out, int nimg, int H, int W, int C, int heads,
                      int shift, hipStream_t st);

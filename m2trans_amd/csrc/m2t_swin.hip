@@ -168,7 +168,16 @@ static int swin_gemm(int dt, int emode, const void* A, int K, const void* W, voi
 // (source index, y0, x0) -> emb [n][512] (unit norm, fp32, device)
 extern "C" int m2t_swin_encode(m2t_swin* p, const float* src, int n_src, int Hs, int Ws, const int* crops_host, int n,
                                float* emb, void* workspace, void* stream) {
-  if (!p || !src || !crops_host || !emb || !workspace) return m2t_set_error(M2T_ERR_ARG, "m2t_swin_encode: null");
+  return m2t_swin_encode_pair(p, src, n_src, nullptr, 0, Hs, Ws, crops_host, n, emb, workspace, stream);
+}
+
+// the same with the source images in TWO tensors (indices 0 .. n_a - 1 in src_a, n_a .. n_a + n_b - 1 in src_b): the SR and
+// HR batches of SemanticLoss.batch are encoded in one pass without concatenating them first
+extern "C" int m2t_swin_encode_pair(m2t_swin* p, const float* src, int n_a, const float* src_b, int n_b, int Hs, int Ws,
+                                    const int* crops_host, int n, float* emb, void* workspace, void* stream) {
+  const int n_src = n_a + n_b;
+  if (!p || !src || !crops_host || !emb || !workspace || n_a < 1 || n_b < 0 || (n_b > 0 && !src_b))
+    return m2t_set_error(M2T_ERR_ARG, "m2t_swin_encode: null / bad source counts");
   if (!p->weights) return m2t_set_error(M2T_ERR_STATE, "m2t_swin_encode: call m2t_swin_load_weights first");
   if (n < 1 || n > p->max_images) return m2t_set_error(M2T_ERR_ARG, "m2t_swin_encode: n out of range");
   for (int i = 0; i < n; ++i) {
@@ -185,7 +194,7 @@ extern "C" int m2t_swin_encode(m2t_swin* p, const float* src, int n_src, int Hs,
   if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
   void *X = SWP("X"), *Hn = SWP("Hn"), *QKV = SWP("QKV"), *AO = SWP("AO"), *MH = SWP("MH");
   const float* fbias = (const float*)SWP("fbias");
-  CKS(launch_swin_patchify(dt, src, Hs, Ws, (const int*)SWP("crops"), n, SWP("A0"), st));
+  CKS(launch_swin_patchify(dt, src, src_b, n_a, Hs, Ws, (const int*)SWP("crops"), n, SWP("A0"), st));
   long long M = (long long)n * 3136;
   CKS(swin_gemm(dt, M2T_E_BIAS, SWP("A0"), 48, spk(p, workspace, "pe"), X, 96, M,
                 wt + p->poff.at("embeddings.patch_embeddings.projection.bias"), nullptr, st));

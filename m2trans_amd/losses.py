@@ -98,6 +98,22 @@ class SwinEncoder:
                                                    _lib.ptr(emb), _lib.ptr(self.workspace), _lib.stream_ptr()), "m2t_swin_encode")
         return emb
 
+    def encode_pair(self, src_a: torch.Tensor, src_b: torch.Tensor, crops: Sequence[Sequence[int]]) -> torch.Tensor:
+        """like ``encode`` with the sources in two tensors (index < len(src_a): src_a, else src_b): no concatenation"""
+        if not self.loaded:
+            raise M2TError("SwinEncoder: weights not loaded")
+        src_a, src_b = src_a.contiguous().float(), src_b.contiguous().float()
+        if tuple(src_a.shape[1:]) != tuple(src_b.shape[1:]):
+            raise M2TError("SwinEncoder.encode_pair: the two source tensors must have the same image shape")
+        n = len(crops)
+        arr = (C.c_int * (3 * n))(*[int(v) for c in crops for v in c])
+        emb = torch.empty(n, 512, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().m2t_swin_encode_pair(self.handle, _lib.ptr(src_a), src_a.shape[0], _lib.ptr(src_b), src_b.shape[0],
+                                                        src_a.shape[2], src_a.shape[3], arr, n, _lib.ptr(emb), _lib.ptr(self.workspace),
+                                                        _lib.stream_ptr()), "m2t_swin_encode_pair")
+        return emb
+
     def __del__(self):
         try:
             if self.handle:
@@ -129,6 +145,7 @@ class SemanticLoss(nn.Module):
         self._enc: Optional[SwinEncoder] = None
         self._state: Optional[Dict[str, torch.Tensor]] = None
         self._text: Dict[str, torch.Tensor] = {}
+        self._text_dev = None
 
     # ---- injected constants -----------------------------------------------------------------
     def load_image_encoder(self, state_dict: Dict[str, torch.Tensor]):
@@ -139,6 +156,7 @@ class SemanticLoss(nn.Module):
 
     def set_text_features(self, table: Dict[str, torch.Tensor]):
         self._text.update({k: v.detach().float().reshape(512).cpu() for k, v in table.items()})
+        self._text_dev = None
 
     def _encoder(self) -> SwinEncoder:
         if self.device.type != "cuda":
@@ -159,7 +177,9 @@ class SemanticLoss(nn.Module):
             raise M2TError(f"SemanticLoss: no text feature for caption {caption!r}: inject the MedCLIP text embeddings with "
                            "set_text_features({caption: tensor[512]}) (the text tower is not part of this build), or construct "
                            "SemanticLoss(synthetic_text=True) for a benchmark with stand-in embeddings")
-        return hash_text_feature(caption)
+        t = hash_text_feature(caption)
+        self._text[caption] = t                    # deterministic: computed once per caption
+        return t
 
     # ---- reference semantics ------------------------------------------------------------------
     def createNRandompatches(self, hs: int, ws: int, N: int, patch_size: int = 224):
@@ -186,23 +206,28 @@ class SemanticLoss(nn.Module):
             raise M2TError(f"batch {B} exceeds max_batch {self.max_batch}")
         hs, ws = sr.shape[2], sr.shape[3]
         with torch.no_grad():
-            src = torch.cat((sr.detach().float(), hr.detach().float()), dim=0).contiguous()
             if self.N_patches > 1:
                 last = []
                 for _ in range(B):                                       # same RNG order as B sequential calls
                     last.append(self.createNRandompatches(hs, ws, self.N_patches - 1)[-1])
                 crops = [(i, last[i][0], last[i][1]) for i in range(B)] + [(B + i, last[i][0], last[i][1]) for i in range(B)]
-                emb = enc.encode(src, crops)
+                emb = enc.encode_pair(sr.detach(), hr.detach(), crops)   # SR crops then HR crops, no torch.cat of the batches
             else:
-                small = torch.empty(2 * B, 3, 224, 224, dtype=torch.float32, device=src.device)
-                with torch.cuda.device(src.device):
+                src = torch.cat((sr.detach().float(), hr.detach().float()), dim=0).contiguous()
+                small = torch.empty(2 * B, 3, 224, 224, dtype=torch.float32, device=sr.device)
+                with torch.cuda.device(sr.device):
                     _lib.check(_lib.load().m2t_bicubic_resize(_lib.ptr(src), _lib.ptr(small), 2 * B * 3, hs, ws, 224, 224,
                                                               _lib.stream_ptr()), "m2t_bicubic_resize")
                 emb = enc.encode(small, [(i, 0, 0) for i in range(2 * B)])
-            text = torch.stack([self._text_feature(c) for c in captions]).to(src.device)
-            per = torch.empty(B, dtype=torch.float32, device=src.device)
-            tot = torch.empty(1, dtype=torch.float32, device=src.device)
-            with torch.cuda.device(src.device):
+            dev = sr.device
+            key = tuple(captions)
+            if self._text_dev is None or self._text_dev[0] != key or self._text_dev[1].device != dev:
+                # the text features are constants of the frozen model: one upload per distinct caption list
+                self._text_dev = (key, torch.stack([self._text_feature(c) for c in captions]).to(dev))
+            text = self._text_dev[1]
+            per = torch.empty(B, dtype=torch.float32, device=dev)
+            tot = torch.empty(1, dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
                 _lib.check(_lib.load().m2t_semantic_loss(_lib.ptr(emb), _lib.ptr(text), B, self.N_patches, _lib.ptr(per),
                                                          _lib.ptr(tot), _lib.stream_ptr()), "m2t_semantic_loss")
         self.last_per_sample = per
