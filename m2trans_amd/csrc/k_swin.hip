@@ -394,3 +394,192 @@ int launch_convert(int dt, const float* src, void* dst, long long n, hipStream_t
   M2T_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// Fused Swin MLP of stages 1 / 2 (bf16):  x <- x + fc2(gelu(fc1(LayerNorm(x)) + b1)) + b2      (modeling_swin: layernorm_after,
+// intermediate.dense + GELU, output.dense, residual) for 64 token rows per workgroup.
+// Unfused the 4C-wide hidden tensor goes through HBM twice (154 MB per layer at stage 1, batch 64) and the LayerNorm is a
+// pass of its own: 23 + 70 + 60 us per layer.  Here the normalised rows (64 x C) and the hidden tile (64 x 4C, 50 / 99 KB)
+// live in LDS; W1 / W2 arrive as pre-packed MFMA A-fragments (FRAG16 order) straight from L2, every fragment is loaded
+// by exactly one wave and reused over the four 16-row tiles.  Six waves: wave w owns 4C/96 channel tiles of fc1 and C/96 of
+// fc2 (C = 96: 4 and 1; C = 192: 8 and 2), so both products are balanced.
+// ---------------------------------------------------------------------------------------
+template <int C> struct MlpCfg {
+  static constexpr int H4 = 4 * C, LDX = C + 8, LDH = H4 + 8;
+  static constexpr int NCT1 = H4 / 16 / 6, NCT2 = C / 16 / 6, KS1 = C / 32, KS2 = H4 / 32;
+  static constexpr size_t szX = sizeof(bf16_t) * 64 * LDX, szH = sizeof(bf16_t) * 64 * LDH, total = szX + szH;
+  static_assert(C % 96 == 0, "six waves split the channel tiles of both products evenly for C = 96 k");
+};
+template <int C>
+__global__ void __launch_bounds__(384) swin_mlp_fused_kernel(bf16_t* __restrict__ X, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const bf16_t* __restrict__ w1f,
+                                                             const float* __restrict__ b1, const bf16_t* __restrict__ w2f,
+                                                             const float* __restrict__ b2, long long M) {
+  using T = bf16_t;
+  using Cfg = MlpCfg<C>;
+  constexpr int LDX = Cfg::LDX, LDH = Cfg::LDH, NCT1 = Cfg::NCT1, NCT2 = Cfg::NCT2, KS1 = Cfg::KS1, KS2 = Cfg::KS2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T(*Hn)[LDX] = reinterpret_cast<T(*)[LDX]>(smem);
+  T(*Hd)[LDH] = reinterpret_cast<T(*)[LDH]>(smem + Cfg::szX);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const long long m0 = (long long)blockIdx.x * 64;
+  // ---- the first fragments of W1 are on their way while the rows are normalised ----
+  Frag8<T> wa[NCT1];
+#pragma unroll
+  for (int c = 0; c < NCT1; ++c) wa[c] = load8(w1f + (((long long)(wv * NCT1 + c) * KS1 + 0) * 64 + lane) * 8);
+  // ---- LayerNorm: 4 lanes per row (threads 0..255), each C/4 channels as 16-byte vectors; fp32 two-pass ----
+  if (tid < 256) {
+    constexpr int NV = C / 32;                      // vectors per lane
+    const int row = tid >> 2, part = tid & 3;
+    const long long m = min(m0 + row, M - 1);
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      load8f(X + m * C + (part + 4 * i) * 8, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    const float mean = s * (1.0f / (float)C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; q += d * d; }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / (float)C) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c0 = (part + 4 * i) * 8;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
+      store8f(&Hn[row][c0], o);
+    }
+  }
+  __syncthreads();
+  // ---- hidden^T = W1 Hn^T: wave wv owns channel tiles wv*NCT1 .. ; all four row tiles ----
+  {
+    f32x4 acc[NCT1][4];
+#pragma unroll
+    for (int c = 0; c < NCT1; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[c][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      Frag8<T> a[NCT1];
+#pragma unroll
+      for (int c = 0; c < NCT1; ++c) a[c] = wa[c];
+      if (ks + 1 < KS1) {
+#pragma unroll
+        for (int c = 0; c < NCT1; ++c) wa[c] = load8(w1f + (((long long)(wv * NCT1 + c) * KS1 + ks + 1) * 64 + lane) * 8);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const Frag8<T> bfr = load8(&Hn[16 * r + lr][32 * ks + 8 * g]);
+#pragma unroll
+        for (int c = 0; c < NCT1; ++c) mma16(acc[c][r], a[c], bfr);
+      }
+    }
+    // lane (row 16 r + lr, g) holds hidden channels 16 ct + 4 g .. + 3
+#pragma unroll
+    for (int c = 0; c < NCT1; ++c) {
+      const int ch = 16 * (wv * NCT1 + c) + 4 * g;
+      const float bb[4] = {b1[ch], b1[ch + 1], b1[ch + 2], b1[ch + 3]};     // (parameter offsets are not 16-byte aligned)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gelu_erf(acc[c][r][e] + bb[e]);
+        store4(&Hd[16 * r + lr][ch], o);
+      }
+    }
+  }
+  // ---- y^T = W2 hidden^T: wave wv owns channel tiles wv*NCT2 .. ; W2 fragments through a 4-deep ring ----
+  constexpr int DEPTH = 4;
+  Frag8<T> wb[NCT2][DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+    for (int c = 0; c < NCT2; ++c) wb[c][d] = load8(w2f + (((long long)(wv * NCT2 + c) * KS2 + d) * 64 + lane) * 8);
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  f32x4 acc2[NCT2][4];
+#pragma unroll
+  for (int c = 0; c < NCT2; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc2[c][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS2; ++ks) {
+    Frag8<T> a[NCT2];
+#pragma unroll
+    for (int c = 0; c < NCT2; ++c) a[c] = wb[c][ks % DEPTH];
+    if (ks + DEPTH < KS2) {
+#pragma unroll
+      for (int c = 0; c < NCT2; ++c) wb[c][ks % DEPTH] = load8(w2f + (((long long)(wv * NCT2 + c) * KS2 + ks + DEPTH) * 64 + lane) * 8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const Frag8<T> bfr = load8(&Hd[16 * r + lr][32 * ks + 8 * g]);
+#pragma unroll
+      for (int c = 0; c < NCT2; ++c) mma16(acc2[c][r], a[c], bfr);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NCT2; ++c) {
+    const int ch = 16 * (wv * NCT2 + c) + 4 * g;
+    const float bb[4] = {b2[ch], b2[ch + 1], b2[ch + 2], b2[ch + 3]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long long m = m0 + 16 * r + lr;
+      if (m < M) {
+        float p[4], o[4];
+        load4(X + m * C + ch, p);                 // the residual: the un-normalised input row (read-modify-write by one lane)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc2[c][r][e] + bb[e] + p[e];
+        store4(X + m * C + ch, o);
+      }
+    }
+  }
+}
+// src [N][K] fp32 -> MFMA A-fragment order [N/16][K/32][64 lanes][8] (see M2T_PACK_FRAG16)
+template <typename T>
+__global__ void __launch_bounds__(256) frag16_pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int K) {
+  const long long total = (long long)N * K;
+  const int nks = K >> 5;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(e & 7), l = (int)((e >> 3) & 63);
+    const long long f = e >> 9;
+    const int ks = (int)(f % nks), tile = (int)(f / nks);
+    dst[e] = from_f<T>(src[(long long)(16 * tile + (l & 15)) * K + 32 * ks + 8 * (l >> 4) + j]);
+  }
+}
+int launch_frag16_pack(int dt, const float* src, void* dst, int N, int K, hipStream_t st) {
+  if (N % 16 || K % 32) return m2t_set_error(-2, "frag16_pack: N must be a multiple of 16 and K of 32");
+  const int g = (int)std::min<long long>(ceil_divll((long long)N * K, 256), 2048);
+  if (dt == M2T_F32) hipLaunchKernelGGL(frag16_pack_kernel<float>, dim3(g), dim3(256), 0, st, src, (float*)dst, N, K);
+  else hipLaunchKernelGGL(frag16_pack_kernel<bf16_t>, dim3(g), dim3(256), 0, st, src, (bf16_t*)dst, N, K);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+// bf16, C = 96 / 192: X [M][C] updated in place; w1f / w2f = fc1 [4C][C] / fc2 [C][4C] weights in FRAG16 order
+int launch_swin_mlp_fused(void* X, const float* gamma, const float* beta, const void* w1f, const float* b1, const void* w2f,
+                          const float* b2, long long M, int C, hipStream_t st) {
+  const unsigned nblk = (unsigned)ceil_divll(M, 64);
+  if (C == 96) {
+    if (int rc__ = m2t_ensure_dynamic_lds((const void*)swin_mlp_fused_kernel<96>, (int)MlpCfg<96>::total)) return rc__;
+    hipLaunchKernelGGL(swin_mlp_fused_kernel<96>, dim3(nblk), dim3(384), MlpCfg<96>::total, st, (bf16_t*)X, gamma, beta, (const bf16_t*)w1f,
+                       b1, (const bf16_t*)w2f, b2, M);
+  } else if (C == 192) {
+    if (int rc__ = m2t_ensure_dynamic_lds((const void*)swin_mlp_fused_kernel<192>, (int)MlpCfg<192>::total)) return rc__;
+    hipLaunchKernelGGL(swin_mlp_fused_kernel<192>, dim3(nblk), dim3(384), MlpCfg<192>::total, st, (bf16_t*)X, gamma, beta, (const bf16_t*)w1f,
+                       b1, (const bf16_t*)w2f, b2, M);
+  } else {
+    return m2t_set_error(-2, "swin_mlp_fused: C must be 96 or 192");
+  }
+  M2T_LAUNCH_CHECK();
+  return 0;
+}

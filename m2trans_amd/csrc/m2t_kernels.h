@@ -213,6 +213,10 @@ int launch_rel_reduce1_multi(const m2t_rel_desc4& a, int n, hipStream_t st);
 int launch_swin_patchify(int dt, const float* src, const float* src_b, int n_a, int Hs, int Ws, const int* crops, int n, void* out,
                          hipStream_t st);
 int launch_layernorm(int dt, const void* x, const float* gamma, const float* beta, void* y, long long M, int C, hipStream_t st);
+// fused Swin MLP (bf16, C = 96 / 192): X <- X + fc2(gelu(fc1(LayerNorm(X)) + b1)) + b2, weights in FRAG16 order
+int launch_swin_mlp_fused(void* X, const float* gamma, const float* beta, const void* w1f, const float* b1, const void* w2f,
+                          const float* b2, long long M, int C, hipStream_t st);
+int launch_frag16_pack(int dt, const float* src, void* dst, int N, int K, hipStream_t st);
 int launch_swin_attn(int dt, const void* qkv, const float* bias_table, void* out, int nimg, int H, int W, int C, int heads,
                      int shift, hipStream_t st);
 int launch_swin_merge_gather(int dt, const void* x, void* y, int nimg, int H, int W, int C, hipStream_t st);

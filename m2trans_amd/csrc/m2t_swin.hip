@@ -27,6 +27,7 @@ struct m2t_swin {
   std::map<std::string, Ws> ws;
   size_t ws_bytes = 0;
   const float* weights = nullptr;          // caller's flat fp32 weights (device), set by load_weights
+  bool fused_mlp = true;                   // bf16, stages 1 / 2: LayerNorm + fc1 + GELU + fc2 + residual in one kernel (k_swin.hip)
   void add_param(const std::string& n, long long c) { pnames.push_back(n); poff[n] = nparams; pnum[n] = c; nparams += c; }
   void add_pack(const std::string& n, long long c) { npacked = (npacked + 7) & ~7LL; pk[n] = npacked; npacked += c; }
   void add_ws(const std::string& n, size_t elems, size_t es) {
@@ -69,6 +70,7 @@ extern "C" int m2t_swin_create(m2t_swin** out, int max_images, int dtype) {
       p->add_pack(b + "o", C * C);
       p->add_pack(b + "fc1", 4 * C * C);
       p->add_pack(b + "fc2", 4 * C * C);
+      if (s < 2) { p->add_pack(b + "fc1F", 4 * C * C); p->add_pack(b + "fc2F", 4 * C * C); }   // MFMA fragment order: fused MLP of stages 1 / 2
       p->fb[b + "qkv_bias"] = p->nfb; p->nfb += 3 * C;
     }
     if (s < 3) {
@@ -147,6 +149,10 @@ extern "C" int m2t_swin_load_weights(m2t_swin* p, const float* weights, void* wo
       CKS(launch_convert(dt, weights + p->poff.at(b + "attention.output.dense.weight"), spk(p, workspace, b + "o"), C * C, st));
       CKS(launch_convert(dt, weights + p->poff.at(b + "intermediate.dense.weight"), spk(p, workspace, b + "fc1"), 4 * C * C, st));
       CKS(launch_convert(dt, weights + p->poff.at(b + "output.dense.weight"), spk(p, workspace, b + "fc2"), 4 * C * C, st));
+      if (s < 2) {
+        CKS(launch_frag16_pack(dt, weights + p->poff.at(b + "intermediate.dense.weight"), spk(p, workspace, b + "fc1F"), (int)(4 * C), (int)C, st));
+        CKS(launch_frag16_pack(dt, weights + p->poff.at(b + "output.dense.weight"), spk(p, workspace, b + "fc2F"), (int)C, (int)(4 * C), st));
+      }
     }
     if (s < 3) {
       const std::string d = "encoder.layers." + std::to_string(s) + ".downsample.";
@@ -209,6 +215,13 @@ extern "C" int m2t_swin_encode_pair(m2t_swin* p, const float* src, int n_a, cons
       CKS(swin_gemm(dt, M2T_E_BIAS, Hn, C, spk(p, workspace, b + "qkv"), QKV, 3 * C, M, fbias + p->fb.at(b + "qkv_bias"), nullptr, st));
       CKS(launch_swin_attn(dt, QKV, wt + p->poff.at(b + "attention.self.relative_position_bias_table"), AO, n, H, H, C, HEADS[s], shift, st));
       CKS(swin_gemm(dt, M2T_E_BIAS_RESID, AO, C, spk(p, workspace, b + "o"), X, C, M, wt + p->poff.at(b + "attention.output.dense.bias"), X, st));
+      if (dt != M2T_F32 && s < 2 && p->fused_mlp) {
+        // LayerNorm + fc1 + GELU + fc2 + residual in one kernel: the 4C-wide hidden tensor stays in LDS
+        CKS(launch_swin_mlp_fused(X, wt + p->poff.at(b + "layernorm_after.weight"), wt + p->poff.at(b + "layernorm_after.bias"),
+                                  spk(p, workspace, b + "fc1F"), wt + p->poff.at(b + "intermediate.dense.bias"), spk(p, workspace, b + "fc2F"),
+                                  wt + p->poff.at(b + "output.dense.bias"), M, C, st));
+        continue;
+      }
       CKS(launch_layernorm(dt, X, wt + p->poff.at(b + "layernorm_after.weight"), wt + p->poff.at(b + "layernorm_after.bias"), Hn, M, C, st));
       CKS(swin_gemm(dt, M2T_E_BIAS_GELU, Hn, C, spk(p, workspace, b + "fc1"), MH, 4 * C, M, wt + p->poff.at(b + "intermediate.dense.bias"), nullptr, st));
       CKS(swin_gemm(dt, M2T_E_BIAS_RESID, MH, 4 * C, spk(p, workspace, b + "fc2"), X, C, M, wt + p->poff.at(b + "output.dense.bias"), X, st));
