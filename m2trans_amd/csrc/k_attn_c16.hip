@@ -396,16 +396,22 @@ __global__ void __launch_bounds__(256, 4) window_attn_fwd_c16_kernel(const bf16_
 // window's own pixels are still written: the backward pass reads them.  Out-of-image halo keys are the zero padding of
 // the normalised map (x^ = 0 -> k = v = 0, key = rel-pos alone).
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 3) window_attn_fused_c16_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
+__global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                                            const float* __restrict__ rstd, const bf16_t* __restrict__ wqkv,
                                                                            const float* __restrict__ rel_h, const float* __restrict__ rel_w,
                                                                            bf16_t* __restrict__ d, bf16_t* __restrict__ qkv,
                                                                            bf16_t* __restrict__ out, int ldo, int oc0, int h, int w, int nwin) {
   __shared__ __attribute__((aligned(16))) bf16_t VsAll[4][112][16];
+  // q and the normalised query rows (the residual) wait in wave-private LDS for the rolled query-tile loop: holding them
+  // in registers across an unrolled loop costs 24 B/lane of scratch at four workgroups per CU (4096 windows = ONE round)
+  __shared__ __attribute__((aligned(16))) bf16_t QsAll[4][64][16];
+  __shared__ __attribute__((aligned(16))) bf16_t XrAll[4][64][16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wi = xcd_block_index() * 4 + wv;
   if (wi >= nwin) return;
   bf16_t(*Vs)[16] = VsAll[wv];
+  bf16_t(*Qs)[16] = QsAll[wv];
+  bf16_t(*Xr)[16] = XrAll[wv];
   const int lr = lane & 15, g = lane >> 4;
   const int nw = w / 8, nh = h / 8;
   const int wx = wi % nw, wy = (wi / nw) % nh, b = wi / (nw * nh);
@@ -439,17 +445,18 @@ __global__ void __launch_bounds__(256, 3) window_attn_fused_c16_fwd_kernel(const
   auto normalise = [&](bf16x4 v) {
     return pack4(((float)v[0] - mu[0]) * rs[0], ((float)v[1] - mu[1]) * rs[1], ((float)v[2] - mu[2]) * rs[2], ((float)v[3] - mu[3]) * rs[3]);
   };
-  bf16x4 qraw[4];
 #pragma unroll
   for (int qt = 0; qt < 4; ++qt) {
     const int q = 16 * qt + lr;
     const long long qpix = img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
-    xq[qt] = normalise(xq[qt]);
-    st4(d + qpix * C16 + 4 * g, xq[qt]);
+    const bf16x4 xn = normalise(xq[qt]);
+    st4(d + qpix * C16 + 4 * g, xn);
+    st4(&Xr[q][4 * g], xn);
     f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mma4(a, wA[0], xq[qt]);
-    qraw[qt] = pack4(a[0], a[1], a[2], a[3]);
-    st4(qkv + qpix * (3 * C16) + 4 * g, qraw[qt]);
+    mma4(a, wA[0], xn);
+    const bf16x4 qr = pack4(a[0], a[1], a[2], a[3]);
+    st4(qkv + qpix * (3 * C16) + 4 * g, qr);
+    st4(&Qs[q][4 * g], qr);
   }
   bf16x4 kA[WA_KT];
 #pragma unroll
@@ -475,11 +482,11 @@ __global__ void __launch_bounds__(256, 3) window_attn_fused_c16_fwd_kernel(const
 #pragma unroll
   for (int t = 0; t < WA_KT; ++t) vT[t] = tr4(&Vs[16 * t + 4 * g + (lr >> 2)][4 * (lr & 3)]);
   const f32x4 L2E = (f32x4){1.4426950408889634f, 1.4426950408889634f, 1.4426950408889634f, 1.4426950408889634f};
-#pragma unroll
+#pragma unroll 1
   for (int qt = 0; qt < 4; ++qt) {
     const int q = 16 * qt + lr;
     const long long qpix = img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
-    const bf16x4 qv = qraw[qt];
+    const bf16x4 qv = ld4(&Qs[q][4 * g]);
     const bf16x4 qB = pack4(0.25f * (float)qv[0], 0.25f * (float)qv[1], 0.25f * (float)qv[2], 0.25f * (float)qv[3]);   // C^-1/2, exact
     f32x4 s[WA_KT];
 #pragma unroll
@@ -516,7 +523,7 @@ __global__ void __launch_bounds__(256, 3) window_attn_fused_c16_fwd_kernel(const
       const f32x4 pv = s[t] * INV;
       mma4(o, vT[t], pack4(pv[0], pv[1], pv[2], pv[3]));
     }
-    const bf16x4 rv = xq[qt];                                  // residual = the normalised input itself (:139)
+    const bf16x4 rv = ld4(&Xr[q][4 * g]);                      // residual = the normalised input itself (:139)
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] += (float)rv[r];
     st4(out + qpix * ldo + oc0 + 4 * g, pack4(o[0], o[1], o[2], o[3]));
