@@ -7,6 +7,8 @@ O=gpurun_out/r02p
 mkdir -p $O
 timeout 1700 python -m pytest tests -q -m gpu --durations=12 2>&1 | tail -60 > $O/pytest.log
 tail -8 $O/pytest.log
+# HBM traffic counters first: bench.py then finds profiles/pmc_traffic.json with this build's stamp and reports roofline.traffic
+timeout 1200 python tools/pmc_traffic.py > $O/pmc_traffic.log 2>&1; cp profiles/pmc_traffic.json $O/pmc_traffic.json; tail -16 $O/pmc_traffic.log
 for c in 1 2 3 4; do
   extra="--no-cpu-baseline"; [ $c = 1 ] && extra=""
   timeout 600 python bench.py --config $c $extra > $O/bench_c$c.json 2> $O/bench_c$c.err
@@ -25,5 +27,4 @@ prof c1_single --config 1 --steps 5 --warmup 2 --no-kernel-events --no-side-stre
 prof c2_default --config 2 --steps 5 --warmup 2 --no-kernel-events
 prof c4_default --config 4 --steps 5 --warmup 2 --no-kernel-events
 timeout 900 python tools/pmc_sq.py > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq.txt $O/pmc_sq.txt; head -12 $O/pmc_sq.txt | cut -c1-260
-timeout 1200 python tools/pmc_traffic.py > $O/pmc_traffic.log 2>&1; cp profiles/pmc_traffic.json $O/pmc_traffic.json; tail -30 $O/pmc_traffic.log
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 tools/dp2_check.py 2>&1 | tail -3 | tee $O/dp2.log
