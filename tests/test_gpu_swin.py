@@ -107,3 +107,9 @@ def test_train_step_with_semantic_loss_term_is_constant_offset():
     assert torch.equal(ts1.grads, g0)
     assert abs((l1 - l0) - 0.01 * float(sl.last_per_sample.sum())) < 1e-6
     assert float(sl.last_per_sample.min()) >= 0.0
+    # the encoder beside the backward pass (default) and after it give the same values, bit for bit
+    per_overlapped = sl.last_per_sample.clone()
+    ts2 = TrainStep(model, world_size=1, semantic_loss=sl, lambda_clip=0.01, overlap_semantic=False)
+    torch.manual_seed(1)
+    l2 = float(ts2.forward_backward(x, hr, ["a", "b"]))
+    assert l2 == l1 and torch.equal(sl.last_per_sample, per_overlapped) and torch.equal(ts2.grads, g0)
