@@ -76,6 +76,9 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           backward kernel (k_attn_res.hip): the window multiplies its own dq | dK | dV rows by Wqkv^T, the
  *                           overlap-add over neighbouring windows moves to the C-wide product.  Removes the halo gather and
  *                           the GEMM launch from the main chain (+2.3 % at batch 16, neutral at batch 32)
+ *   "wgrad_big_tiles"   [-1] qkv weight gradient of the C = 256 branches with 128 x 128 output tiles (half the L2 re-reads of the 64 x 64
+ *                           kernel): value = target number of workgroups (64..512), 0 = off, -1 = auto (256 when the branch has
+ *                           >= 24 576 pixels, i.e. from batch 24 on: +1.1 % at batch 32, -0.7 % at batch 16)
  *   "merged_rel_reduce" [0] first stage of the rel-pos gradient reduction for a block's four branches in one launch instead of four
  *                           (bit-identical; 0.7 % / 1.8 % slower at batch 16 / 32: the merged launch sits at the end of the block's
  *                           side work and meets the next block's conv data gradient)

@@ -586,10 +586,102 @@ wgrad_tn_fast_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ X, 
     for (int r = 0; r < 4; ++r) out[(long long)(n0 + 16 * wv + 4 * g + r) * K + k0 + 16 * kt + lr] = acc[kt][r];
 }
 
+// ---------------------------------------------------------------------------------------
+// 128 x 128 output tiles, 8 waves (wave (wn, wk) = 32 rows n x 64 columns k): the 64 x 64 kernel above re-reads G K/64 times
+// and X N/64 times from L2 (C = 256 qkv: 200 MB of L2 traffic per launch for 33.5 MB of operands, 2.5 transposing LDS
+// reads per MFMA) and is bound by exactly that; this one halves both and needs 1.5 LDS reads per MFMA.  Same stage
+// structure (128 rows, two register sets of prefetch); N % 128 == 0, K % 128 == 0.
+// ---------------------------------------------------------------------------------------
+#define WGB_LD 136
+template <typename T>
+__global__ void __launch_bounds__(512)
+wgrad_tn_big_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ X, int ldx, float* __restrict__ slabs, long long M,
+                    int N, int K, long long rows_per_slab) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  T(*Gs)[WGB_LD] = reinterpret_cast<T(*)[WGB_LD]>(smem);
+  T(*Xs)[WGB_LD] = reinterpret_cast<T(*)[WGB_LD]>(smem + sizeof(T) * WG_BM * WGB_LD);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 15, g = lane >> 4;
+  const int wn = wv & 3, wk = wv >> 2;
+  const int tn = N / 128, tk = K / 128;
+  const int L = xcd_block_index();
+  const int slab = L / (tn * tk), rem = L - slab * (tn * tk);
+  const int n0 = (rem % tn) * 128, k0 = (rem / tn) * 128;
+  const long long mb = (long long)slab * rows_per_slab;
+  const int nst = (int)((min(M, mb + rows_per_slab) - mb) / WG_BM);
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // thread's four (row, vector) slots of a stage: row = (tid >> 4) + 32 it, vector = tid & 15 (16 x 8 = 128 columns)
+  const T* pg = G + (mb + (tid >> 4)) * ldg + n0 + (tid & 15) * 8;
+  const T* px = X + (mb + (tid >> 4)) * ldx + k0 + (tid & 15) * 8;
+  const long long sg32 = 32LL * ldg, sx32 = 32LL * ldx;
+  Frag8<T> rg[2][4], rx[2][4];
+  auto fetch = [&](int set, int st) {
+    const T* qg = pg + (long long)st * WG_BM * ldg;
+    const T* qx = px + (long long)st * WG_BM * ldx;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      rg[set][it] = load8(qg + it * sg32);
+      rx[set][it] = load8(qx + it * sx32);
+    }
+  };
+  fetch(0, 0);
+  if (nst > 1) fetch(1, 1);
+  for (int sb = 0; sb < nst; sb += 2) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int st = sb + j;
+      if (st < nst) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          store8(&Gs[(tid >> 4) + 32 * it][(tid & 15) * 8], rg[j][it]);
+          store8(&Xs[(tid >> 4) + 32 * it][(tid & 15) * 8], rx[j][it]);
+        }
+        __syncthreads();
+        if (st + 2 < nst) fetch(j, st + 2);
+#pragma unroll
+        for (int ch = 0; ch < WG_BM / 32; ++ch) {
+          Frag8<T> gf[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            gf[i] = load8_tr(&Gs[32 * ch + 8 * g][32 * wn + 16 * i], &Gs[32 * ch + 8 * g + 4][32 * wn + 16 * i], WGB_LD, lane);
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            const Frag8<T> xf = load8_tr(&Xs[32 * ch + 8 * g][64 * wk + 16 * kt], &Xs[32 * ch + 8 * g + 4][64 * wk + 16 * kt], WGB_LD, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mma16(acc[i][kt], gf[i], xf);
+          }
+        }
+      }
+    }
+  }
+  float* out = slabs + (long long)slab * N * K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(long long)(n0 + 32 * wn + 16 * i + 4 * g + r) * K + k0 + 64 * wk + 16 * kt + lr] = acc[i][kt][r];
+}
+static bool wgrad_big_ok(long long M, int N, int K) { return N % 128 == 0 && K % 128 == 0 && M % WG_BM == 0 && N * (long long)K >= 128 * 256; }
+static int wgrad_big_slabs(long long M, int N, int K, int target = 256) {
+  // ~256 workgroups of 512 threads (two fit on a CU): enough to keep the MFMAs of the used CUs busy, few enough that the
+  // slab partials (slabs x N x K fp32, written here and read once more by the deferred reduction) stay below the operands
+  const long long want = std::max<long long>(1, target / ((N / 128) * (K / 128)));
+  return (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want, ceil_divll(M, WG_BM)));
+}
+
 int wgrad_slab_count(long long M, int N, int K) {
   const int tn = ceil_div(N, 64), tk = ceil_div(K, 64);
   const long long want = std::max<long long>(1, 512 / (tn * tk));
-  return (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want, ceil_divll(M, WG_BM)));
+  int n = (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want, ceil_divll(M, WG_BM)));
+  if (wgrad_big_ok(M, N, K)) n = std::max(n, wgrad_big_slabs(M, N, K, 512));     // upper bound over the selectable targets
+  return n;
 }
 
 template <typename T>
@@ -597,7 +689,23 @@ static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_
   if (a.K % 8 || a.N % 8) return m2t_set_error(-2, "wgrad_tn: N,K must be multiples of 8");
   const int tn = ceil_div(a.N, 64), tk = ceil_div(a.K, 64);
   // enough slabs for ~2 workgroups per CU (more slabs only inflate the deferred reduction); rows per slab a multiple of the 128-row step
-  int nslab = wgrad_slab_count(a.M, a.N, a.K);
+  if constexpr (sizeof(T) == 2) {
+  if (a.big_tiles && a.gmode == M2T_A_PLAIN && a.xmode == M2T_A_PLAIN && !a.bias_slabs && a.ldg > 0 && a.ldx > 0 &&
+      wgrad_big_ok(a.M, a.N, a.K)) {
+    int nb = wgrad_big_slabs(a.M, a.N, a.K, std::min(std::max(a.big_tiles, 64), 512));
+    const long long rpb = ceil_divll(ceil_divll(a.M, nb), WG_BM) * WG_BM;
+    nb = (int)ceil_divll(a.M, rpb);
+    const size_t sh = sizeof(T) * 2 * WG_BM * WGB_LD;
+    if (int rc__ = m2t_ensure_dynamic_lds((const void*)wgrad_tn_big_kernel<T>, (int)sh)) return rc__;
+    hipLaunchKernelGGL((wgrad_tn_big_kernel<T>), dim3((a.N / 128) * (a.K / 128) * nb), dim3(512), sh, st, (const T*)a.G, a.ldg, (const T*)a.X,
+                       a.ldx, a.slabs, a.M, a.N, a.K, rpb);
+    M2T_LAUNCH_CHECK();
+    *nslab_out = nb;
+    return 0;
+  }
+  }
+  const long long want64 = std::max<long long>(1, 512 / (tn * tk));
+  int nslab = (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want64, ceil_divll(a.M, WG_BM)));
   long long rps = ceil_divll(ceil_divll(a.M, nslab), WG_BM) * WG_BM;
   nslab = (int)ceil_divll(a.M, rps);
   if (sizeof(T) == 2 && a.gmode == M2T_A_PLAIN && a.xmode == M2T_A_PLAIN && !a.bias_slabs && a.ldg > 0 && a.ldx > 0 &&

@@ -133,6 +133,8 @@ struct m2t_plan {
                                        // bit-identical; same-box A/B 5.73 vs 5.69 ms per step, i.e. no gain: kept as an option)
   int norm_single_stage = 0;           // InstanceNorm reductions: bit 0 / bit 1 = forward statistics / backward sums by one workgroup per (image, chunk)
   bool fused_dgrad_gather_in_prep = true;   // ring rows of the fused data gradient added by branch_prep_bwd on load (0: separate gather launch)
+  int wgrad_big_tiles = -1;            // C = 256 qkv weight gradient: 128 x 128 output tiles instead of 64 x 64 (k_gemm.hip); value = target
+                                       // workgroups, 0 = off, -1 = auto: 256 from 24 576 rows on (batch 32: 9.82 vs 9.93 ms; batch 16: 5.53 vs 5.49)
   bool merged_rel_reduce = false;      // the rel-pos partial reductions of a block's four branches in one launch: measured SLOWER (5.48 vs 5.44 ms; batch 32: 10.03 vs 9.85)
   bool use_fused_c16_dgrad = false;    // ... and inside the wave-per-window C = 16 backward kernel (k_attn_c16.hip): a tie at batch 16, -0.3 % at batch 32
   bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside the attention backward kernel (k_attn_res.hip)
@@ -721,6 +723,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       m2t_wgrad_args wa{};
       wa.G = gqkv_buf[i]; wa.ldg = 3 * C; wa.gmode = M2T_A_PLAIN; wa.X = WSP(k + "d" + std::to_string(i + 1)); wa.ldx = C; wa.xmode = M2T_A_PLAIN;
       wa.slabs = slabs; wa.M = M; wa.N = 3 * C; wa.K = C; wa.H = h; wa.Wd = w; wa.r = 1; wa.C = C; wa.halo_win = win_buf[i];
+      wa.big_tiles = p->wgrad_big_tiles >= 0 ? p->wgrad_big_tiles : (M >= 24576 ? 256 : 0);
       { M2TProfScope ps(M2T_PROF_WGRAD_QKV, sd); CK(launch_wgrad_tn(dt, wa, &ns, sd)); }
       defer(slabs, p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0);
       ARENA(relp, (size_t)32 * 10 * C);
@@ -876,6 +879,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
   if (std::string(key) == "norm_single_stage") { p->norm_single_stage = (int)value; return 0; }
   if (std::string(key) == "dgrad_gather_in_prep") { p->fused_dgrad_gather_in_prep = (value != 0); return 0; }
+  if (std::string(key) == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
   if (std::string(key) == "merged_rel_reduce") { p->merged_rel_reduce = (value != 0); return 0; }
   if (std::string(key) == "fused_c16_dgrad") { p->use_fused_c16_dgrad = (value != 0); return 0; }
   if (std::string(key) == "fused_qkv_dgrad") { p->use_fused_qkv_dgrad = (value != 0); return 0; }

@@ -116,6 +116,8 @@ struct m2t_wgrad_args {
   long long M; int N, K;
   int H, Wd, r, C;
   const void* halo_win = nullptr;
+  int big_tiles = 0;                   // > 0: bf16 plain / plain, N % 128 == 0, K % 128 == 0: 128 x 128 output tiles (wgrad_tn_big_kernel),
+                                       // value = target number of workgroups (tiles x slabs), 64 .. 512
 };
 int launch_wgrad_tn(int dt, const m2t_wgrad_args& a, int* nslab_out, hipStream_t st);
 int wgrad_slab_count(long long M, int N, int K);   // upper bound of the slabs launch_wgrad_tn will write
