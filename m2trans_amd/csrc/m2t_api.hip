@@ -133,6 +133,7 @@ struct m2t_plan {
                                        // bit-identical; same-box A/B 5.73 vs 5.69 ms per step, i.e. no gain: kept as an option)
   int norm_single_stage = 0;           // InstanceNorm reductions: bit 0 / bit 1 = forward statistics / backward sums by one workgroup per (image, chunk)
   bool fused_dgrad_gather_in_prep = true;   // ring rows of the fused data gradient added by branch_prep_bwd on load (0: separate gather launch)
+  bool last_block_conv_first = false;  // see the gate in m2t_backward (measured: 5.51 vs 5.48 ms, neutral at batch 32)
   int wgrad_big_tiles = -1;            // C = 256 qkv weight gradient: 128 x 128 output tiles instead of 64 x 64 (k_gemm.hip); value = target
                                        // workgroups, 0 = off, -1 = auto: 256 from 24 576 rows on (batch 32: 9.82 vs 9.93 ms; batch 16: 5.53 vs 5.49)
   bool merged_rel_reduce = false;      // the rel-pos partial reductions of a block's four branches in one launch: measured SLOWER (5.48 vs 5.44 ms; batch 32: 10.03 vs 9.85)
@@ -783,17 +784,20 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         branch_done[i] = side_marker();
       } else if (i == gate) {
         fork();                              // the gate: the LDS-hungry attention kernels of this block are on their way
-        if (p->side_conv_pos == 0) { CK(side_conv()); conv_done = side_marker(); }
+        // the LAST block processed (b == 0) has no next block to collide with: its conv weight gradient goes first, so the
+        // side stream's lag behind the main chain (fully exposed at the end of the step) is that much shorter
+        const int conv_pos = (b == 0 && p->last_block_conv_first) ? 0 : p->side_conv_pos;
+        if (conv_pos == 0) { CK(side_conv()); conv_done = side_marker(); }
         for (int j = 3; j >= gate; --j) {
           CK(side_branch(j));
           branch_done[j] = side_marker();
         }
-        if (p->side_conv_pos == 1 || (p->side_conv_pos == 2 && gate == 0)) { CK(side_conv()); conv_done = side_marker(); }
+        if (conv_pos == 1 || (conv_pos == 2 && gate == 0)) { CK(side_conv()); conv_done = side_marker(); }
       } else if (i < gate) {
         fork();
         CK(side_branch(i));
         branch_done[i] = side_marker();
-        if (p->side_conv_pos == 2 && i == 0) { CK(side_conv()); conv_done = side_marker(); }
+        if (p->side_conv_pos == 2 && i == 0 && !(b == 0 && p->last_block_conv_first)) { CK(side_conv()); conv_done = side_marker(); }
       }
       if (fused_dgrad(i)) {
         // own-window products are in gd; add the ring rows of the (<= 3) neighbouring windows to the border pixels
@@ -879,6 +883,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
   if (std::string(key) == "norm_single_stage") { p->norm_single_stage = (int)value; return 0; }
   if (std::string(key) == "dgrad_gather_in_prep") { p->fused_dgrad_gather_in_prep = (value != 0); return 0; }
+  if (std::string(key) == "last_block_conv_first") { p->last_block_conv_first = (value != 0); return 0; }
   if (std::string(key) == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
   if (std::string(key) == "merged_rel_reduce") { p->merged_rel_reduce = (value != 0); return 0; }
   if (std::string(key) == "fused_c16_dgrad") { p->use_fused_c16_dgrad = (value != 0); return 0; }
