@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--gate-branch", type=int, default=None, help="side-stream gate position (experiment)")
     ap.add_argument("--tail-wgrad-main", action="store_true", help="tail weight gradients on the main stream (experiment; default: side stream)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the whole backward on one stream")
+    ap.add_argument("--sem-normal-priority", action="store_true", help="SemanticLoss stream at normal instead of lowest priority (experiment)")
     ap.add_argument("--no-overlap-semantic", action="store_true", help="SemanticLoss forward after the backward pass instead of beside it")
     ap.add_argument("--debug-skip-side", action="store_true", help="TIMING EXPERIMENT: skip all parameter-gradient kernels (wrong results)")
     ap.add_argument("--semantic-loss", action="store_true",
@@ -187,6 +188,7 @@ def main():
                    semantic_loss=sem, lambda_clip=0.01 if sem is not None else 0.0,
                    overlap_comm=not args.no_overlap_comm, force_comm_path=args.force_comm_path,
                    overlap_semantic=not args.no_overlap_semantic)
+    ts.sem_low_priority = not args.sem_normal_priority
     batches = [synthetic_batch(B, args.lr_size, args.scale, rank, s, device) for s in range(2)]
     if args.debug_skip_side:
         plan = model._plan_for(batches[0][0])
@@ -258,7 +260,7 @@ def main():
             "option": args.option or None, "gate_branch": args.gate_branch, "tail_wgrad_main": args.tail_wgrad_main or None,
             "no_side_stream": args.no_side_stream or None, "null_stream": args.null_stream or None,
             "no_overlap_comm": args.no_overlap_comm or None, "force_comm_path": args.force_comm_path or None,
-            "all_kernel_events": args.all_kernel_events or None, "no_overlap_semantic": args.no_overlap_semantic or None, "debug_skip_side": args.debug_skip_side or None}.items() if v is not None}
+            "all_kernel_events": args.all_kernel_events or None, "no_overlap_semantic": args.no_overlap_semantic or None, "sem_normal_priority": args.sem_normal_priority or None, "debug_skip_side": args.debug_skip_side or None}.items() if v is not None}
         out = {
             "metric": f"train-step HR patches/sec at {args.lr_size}x{args.lr_size} LR x{args.scale}",
             "value": None if args.debug_skip_side else round(world * B * args.steps / dt, 3),
