@@ -134,6 +134,7 @@ struct m2t_plan {
   int norm_single_stage = 0;           // InstanceNorm reductions: bit 0 / bit 1 = forward statistics / backward sums by one workgroup per (image, chunk)
   bool fused_dgrad_gather_in_prep = true;   // ring rows of the fused data gradient added by branch_prep_bwd on load (0: separate gather launch)
   bool last_block_conv_first = false;  // see the gate in m2t_backward (measured: 5.51 vs 5.48 ms, neutral at batch 32)
+  int side_priority = 0;               // stream priority of the side stream: 0 default, 1 lowest, -1 highest (set before the first m2t_backward)
   int wgrad_big_tiles = -1;            // C = 256 qkv weight gradient: 128 x 128 output tiles instead of 64 x 64 (k_gemm.hip); value = target
                                        // workgroups, 0 = off, -1 = auto: 256 from 24 576 rows on (batch 32: 9.82 vs 9.93 ms; batch 16: 5.53 vs 5.49)
   bool merged_rel_reduce = false;      // the rel-pos partial reductions of a block's four branches in one launch: measured SLOWER (5.48 vs 5.44 ms; batch 32: 10.03 vs 9.85)
@@ -168,6 +169,10 @@ struct m2t_plan {
       std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
       for (int i = 0; i < cus; ++i) mask[i / 32] |= 1u << (i % 32);
       if (hipExtStreamCreateWithCUMask(&side, (uint32_t)mask.size(), mask.data()) != hipSuccess) return -1;
+    } else if (side_priority != 0) {
+      int lo = 0, hi = 0;                          // (numerically larger = lower priority)
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, side_priority > 0 ? lo : hi) != hipSuccess) return -1;
     } else if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return -1;
     events.resize(192);
     for (auto& e : events)
@@ -884,6 +889,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (std::string(key) == "norm_single_stage") { p->norm_single_stage = (int)value; return 0; }
   if (std::string(key) == "dgrad_gather_in_prep") { p->fused_dgrad_gather_in_prep = (value != 0); return 0; }
   if (std::string(key) == "last_block_conv_first") { p->last_block_conv_first = (value != 0); return 0; }
+  if (std::string(key) == "side_priority") { p->side_priority = (int)value; return 0; }
   if (std::string(key) == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
   if (std::string(key) == "merged_rel_reduce") { p->merged_rel_reduce = (value != 0); return 0; }
   if (std::string(key) == "fused_c16_dgrad") { p->use_fused_c16_dgrad = (value != 0); return 0; }
