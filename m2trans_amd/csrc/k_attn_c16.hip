@@ -406,12 +406,15 @@ __global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const
   // in registers across an unrolled loop costs 24 B/lane of scratch at four workgroups per CU (4096 windows = ONE round)
   __shared__ __attribute__((aligned(16))) bf16_t QsAll[4][64][16];
   __shared__ __attribute__((aligned(16))) bf16_t XrAll[4][64][16];
+  // the rel-pos table (rel_h [10][8] | rel_w [10][8] fp32) per wave: read tile by tile instead of 28 registers held from the start
+  __shared__ __attribute__((aligned(16))) float RelAll[4][160];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wi = xcd_block_index() * 4 + wv;
   if (wi >= nwin) return;
   bf16_t(*Vs)[16] = VsAll[wv];
   bf16_t(*Qs)[16] = QsAll[wv];
   bf16_t(*Xr)[16] = XrAll[wv];
+  float* RelS = RelAll[wv];
   const int lr = lane & 15, g = lane >> 4;
   const int nw = w / 8, nh = h / 8;
   const int wx = wi % nw, wy = (wi / nw) % nh, b = wi / (nw * nh);
@@ -424,7 +427,6 @@ __global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const
     const int q = 16 * qt + lr;
     xq[qt] = ld4(x + (img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7)) * C16 + 4 * g);
   }
-  f32x4 rel[WA_KT];
 #pragma unroll
   for (int t = 0; t < WA_KT; ++t) {
     const int key = min(16 * t + lr, WA_NK - 1);
@@ -433,9 +435,13 @@ __global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const
     inb[t] = (16 * t + lr < WA_NK) && y >= 0 && y < h && xx >= 0 && xx < w;
     const int yc = min(max(y, 0), h - 1), xc = min(max(xx, 0), w - 1);
     xk[t] = ld4(x + (img + (long long)yc * w + xc) * C16 + 4 * g);
-    const float* rp = (g < 2) ? (rel_h + kr * (C16 / 2) + 4 * g) : (rel_w + kc * (C16 / 2) + 4 * g - C16 / 2);
-    rel[t] = *reinterpret_cast<const f32x4*>(rp);
   }
+  {
+    const int l40 = min(lane, 39);                 // lanes 0..19: rel_h, 20..39: rel_w, one float4 each (clamped, store masked)
+    const f32x4 rv4 = *reinterpret_cast<const f32x4*>((l40 < 20 ? rel_h + 4 * l40 : rel_w + 4 * (l40 - 20)));
+    if (lane < 40) *reinterpret_cast<f32x4*>(&RelS[4 * lane]) = rv4;
+  }
+  wave_sync();
   bf16x4 wA[3];                                  // rows 16 n + lr of [q | k | v], input channels 4g ..
 #pragma unroll
   for (int n = 0; n < 3; ++n) wA[n] = ld4(wqkv + (16 * n + lr) * C16 + 4 * g);
@@ -473,7 +479,9 @@ __global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const
       st4(pk + C16, kraw);
       st4(pk + 2 * C16, vraw);
     }
-    kA[t] = (key < WA_NK) ? pack4((float)kraw[0] + rel[t][0], (float)kraw[1] + rel[t][1], (float)kraw[2] + rel[t][2], (float)kraw[3] + rel[t][3])
+    const int kk = min(key, WA_NK - 1), kr2 = kk / 10, kc2 = kk - kr2 * 10;
+    const f32x4 rel = *reinterpret_cast<const f32x4*>(&RelS[(g < 2) ? kr2 * 8 + 4 * g : 80 + kc2 * 8 + 4 * g - 8]);
+    kA[t] = (key < WA_NK) ? pack4((float)kraw[0] + rel[0], (float)kraw[1] + rel[1], (float)kraw[2] + rel[2], (float)kraw[3] + rel[3])
                           : zero4();
     st4(&Vs[16 * t + lr][4 * g], (key < WA_NK) ? vraw : zero4());
   }

@@ -1,4 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-bash tools/ab_opts.sh "--option last_block_conv_first=1" "--option last_block_conv_first=0" 3
-bash tools/ab_opts.sh "--config 3 --option last_block_conv_first=1" "--config 3 --option last_block_conv_first=0" 2
+timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_baseline_configs.py -q -m gpu -x 2>&1 | tail -2
+for i in 1 2 3; do python bench.py --no-cpu-baseline --no-kernel-events --steps 20 2>&1 | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done
