@@ -71,3 +71,12 @@ def test_device_cutmix_and_cut_out_are_bit_identical_to_the_reference():
         a, b = A.cutmix(lr.cuda(), hr.cuda(), alpha=1.0, n_patch=n_patch, scale=2)
         c = A.cut_out(lr.cuda(), n_holes=n_holes, length=length)
         assert torch.equal(a.cpu(), cm_lr) and torch.equal(b.cpu(), cm_hr) and torch.equal(c.cpu(), co), seed
+
+
+def test_halves_follow_torch_chunk():
+    from m2trans_amd import augment as A
+    for n in range(1, 12):
+        want = [t.shape[0] for t in torch.arange(n).chunk(2)] if n > 1 else [1]
+        got = A._halves(n)
+        assert [l for _, l in got] == want, (n, got, want)
+        assert [s for s, _ in got] == [0] + ([want[0]] if len(want) > 1 else []), (n, got)

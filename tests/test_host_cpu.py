@@ -351,3 +351,20 @@ def test_eval_and_data_entry_points_validate_arguments_without_a_gpu():
     assert L.m2t_crop_patches(one, one, desc.ctypes.data_as(C.c_void_p), 1, 3, 50, 4, one, one, None) == -2   # 50 % 4 != 0
     assert L.m2t_image_to_tensor(one, 20, 30, 3, 21, 30, one, None) == -2         # crop taller than the image
     assert b"m2t_image_to_tensor" in L.m2t_last_error_string()
+
+
+def test_roofline_work_table_matches_the_profiler_categories():
+    """every category the work model emits is a profiler category, the fused / unfused variants partition the same FLOPs,
+    and the dominant-kernel arithmetic of DESIGN.md holds (attention backward at C = 256 with the fused data gradient:
+    10.6 GFLOP and 67 MB per launch at batch 16)."""
+    from m2trans_amd import profile as P
+    w = P.algorithmic_work(16, 128, 4, "bf16")
+    assert set(w) <= set(P.CATS), set(w) - set(P.CATS)
+    fl, by, n = w["attn_bwd_c256"]
+    assert n == 16 and abs(fl / n - 10.64e9) < 0.05e9 and abs(by / n - 67.1e6) < 0.2e6
+    w0 = P.algorithmic_work(16, 128, 4, "bf16", fused_attn_fwd=False, fused_qkv_dgrad=False)
+    tot = lambda t, keys: sum(t[k][0] for k in keys if k in t)
+    fwd_keys = ["attn_fwd_c16", "attn_fwd_c64", "attn_fwd_c256", "attn_fused_c16", "attn_fused_c64", "attn_fused_c256", "gemm_qkv"]
+    bwd_keys = ["attn_bwd_c16", "attn_bwd_c64", "attn_bwd_c256", "gemm_qkv_dgrad"]
+    assert abs(tot(w, fwd_keys) - tot(w0, fwd_keys)) < 1e-3 * tot(w0, fwd_keys)
+    assert abs(tot(w, bwd_keys) - tot(w0, bwd_keys)) < 1e-3 * tot(w0, bwd_keys)
