@@ -5,8 +5,10 @@
 
 One "step" = one pass of the hot path (forward, L1 loss, backward, gradient all-reduce when
 N > 1, fused Adam) over one batch of synthetic 128x128 LR / 512x512 HR patches that are already
-resident in HBM.  For N > 1 launch under torch.distributed.run (one rank per GPU, RCCL); per-GPU
-batch is fixed (weak scaling); value = patches of ALL ranks / max-over-ranks time.
+resident in HBM.  N > 1: one rank per GPU over RCCL, either launched by the caller under
+torch.distributed.run, or -- `python bench.py --gpus N` alone -- by this script, which then starts that
+launcher as a CHILD process before touching the GPU and exits with its status.  Per-GPU batch is
+fixed (weak scaling); value = patches of ALL ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line (metric/value/... + "roofline" for the dominant kernel measured
 with HIP events inside the timed region + "cpu_baseline": the CPU oracle timed on the host).
@@ -46,10 +48,7 @@ def parse():
     ap.add_argument("--no-overlap-comm", action="store_true", help="one all-reduce after the backward instead of the bucketed overlap")
     ap.add_argument("--force-comm-path", action="store_true", help="issue the gradient collectives even with one rank (needs an initialised process group)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=INT", help="m2t_set_option on the plan (experiments)")
-    ap.add_argument("--gate-branch", type=int, default=None, help="side-stream gate position (experiment)")
-    ap.add_argument("--tail-wgrad-main", action="store_true", help="tail weight gradients on the main stream (experiment; default: side stream)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the whole backward on one stream")
-    ap.add_argument("--sem-normal-priority", action="store_true", help="SemanticLoss stream at normal instead of lowest priority (experiment)")
     ap.add_argument("--no-overlap-semantic", action="store_true", help="SemanticLoss forward after the backward pass instead of beside it")
     ap.add_argument("--debug-skip-side", action="store_true", help="TIMING EXPERIMENT: skip all parameter-gradient kernels (wrong results)")
     ap.add_argument("--semantic-loss", action="store_true",
@@ -141,14 +140,45 @@ def cpu_baseline(args):
                       f"{n} timed steps after 1 warm-up, torch CPU {torch.get_num_threads()} threads"}
 
 
+def child_command(argv, n_gpus: int, port: int):
+    """The launcher line a plain `python bench.py --gpus N` turns into: one rank per GPU under torch.distributed.run
+    (the same line the driver uses when it launches the ranks itself)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (never an exec: this process
+    has not touched the GPU yet and stays a plain parent), relay rank 0's JSON line, return the child's status."""
+    import subprocess
+    visible = torch.cuda.device_count()           # counting devices does not initialise the HIP runtime
+    if visible < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {visible} device(s) are visible", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(1, args.gpus))))
+    cmd = child_command(sys.argv[1:], args.gpus, free_port())
+    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
@@ -169,6 +199,10 @@ def main():
     margs = types.SimpleNamespace(n_feats=64, scale=args.scale, rgb_range=1.0, n_blocks=8, colors=3,
                                   compute_dtype=args.dtype)
     model = create_model(margs).to(device)
+    if world > 1:
+        # persistent replicas start from rank 0's weights (the reference re-broadcasts every forward, train.py:73)
+        from m2trans_amd.dist import broadcast_params
+        broadcast_params(model.flat_params, src=0)
     sem, captions = None, None
     B = args.batch
     if args.semantic_loss:
@@ -188,7 +222,6 @@ def main():
                    semantic_loss=sem, lambda_clip=0.01 if sem is not None else 0.0,
                    overlap_comm=not args.no_overlap_comm, force_comm_path=args.force_comm_path,
                    overlap_semantic=not args.no_overlap_semantic)
-    ts.sem_low_priority = not args.sem_normal_priority
     batches = [synthetic_batch(B, args.lr_size, args.scale, rank, s, device) for s in range(2)]
     if args.debug_skip_side:
         plan = model._plan_for(batches[0][0])
@@ -197,12 +230,6 @@ def main():
         key, val = kv.split("=")
         plan = model._plan_for(batches[0][0])
         _lib.check(_lib.load().m2t_set_option(plan.handle, key.encode(), int(val)), "m2t_set_option")
-    if args.gate_branch is not None:
-        plan = model._plan_for(batches[0][0])
-        _lib.check(_lib.load().m2t_set_option(plan.handle, b"gate_branch", args.gate_branch), "m2t_set_option")
-    if args.tail_wgrad_main:
-        plan = model._plan_for(batches[0][0])
-        _lib.check(_lib.load().m2t_set_option(plan.handle, b"tail_wgrad_main", 1), "m2t_set_option")
     if args.no_side_stream:
         plan = model._plan_for(batches[0][0])
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"side_stream", 0), "m2t_set_option")
@@ -246,7 +273,8 @@ def main():
     if rank == 0 and not args.no_kernel_events:
         roofline = m2t_profile.roofline_report(B, args.lr_size, args.scale, args.dtype, args.steps,
                                                os.path.join(ROOT, "profiles", "pmc_traffic.json"), source_stamp(),
-                                               workload=f"config{args.config}" if not args.preset_overridden else None)
+                                               workload=f"config{args.config}" if not args.preset_overridden else None,
+                                               plan=model._plan_for(batches[0][0]))
         m2t_profile.enable(0)
 
     if rank == 0:
@@ -257,10 +285,10 @@ def main():
             what = ("L1 + MedCLIP(Swin-T) regulariser" if args.semantic_loss else "L1 loss only") + " (preset overridden on the command line)"
         # every switch that changes the measured work or schedule is echoed, so an experiment cannot pass for a headline
         experiment = {k: v for k, v in {
-            "option": args.option or None, "gate_branch": args.gate_branch, "tail_wgrad_main": args.tail_wgrad_main or None,
+            "option": args.option or None,
             "no_side_stream": args.no_side_stream or None, "null_stream": args.null_stream or None,
             "no_overlap_comm": args.no_overlap_comm or None, "force_comm_path": args.force_comm_path or None,
-            "all_kernel_events": args.all_kernel_events or None, "no_overlap_semantic": args.no_overlap_semantic or None, "sem_normal_priority": args.sem_normal_priority or None, "debug_skip_side": args.debug_skip_side or None}.items() if v is not None}
+            "all_kernel_events": args.all_kernel_events or None, "no_overlap_semantic": args.no_overlap_semantic or None, "debug_skip_side": args.debug_skip_side or None}.items() if v is not None}
         out = {
             "metric": f"train-step HR patches/sec at {args.lr_size}x{args.lr_size} LR x{args.scale}",
             "value": None if args.debug_skip_side else round(world * B * args.steps / dt, 3),

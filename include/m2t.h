@@ -32,6 +32,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#pragma GCC visibility push(default)
 
 typedef struct m2t_plan m2t_plan;
 
@@ -51,50 +53,24 @@ void m2t_plan_destroy(m2t_plan* p);
  * "ws:<tensor>" (byte offset of a workspace tensor, e.g. "ws:b0.qkv3"), "wsn:<tensor>" (elements).
  * Returns -1 for an unknown key. */
 long long m2t_plan_query(const m2t_plan* p, const char* key);
-/* Scheduling / kernel-selection options (results are the same up to bf16 rounding; every pair is A/B-tested in
- * tests/test_gpu_model.py).  Defaults in brackets.
+/* Scheduling / kernel-selection options: each selects between a fused gfx950 kernel and the plain kernels it replaces
+ * (which fp32 parity mode always uses), or places the parameter-gradient work; results are the same up to bf16 rounding and
+ * every pair is A/B-tested in tests/test_gpu_model.py.  Defaults in brackets; m2t_plan_query("opt:<key>") reads the value in
+ * force (gate_branch / wgrad_big_tiles are reported + 1000).  Variants that were measured and lost live under scratch/ with
+ * their numbers in profiles/README.md, not behind options.
  *   "side_stream"       [1] parameter-gradient kernels of m2t_backward on a plan-owned second stream
- *   "gated_side"        [1] release a block's side-stream work only after its LDS-hungry attention launches
- *   "gate_branch"       [1] branch index (3..0) after whose attention launch the gate opens (1 = behind the two C = 256 launches
- *                           and the C = 64 one: 2 % faster than 2, 3 % faster than 0 = behind all four or ungated)
- *   "side_conv_pos"     [1] where the block's conv weight gradient enters the side stream: 0 first at the gate, 1 after the
- *                           gated qkv weight gradients (1.9 % faster than 0), 2 after the block's last attention launch
- *   "tail_wgrad_main"   [0] 1: tail weight gradients on the caller's stream instead of the side stream (0.5 % slower)
- *   "fused_tail_bwd"    [1] bf16 x4: one fused kernel for the high-resolution half of the tail backward
- *   "resident_attn_bwd" [1] bf16: whole-window-resident / wave-per-window attention backward kernels
+ *   "gate_branch"       [1] -1: side work released as soon as its inputs exist; 0..3: a block's side work waits for the
+ *                           attention launch of that branch (1 = behind the two LDS-filling C = 256 launches and the C = 64 one)
+ *   "wgrad_big_tiles"   [-1] qkv weight gradient of the C = 256 branches with 128 x 128 output tiles: value = target number of
+ *                           workgroups (64..512), 0 = off, -1 = auto (256 from 24 576 branch pixels on, i.e. batch >= 24)
+ *   "fused_tail_bwd"    [1] bf16 x4: one fused kernel for the high-resolution half of the tail backward (k_tail_bwd.hip)
  *   "fused_tail_fwd"    [0] bf16 x4: tail.3 expansion + PixelShuffle + GELU + tail conv in one kernel (k_tail_fwd.hip); gelu(t2) and
- *                           gelu'(t2) (1.07 GB at batch 16) are never stored, the fused tail backward recomputes them per tile.
- *                           Bit-identical; measured 1 % SLOWER on the step (erf re-evaluation costs more than re-reading bf16).
- *                           Needs "fused_tail_bwd"; m2t_plan_query("stores_t2") tells whether ws:t2act / ws:t2der are written
- *   "fused_attn_fwd"    [1] bf16, C = 64 / 256 branches: qkv projection + window attention + IWT / residual epilogue in one
- *                           kernel per window (k_attn_fused.hip) instead of a GEMM launch + an attention launch
- *   "norm_single_stage" [0] InstanceNorm reductions by ONE 512-thread workgroup per (image, 16-channel chunk plane), no partials and
- *                           no fold launch: bit 0 = forward statistics, bit 1 = backward sums.  Measured slower at batch 16
- *                           (+15 / +21 us per launch: 64 workgroups cannot stream the map as fast as 512); bit 2 = the fold of the
- *                           backward partials inside the apply kernel instead of a separate launch (bit-identical, 1.5 % slower)
- *   "fused_qkv_dgrad"   [1] bf16, C = 64 / 256 branches: the data gradient of the qkv projection is taken inside the attention
- *                           backward kernel (k_attn_res.hip): the window multiplies its own dq | dK | dV rows by Wqkv^T, the
- *                           overlap-add over neighbouring windows moves to the C-wide product.  Removes the halo gather and
- *                           the GEMM launch from the main chain (+2.3 % at batch 16, neutral at batch 32)
- *   "wgrad_big_tiles"   [-1] qkv weight gradient of the C = 256 branches with 128 x 128 output tiles (half the L2 re-reads of the 64 x 64
- *                           kernel): value = target number of workgroups (64..512), 0 = off, -1 = auto (256 when the branch has
- *                           >= 24 576 pixels, i.e. from batch 24 on: +1.1 % at batch 32, -0.7 % at batch 16)
- *   "merged_rel_reduce" [0] first stage of the rel-pos gradient reduction for a block's four branches in one launch instead of four
- *                           (bit-identical; 0.7 % / 1.8 % slower at batch 16 / 32: the merged launch sits at the end of the block's
- *                           side work and meets the next block's conv data gradient)
- *   "fused_c16_dgrad"   [0] the same inside the wave-per-window C = 16 backward kernel (measured a tie / -0.3 %); needs
- *                           "fused_qkv_dgrad"
- *   "dgrad_gather_in_prep" [1] with "fused_qkv_dgrad": branch_prep_bwd adds the ring rows of the neighbouring windows while it
- *                           loads the row (0: a separate gather launch; bit-identical)
- *   "fused_c16_fwd"     [1] bf16, C = 16 branch: InstanceNorm apply of chunk 0 + qkv projection + window attention + residual in
- *                           one wave-per-window kernel (k_attn_c16.hip) instead of branch_prep + GEMM + attention launches
- *   "persistent_conv"   [0] bf16: conv3x3 with LDS-resident weights (bit-identical, measured slower)
- *   "conv_variant"      [1] bf16 conv3x3: 1 = the tap-pipelined kernel; 0 = weight slices register-resident, several tiles per
- *                           workgroup with the next halo tile in flight under the taps (>= 1024 tiles; bit-identical, measured a tie);
- *                           2 = 16x16-pixel tiles, XOR-swizzled 128-byte LDS rows, a wave owns 4 pixel rows x 64 channels
- *                           (bit-identical; a tie stand-alone, 1.5 % slower on the step)
- *   "side_cus"          [0] CU mask size of the side stream (0 = all CUs; masking measured slower); set before the
- *                           first m2t_backward, and only effective when the caller's stream is not the NULL stream
+ *                           gelu'(t2) are then never stored and the fused tail backward recomputes them per tile (needs
+ *                           "fused_tail_bwd"); m2t_plan_query("stores_t2") tells whether ws:t2act / ws:t2der are written
+ *   "resident_attn_bwd" [1] bf16: whole-window-resident / wave-per-window attention backward kernels
+ *   "fused_attn_fwd"    [1] bf16, C = 64 / 256: qkv projection + window attention + IWT / residual in one kernel per window
+ *   "fused_c16_fwd"     [1] bf16, C = 16: InstanceNorm apply + qkv projection + window attention + residual, one wave per window
+ *   "fused_qkv_dgrad"   [1] bf16, C = 64 / 256: the data gradient of the qkv projection inside the attention backward kernel
  *   "debug_skip_side"   [0] timing experiments only: skips every parameter-gradient kernel (results are WRONG) */
 int m2t_set_option(m2t_plan* p, const char* key, long long value);
 /* Gradient buckets for communication overlap (replaces the reduce-to-GPU-0 of nn.DataParallel, train.py:73):
@@ -231,6 +207,7 @@ int m2t_image_to_tensor(const unsigned char* img, int img_h, int img_w, int chan
 int m2t_box_mix(const float* src, float* dst, int B, int C, int H, int W, const int* table_dev, int max_boxes, int mode,
                 int mult, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -84,4 +84,8 @@ def import_checkpoint(ckpt: dict, model, train_step=None) -> int:
         sch = ckpt.get("scheduler_state_dict")
         if sch is not None:
             train_step.scheduler_last_epoch = int(sch.get("last_epoch", 0))
+        else:
+            # a checkpoint without scheduler state (e.g. --pretrain files): the reference saves BEFORE the epoch's
+            # scheduler.step() (train.py:341-358), so the scheduler stood at epoch - 1
+            train_step.scheduler_last_epoch = max(0, int(ckpt.get("epoch", 0)) - 1)
     return int(ckpt.get("epoch", 0)) + 1

@@ -626,36 +626,6 @@ __global__ void __launch_bounds__(256) rel_reduce1_kernel(const float* __restric
     part[(long long)blockIdx.y * ncol + col] = t;
   }
 }
-// the same first stage for up to four branches in ONE launch (grid.z = branch; blocks outside a branch's column / split
-// range leave at once): 32 launches of ~5 us each per step become 8
-__global__ void __launch_bounds__(256) rel_reduce1_multi_kernel(m2t_rel_desc4 a) {
-  const m2t_rel_desc d = a.d[blockIdx.z];
-  if ((int)blockIdx.x * 32 >= d.ncol || (int)blockIdx.y >= d.nsplit) return;
-  __shared__ float red[8][33];
-  const int c = threadIdx.x & 31, l = threadIdx.x >> 5;
-  const int col = blockIdx.x * 32 + c;
-  const int w0 = blockIdx.y * d.wps, w1 = min(d.nwin, w0 + d.wps);
-  const float* __restrict__ relw = d.relw;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (col < d.ncol) {
-    int wi = w0 + l;
-    for (; wi + 24 < w1; wi += 32) {
-      a0 += relw[(long long)wi * d.ncol + col];
-      a1 += relw[(long long)(wi + 8) * d.ncol + col];
-      a2 += relw[(long long)(wi + 16) * d.ncol + col];
-      a3 += relw[(long long)(wi + 24) * d.ncol + col];
-    }
-    for (; wi < w1; wi += 8) a0 += relw[(long long)wi * d.ncol + col];
-  }
-  red[l][c] = (a0 + a1) + (a2 + a3);
-  __syncthreads();
-  if (l == 0 && col < d.ncol) {
-    float t = red[0][c];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) t += red[j][c];
-    d.part[(long long)blockIdx.y * d.ncol + col] = t;
-  }
-}
 __global__ void __launch_bounds__(256) rel_reduce2_kernel(const float* __restrict__ part, float* __restrict__ grel_h,
                                                           float* __restrict__ grel_w, int nsplit, int C) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -728,18 +698,6 @@ int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int*
   hipLaunchKernelGGL(rel_reduce1_kernel, dim3(ceil_div(10 * C, 32), nsplit), dim3(256), 0, st, relw, rel_part, nwin, 10 * C, wps);
   M2T_LAUNCH_CHECK();
   *nsplit_out = nsplit;
-  return 0;
-}
-void rel_reduce1_plan(int nwin, int C, m2t_rel_desc* d) {      // the split rule of launch_rel_reduce1
-  int nsplit = std::min(nwin, 32);
-  const int wps = ceil_div(nwin, nsplit);
-  d->nwin = nwin; d->ncol = 10 * C; d->wps = wps; d->nsplit = ceil_div(nwin, wps);
-}
-int launch_rel_reduce1_multi(const m2t_rel_desc4& a, int n, hipStream_t st) {
-  int gx = 0, gy = 0;
-  for (int i = 0; i < n; ++i) { gx = std::max(gx, ceil_div(a.d[i].ncol, 32)); gy = std::max(gy, a.d[i].nsplit); }
-  hipLaunchKernelGGL(rel_reduce1_multi_kernel, dim3(gx, gy, n), dim3(256), 0, st, a);
-  M2T_LAUNCH_CHECK();
   return 0;
 }
 int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st) {

@@ -65,21 +65,12 @@ __device__ __forceinline__ void wave_sync() {
 __global__ void __launch_bounds__(256, 2) window_attn_bwd_c16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                                   const float* __restrict__ rel_w, const bf16_t* __restrict__ go,
                                                                   int ldg, int gc0, bf16_t* __restrict__ gqkv, bf16_t* __restrict__ win,
-                                                                  float* __restrict__ relw, int h, int w, int nwin,
-                                                                  const bf16_t* __restrict__ wT, bf16_t* __restrict__ gd,
-                                                                  bf16_t* __restrict__ gdwin) {
-  // wT != nullptr: the data gradient of the 16 -> 48 projection, g_d = g_q Wq + g_k Wk + g_v Wv, is taken here too
-  // (wT = Wqkv^T [16][48] bf16).  The accumulator layout of dq / dK^ / dV (lane = pixel, channels 4g ..) is the B-operand
-  // layout of W^T g^T, so it costs 18 MFMAs per window; the products of the window's own contributions go to
-  // gd [pixel][16] (own pixels) and gdwin [window][36][16] (ring keys), see window_attn_bwd_res_kernel<.., DG>.
+                                                                  float* __restrict__ relw, int h, int w, int nwin) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wi = xcd_block_index() * 4 + wv;
   if (wi >= nwin) return;                         // no workgroup barrier anywhere: a wave may leave alone
   C16WaveLds& L = reinterpret_cast<C16WaveLds*>(smem)[wv];
-  bf16x4 wA[3];                                   // W^T rows (output channel lr), contraction n = 16 s + 4g .. (s: q | k | v)
-#pragma unroll
-  for (int s3 = 0; s3 < 3; ++s3) wA[s3] = wT ? ld4(wT + lr_of(lane) * (3 * C16) + 16 * s3 + 4 * g_of(lane)) : zero4();
   const int lr = lane & 15, g = lane >> 4;
   const int nw = w / 8, nh = h / 8;
   const int wx = wi % nw, wy = (wi / nw) % nh, b = wi / (nw * nh);
@@ -199,13 +190,10 @@ __global__ void __launch_bounds__(256, 2) window_attn_bwd_c16_kernel(const bf16_
       mma4(o, kT[t], db);
     }
     o *= (f32x4){scale, scale, scale, scale};
-    f32x4 gq = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
       const int q = 16 * qt + lr;
       const long long qpix = img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
-      const bf16x4 ob = pack4(o[0], o[1], o[2], o[3]);
-      st4(gqkv + qpix * (3 * C16) + 4 * g, ob);
-      if (wT) mma4(gq, wA[0], ob);                // g_q Wq of this query tile: lane = query lr, output channels 4g ..
+      st4(gqkv + qpix * (3 * C16) + 4 * g, pack4(o[0], o[1], o[2], o[3]));
     }
     wave_sync();
     // dV^T [c][key] += dO^T P ; dK^^T [c][key] += q^T dS   (contraction over this tile's 16 queries)
@@ -217,38 +205,16 @@ __global__ void __launch_bounds__(256, 2) window_attn_bwd_c16_kernel(const bf16_
       mma4(dkT[t], qT, dB);
     }
     wave_sync();
-    // K^ is dead once kT is loaded: its rows hold g_q Wq [query][16] (bf16) until the rel-pos sums reuse the region
-    if (wT) st4(&L.Kh[16 * qt + lr][4 * g], pack4(gq[0], gq[1], gq[2], gq[3]));
   }
 
   // ---- dK^ | dV rows of this window: lane holds channels 4g .. 4g+3 of key 16 t + lr ----
-  wave_sync();                                     // GQ rows of the last query tile are visible
 #pragma unroll
   for (int t = 0; t < WA_KT; ++t) {
     const int key = 16 * t + lr;
-    const bf16x4 kb = pack4(dkT[t][0], dkT[t][1], dkT[t][2], dkT[t][3]);
-    const bf16x4 vb = pack4(dvT[t][0], dvT[t][1], dvT[t][2], dvT[t][3]);
-    f32x4 gdv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (wT) {                                      // wave-uniform
-      mma4(gdv, wA[1], kb);
-      mma4(gdv, wA[2], vb);
-    }
     if (key < WA_NK) {
       bf16_t* wp = dkv_row(gqkv, win, (long long)wi, b, wy, wx, h, w, C16, key) + 4 * g;
-      st4(wp, kb);
-      st4(wp + C16, vb);
-      if (wT) {
-        const int kr = key / 10, kc = key - kr * 10;
-        const int y = 8 * wy + kr - 1, x = 8 * wx + kc - 1;
-        if (kr >= 1 && kr <= 8 && kc >= 1 && kc <= 8) {
-          const bf16x4 gqb = ld4(&L.Kh[(kr - 1) * 8 + (kc - 1)][4 * g]);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) gdv[r] += (float)gqb[r];
-          st4(gd + (img + (long long)y * w + x) * C16 + 4 * g, pack4(gdv[0], gdv[1], gdv[2], gdv[3]));
-        } else if (y >= 0 && y < h && x >= 0 && x < w) {
-          st4(gdwin + ((long long)wi * WA_RING + ring_index(kr, kc)) * C16 + 4 * g, pack4(gdv[0], gdv[1], gdv[2], gdv[3]));
-        }
-      }
+      st4(wp, pack4(dkT[t][0], dkT[t][1], dkT[t][2], dkT[t][3]));
+      st4(wp + C16, pack4(dvT[t][0], dvT[t][1], dvT[t][2], dvT[t][3]));
     }
   }
   // ---- rel-pos gradient: dK^ summed over key columns (c < 8) / key rows (c >= 8), phantom keys included ----
@@ -541,14 +507,12 @@ __global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const
 }  // namespace
 
 int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
-                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st, const void* wT, void* gd,
-                               void* gdwin) {
-  if (wT && (!gd || !gdwin)) return m2t_set_error(-2, "window_attn_bwd_c16: fused data gradient needs gd and gdwin");
+                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st) {
   const int nwin = B * (h / 8) * (w / 8);
   const size_t sh = 4 * sizeof(C16WaveLds);
   if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_bwd_c16_kernel, (int)sh)) return rc__;
   M2T_LAUNCH_TIMED(window_attn_bwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), sh, st, (const bf16_t*)qkv, rel_h, rel_w,
-                     (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, h, w, nwin, (const bf16_t*)wT, (bf16_t*)gd, (bf16_t*)gdwin);
+                     (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, h, w, nwin);
   M2T_LAUNCH_CHECK();
   return 0;
 }

@@ -459,7 +459,7 @@ int go_fused(const bf16_t* x, const bf16_t* wfrag, const float* rel_h, const flo
 
 }  // namespace
 
-// bf16; (C, post_levels) in {(64, 0), (64, 1), (256, 0), (256, 2)}; M2T_UNSUPPORTED otherwise.
+// bf16; (C, post_levels) in {(64, 1), (256, 2)} -- the two shapes of the model; anything else is an argument error.
 // x [B][h][w][C]; wfrag: the qkv weight in M2T_PACK_FRAG16 order; qkv [B][h][w][3C] (written); out / res as in
 // launch_window_attn_fwd (post_levels > 0: the full-resolution xc chunk / xin planes; res is then mandatory).
 int launch_window_attn_fused_fwd(const void* x_, const void* wfrag_, const float* rel_h, const float* rel_w, void* qkv_, void* out_,
@@ -473,6 +473,8 @@ int launch_window_attn_fused_fwd(const void* x_, const void* wfrag_, const float
   bf16_t* out = (bf16_t*)out_;
   const bf16_t* res = (const bf16_t*)res_;
   const int nwin = B * (h / 8) * (w / 8);
+  if (!((C == 256 && post_levels == 2) || (C == 64 && post_levels == 1)))
+    return m2t_set_error(M2T_UNSUPPORTED, "window_attn_fused: unsupported (C, post_levels); built for (64, 1) and (256, 2)");
   int rc = M2T_UNSUPPORTED;
   M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_FUSED_64 : M2T_PROF_ATTN_FUSED_256, st);
   if (C == 256 && post_levels == 2) rc = go_fused<256, 2, 8>(x, wfrag, rel_h, rel_w, qkv, out, ldo, oc0, res, ldr, nwin, h, w, st);

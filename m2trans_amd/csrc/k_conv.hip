@@ -363,500 +363,13 @@ __global__ void __launch_bounds__(256, 4) conv3x3_c64_pipe_kernel(const T* __res
     M2T_CONV_STAMP(3);
   }
 }
-// ---------------------------------------------------------------------------------------
-// Weights-in-registers variant (bf16): what bounded the two kernels above was found with the fused attention kernel
-// (k_attn_fused.hip): vmcnt retires IN ORDER, so
-//   * every tap's `wait for the next weight slice` (a load issued AFTER the next tile's halo prefetch) also waits for
-//     that prefetch: it never stayed in flight under more than one tap, and each of the nine taps paid an exposed L2
-//     round trip for its 8 KB weight slice (the "13 us of tap work ADDED to the 21 us memory phase" of DESIGN.md);
-//   * the residual loads of the epilogue, issued after the first output stores, waited for those stores' acknowledgements.
-// Here a workgroup walks `tiles_per_block` tiles and loads its share of ALL nine weight slices ONCE, into registers
-// (18 fragments = 72 registers per thread; occupancy 2 workgroups per CU instead of 4, paid for by the in-workgroup
-// prefetch): inside the tile loop the only loads left are the next tile's halo (issued right after the current tile is
-// staged, first waited for at the next tile) and the residuals (issued under the last tap, before any store).
-// Same tile, lane mapping and accumulation order as conv3x3_c64_kernel: identical bits.
-// MEASURED (same-box A/B, B = 16, 128x128): 32.0 / 29.6 us forward / data gradient against 31.7 / 29.9 for the
-// tap-pipelined kernel, step 5.73 vs 5.69 ms -- a tie: removing the exposed weight round trips and halving the
-// occupancy cancel.  Kept as option "conv_variant" = 0; what bounds this conv is still open (HBM floor ~21 us).
-// ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) conv3x3_c64_wreg_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
-                                                                   const float* __restrict__ bias, const bf16_t* __restrict__ res1,
-                                                                   const bf16_t* __restrict__ res2, bf16_t* __restrict__ y, int B, int H,
-                                                                   int W, int tiles_per_block, int xcd_order) {
-  using T = bf16_t;
-  __shared__ __attribute__((aligned(16))) T Xs[(C3_TH + 2) * (C3_TW + 2)][C3_LD];
-  __shared__ __attribute__((aligned(16))) T Ws[64][C3_LD];
-  constexpr int TOT = (C3_TH + 2) * (C3_TW + 2) * 8, ITEMS = (TOT + 255) / 256;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int lr = lane & 15, g = lane >> 4;
-  const int tw = W / C3_TW, th = H / C3_TH;
-  const int ntiles = B * th * tw;
-  const long long npix = (long long)B * H * W;
-  int chunk = blockIdx.x;
-  if (xcd_order) chunk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int t0 = chunk * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
-  if (t0 >= t1) return;
-  Frag8<T> f[ITEMS];
-  unsigned fvalid = 0;                    // bit it: item `it` of f lies inside the image (else the halo is zero)
-  auto fetch = [&](int t) {               // branch-free: clamped address, validity applied at the LDS store
-    const int tx = t % tw, q = t / tw;
-    const int ty = q % th;
-    const long long pb = (long long)(q / th) * H * W;
-    const int x0 = tx * C3_TW, y0 = ty * C3_TH;
-    fvalid = 0;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = tid + it * 256;
-      const int cv = idx & 7, p = min(idx >> 3, (C3_TH + 2) * (C3_TW + 2) - 1);
-      const int py = p / (C3_TW + 2), px = p - py * (C3_TW + 2);
-      const int gy = y0 + py - 1, gx = x0 + px - 1;
-      if (idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W) fvalid |= 1u << it;
-      const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-      f[it] = load8(x + p64(npix, pb + (long long)cy * W + cx, cv * 8));
-    }
-  };
-  fetch(t0);
-  Frag8<T> wreg[9][2];
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int idx = tid + it * 256;
-      wreg[tap][it] = load8(wp + ((long long)tap * 64 + (idx >> 3)) * 64 + (idx & 7) * 8);
-    }
-  float bv[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) bv[e] = bias ? bias[16 * g + e] : 0.f;
-  for (int t = t0; t < t1; ++t) {
-    const int tx = t % tw, q = t / tw;
-    const int ty = q % th;
-    const long long pb = (long long)(q / th) * H * W;
-    const int x0 = tx * C3_TW, y0 = ty * C3_TH;
-    if (t > t0) lds_barrier();            // every wave is done with the previous tile's Xs
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = tid + it * 256;
-      if (idx < TOT) store8(&Xs[idx >> 3][(idx & 7) * 8], ((fvalid >> it) & 1u) ? f[it] : frag_zero<T>());
-    }
-    if (t + 1 < t1) fetch(t + 1);         // in flight under this tile's 576 MFMAs: no younger load is waited for before the last tap
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    long long off[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) off[mt] = ((long long)g * npix + pb + (long long)(y0 + 2 * wv + mt) * W + x0 + lr) * 16;
-    Frag8<T> r1[2][2], r2[2][2];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
-      lds_barrier();
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int idx = tid + it * 256;
-        store8(&Ws[idx >> 3][(idx & 7) * 8], wreg[tap][it]);
-      }
-      lds_barrier();
-      if (tap == 8) {
-        // residuals: under the last tap, and before the first output store
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          if (res1) { r1[mt][0] = load8(res1 + off[mt]); r1[mt][1] = load8(res1 + off[mt] + 8); }
-          if (res2) { r2[mt][0] = load8(res2 + off[mt]); r2[mt][1] = load8(res2 + off[mt] + 8); }
-        }
-      }
-#pragma unroll
-      for (int kc = 0; kc < 2; ++kc) {
-        Frag8<T> xf[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          xf[mt] = load8(&Xs[(2 * wv + mt + ky) * (C3_TW + 2) + lr + kx][kc * 32 + g * 8]);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int nl = 16 * (lr >> 2) + 4 * nt + (lr & 3);
-          const Frag8<T> wf = load8(&Ws[nl][kc * 32 + g * 8]);
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wf, xf[mt]);
-        }
-      }
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float v[16];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
-      if (bias) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += bv[e];
-      }
-      if (res1) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += r1[mt][e >> 3].get(e & 7);
-      }
-      if (res2) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] += r2[mt][e >> 3].get(e & 7);
-      }
-      store16f(y + off[mt], v);
-    }
-  }
-}
-// ---------------------------------------------------------------------------------------
-// Persistent variant (bf16): a workgroup keeps ALL nine tap slices of the packed weights in LDS (83 KB) and sweeps
-// a strip of tiles with the halo tile double-buffered: one barrier per tile instead of eighteen, the next tile's
-// global loads (halo + residuals) in flight under the current tile's 576 MFMAs.  Same tile / wave / lane mapping
-// and the same accumulation order as conv3x3_c64_kernel, so the two produce identical bits.
-// MEASURED (B=16, 128x128): with one 4-wave workgroup per CU 53 us against 39 us for the tile-per-workgroup kernel;
-// with 8 waves (two tiles in lockstep, below) 41 / 33 us (forward / data gradient) -- a tie.  Three designs with
-// very different weight traffic and latency structure all land at 33-40 us for 102 MB of HBM traffic (PMC), i.e.
-// ~3 TB/s on the 18-pixel x 32-byte runs of the P64 halo tiles; kept as option "persistent_conv" (default off).
-// ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512) conv3x3_c64_persistent_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
-                                                                     const float* __restrict__ bias, const bf16_t* __restrict__ res1,
-                                                                     const bf16_t* __restrict__ res2, bf16_t* __restrict__ y, int B,
-                                                                     int H, int W, int tiles_per_block) {
-  // 8 waves = two groups of 4; each group owns one tile of the current pair (its own halo buffer), all share the
-  // weights.  Per pair: stage -> barrier -> (next pair's loads issued) -> 576 MFMAs per group -> epilogue -> barrier.
-  using T = bf16_t;
-  constexpr int HP = (C3_TH + 2) * (C3_TW + 2);                   // 180 halo pixels
-  constexpr int TOT = HP * 8, ITEMS = (TOT + 255) / 256;          // 16-byte vectors of a halo tile
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T(*Ws)[64][C3_LD] = reinterpret_cast<T(*)[64][C3_LD]>(smem);                                   // [9][64][72]
-  T(*Xs)[HP][C3_LD] = reinterpret_cast<T(*)[HP][C3_LD]>(smem + sizeof(T) * 9 * 64 * C3_LD);      // [2 groups][180][72]
-  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6;
-  const int lr = lane & 15, g = lane >> 4;
-  const int tw = W / C3_TW, th = H / C3_TH;
-  const long long ntiles = (long long)B * th * tw;
-  const long long npix = (long long)B * H * W;                    // P64 feature maps
-  const long long t0 = (long long)blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
-  if (t0 >= t1) return;
-  {
-    Frag8<T> wr[9];                       // every load first, then the LDS stores (a rolled load -> store loop pays nine L2 round trips)
-#pragma unroll
-    for (int it = 0; it < 9; ++it) { const int idx = threadIdx.x + it * 512; wr[it] = load8(wp + (long long)(idx >> 3) * 64 + (idx & 7) * 8); }
-#pragma unroll
-    for (int it = 0; it < 9; ++it) { const int idx = threadIdx.x + it * 512; store8(&Ws[0][idx >> 3][(idx & 7) * 8], wr[it]); }
-  }
-  Frag8<T> f[ITEMS];
-  unsigned fvalid = 0;                    // bit it: item `it` of f lies inside the image (else the halo is zero)
-  // branch-free (clamped address + validity bit): a load under a lane-dependent branch makes hipcc wait vmcnt(0) per load
-  auto fetch = [&](long long t) {
-    const int tx = (int)(t % tw);
-    const long long q = t / tw;
-    const int ty = (int)(q % th);
-    const long long pb = (q / th) * H * W;
-    const int x0 = tx * C3_TW, y0 = ty * C3_TH;
-    fvalid = 0;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = tid + it * 256;
-      const int cv = idx & 7, p = min(idx >> 3, HP - 1);
-      const int py = p / (C3_TW + 2), px = p - py * (C3_TW + 2);
-      const int gy = y0 + py - 1, gx = x0 + px - 1;
-      if (idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W) fvalid |= 1u << it;
-      const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-      f[it] = load8(x + p64(npix, pb + (long long)cy * W + cx, cv * 8));
-    }
-  };
-  M2T_CONV_STAMP(0);
-  if (t0 + grp < t1) fetch(min(t0 + grp, t1 - 1));
-  float bv[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) bv[e] = bias ? bias[16 * g + e] : 0.f;
-  for (long long tp = t0; tp < t1; tp += 2) {
-    const long long t = tp + grp;
-    const bool live = t < t1;
-    if (live) {
-#pragma unroll
-      for (int it = 0; it < ITEMS; ++it) {
-        const int idx = tid + it * 256;
-        if (idx < TOT) store8(&Xs[grp][idx >> 3][(idx & 7) * 8], ((fvalid >> it) & 1u) ? f[it] : frag_zero<T>());
-      }
-    }
-    lds_barrier();
-    if (tp == t0 + 2) M2T_CONV_STAMP(1);
-    const long long tc = live ? t : t1 - 1;                 // (an idle group of the last pair recomputes a tile and discards it)
-    const int tx = (int)(tc % tw);
-    const long long q = tc / tw;
-    const int ty = (int)(q % th);
-    const long long pb = (q / th) * H * W;
-    const int x0 = tx * C3_TW, y0 = ty * C3_TH;
-    // vmcnt retires in order: the residuals (needed by the epilogue) are issued BEFORE the next pair's halo, so that the
-    // epilogue's wait leaves the halo loads in flight; the stores come last and nothing issued later is waited for before
-    // the next tile's halo, which is older than they are
-    Frag8<T> r1[2][2], r2[2][2];
-    long long off[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      off[mt] = ((long long)g * npix + pb + (long long)(y0 + 2 * wv + mt) * W + x0 + lr) * 16;
-      if (res1) { r1[mt][0] = load8(res1 + off[mt]); r1[mt][1] = load8(res1 + off[mt] + 8); }
-      if (res2) { r2[mt][0] = load8(res2 + off[mt]); r2[mt][1] = load8(res2 + off[mt] + 8); }
-    }
-    if (t + 2 < t1) fetch(t + 2);
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-      for (int kc = 0; kc < 2; ++kc) {
-        Frag8<T> xf[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          xf[mt] = load8(&Xs[grp][(2 * wv + mt + ky) * (C3_TW + 2) + lr + kx][kc * 32 + g * 8]);
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int nl = 16 * (lr >> 2) + 4 * nt + (lr & 3);
-          const Frag8<T> wf = load8(&Ws[tap][nl][kc * 32 + g * 8]);
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wf, xf[mt]);
-        }
-      }
-    }
-    if (tp == t0 + 2) M2T_CONV_STAMP(2);
-    if (live) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        float v[16];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
-        if (bias) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += bv[e];
-        }
-        if (res1) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += r1[mt][e >> 3].get(e & 7);
-        }
-        if (res2) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += r2[mt][e >> 3].get(e & 7);
-        }
-        store16f(y + off[mt], v);
-      }
-    }
-    if (tp == t0 + 2) M2T_CONV_STAMP(3);
-    lds_barrier();            // both halo buffers are free for the next pair
-    if (tp == t0 + 2) M2T_CONV_STAMP(4);
-  }
-}
-
-// ---------------------------------------------------------------------------------------
-// v2 (bf16): what the three kernels above have in common is their LDS operand traffic: a wave multiplies 2 pixel tiles
-// by 4 channel tiles per (tap, k-chunk), i.e. 6 fragment reads per 8 MFMAs, two thirds of them WEIGHT fragments that
-// every wave re-reads for every tile, and with the 144-byte rows the weight rows a lane group touches (16 apart) fall on
-// the same banks (2-way).  Per pair of tiles that is 864 KB of ds_read_b128 at ~1.7 cycles each: ~5.6 k cycles of LDS
-// against 4.6 k cycles of MFMA -- the taps phase measured 8.7 k cycles (scratch/bench_conv.hip), the kernel 30 us.
-// Here: 16 x 16-pixel tiles, a wave owns 4 pixel rows x all 64 channels = 4 x 4 tiles in 64 accumulators, so one
-// (tap, k-chunk) step reads 4 + 4 fragments for 16 MFMAs (2.25 instead of 3.4 KB of LDS reads per output pixel); rows
-// are 128 bytes with the 16-byte chunk index XOR-swizzled by ((row >> 1) & 7), which makes every fragment read
-// conflict-free (16 consecutive rows -> 16 distinct 16-byte slots of the 256-byte bank row), and the weight rows are
-// stored pre-permuted so that consecutive LDS rows are the rows a lane group needs.  All nine weight slices stay in LDS
-// for the whole launch (73.7 KB) beside two halo tiles (2 x 41.5 KB): one 8-wave workgroup per CU, two tiles in lockstep,
-// next pair's halo + this pair's residuals in flight under the taps (issue order chosen for the in-order vmcnt: residuals
-// first, halo prefetch second, stores last).  Same per-output accumulation order (tap-major, k-chunk inner) as
-// conv3x3_c64_kernel: identical bits.
-// ---------------------------------------------------------------------------------------
-#define C3V_T 16
-#define C3V_HP ((C3V_T + 2) * (C3V_T + 2))      // 324 halo pixels
-__device__ __forceinline__ int c3v_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }   // element offset
-
-template <int NRES>       // residual tensors added in the epilogue (0: data gradient, 1: forward, 2: forward of the last block)
-__global__ void __launch_bounds__(512) conv3x3_c64_v2_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
-                                                             const float* __restrict__ bias, const bf16_t* __restrict__ res1,
-                                                             const bf16_t* __restrict__ res2, bf16_t* __restrict__ y, int B, int H,
-                                                             int W, int tiles_per_block, int xcd_order) {
-  using T = bf16_t;
-  constexpr int TOT = C3V_HP * 8, ITEMS = (TOT + 255) / 256;      // 16-byte vectors of a halo tile: 11 per thread
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* Ws = reinterpret_cast<T*>(smem);                                          // [9][64 permuted rows][64], swizzled
-  T* Xg = reinterpret_cast<T*>(smem + sizeof(T) * 9 * 64 * 64);                // [2 groups][324][64], swizzled
-  float* Bs = reinterpret_cast<float*>(smem + sizeof(T) * 64 * (9 * 64 + 2 * C3V_HP));     // bias [64]
-  const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wv = tid >> 6;
-  const int lr = lane & 15, g = lane >> 4;
-  T* Xs = Xg + grp * (C3V_HP * 64);
-  const int tw = W / C3V_T, th = H / C3V_T;
-  const int ntiles = B * th * tw;
-  const long long npix = (long long)B * H * W;                    // P64 feature maps
-  int chunk = blockIdx.x;
-  if (xcd_order) chunk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int t0 = chunk * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
-  if (t0 >= t1) return;
-  Frag8<T> f[ITEMS];
-  unsigned fvalid = 0;
-  auto fetch = [&](int t) {               // branch-free: clamped address, validity applied at the LDS store
-    const int tx = t % tw, q = t / tw;
-    const int ty = q % th;
-    const long long pb = (long long)(q / th) * H * W;
-    const int x0 = tx * C3V_T, y0 = ty * C3V_T;
-    fvalid = 0;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = tid + it * 256;
-      const int cv = idx & 7, p = min(idx >> 3, C3V_HP - 1);
-      const int py = p / (C3V_T + 2), px = p - py * (C3V_T + 2);
-      const int gy = y0 + py - 1, gx = x0 + px - 1;
-      if (idx < TOT && gy >= 0 && gy < H && gx >= 0 && gx < W) fvalid |= 1u << it;
-      const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-      f[it] = load8(x + p64(npix, pb + (long long)cy * W + cx, cv * 8));
-    }
-  };
-  M2T_CONV_STAMP(0);
-  fetch(min(t0 + grp, t1 - 1));
-  // weights: LDS row 16 nt + i of a slice holds packed row 16 (i >> 2) + 4 nt + (i & 3): the 16 rows an A-operand tile reads
-  // are then consecutive, and lane (i, g) still ends with output channels 16 g + 4 nt + r of its pixel
-  // (every load first, then the LDS stores: as a rolled load -> store loop each of the nine trips paid its own L2 round
-  //  trip and the prologue took 23 k cycles -- 40 % of the kernel)
-  {
-    Frag8<T> wr[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int idx = threadIdx.x + tap * 512;                  // one 64 x 64 slice per trip: 512 vectors
-      const int cv = idx & 7, rho = (idx >> 3) & 63;
-      const int i = rho & 15, nt = rho >> 4;
-      const int nl = 16 * (i >> 2) + 4 * nt + (i & 3);
-      wr[tap] = load8(wp + ((long long)tap * 64 + nl) * 64 + cv * 8);
-    }
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int idx = threadIdx.x + tap * 512;
-      store8(Ws + tap * 4096 + c3v_off((idx >> 3) & 63, idx & 7), wr[tap]);
-    }
-  }
-  if (threadIdx.x < 64) Bs[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
-  for (int tp = t0; tp < t1; tp += 2) {
-    const int t = tp + grp;
-    const bool live = t < t1;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int idx = tid + it * 256;
-      if (idx < TOT) store8(Xs + c3v_off(idx >> 3, idx & 7), ((fvalid >> it) & 1u) ? f[it] : frag_zero<T>());
-    }
-    lds_barrier();
-    if (tp == t0 + 2) M2T_CONV_STAMP(1);
-    const int tc = live ? t : t1 - 1;                       // (an idle group of the last pair recomputes a tile and discards it)
-    const int tx = tc % tw, q = tc / tw;
-    const int ty = q % th;
-    const long long pb = (long long)(q / th) * H * W;
-    const int x0 = tx * C3V_T, y0 = ty * C3V_T;
-    Frag8<T> r1[NRES >= 1 ? 4 : 1][2], r2[NRES >= 2 ? 4 : 1][2];
-    const long long off0 = ((long long)g * npix + pb + (long long)(y0 + 4 * wv) * W + x0 + lr) * 16;
-    const long long offs = (long long)W * 16;               // one tile row further
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      if constexpr (NRES >= 1) { r1[mt][0] = load8(res1 + off0 + mt * offs); r1[mt][1] = load8(res1 + off0 + mt * offs + 8); }
-      if constexpr (NRES >= 2) { r2[mt][0] = load8(res2 + off0 + mt * offs); r2[mt][1] = load8(res2 + off0 + mt * offs + 8); }
-    }
-    if (t + 2 < t1) fetch(t + 2);
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // (one tap per trip: fully unrolled, hipcc hoists the 144 fragment reads and spills)
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
-#pragma unroll
-      for (int kc = 0; kc < 2; ++kc) {
-        Frag8<T> xf[4], wf[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) xf[mt] = load8(Xs + c3v_off((4 * wv + mt + ky) * (C3V_T + 2) + lr + kx, kc * 4 + g));
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[nt] = load8(Ws + tap * 4096 + c3v_off(16 * nt + lr, kc * 4 + g));
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int mt = 0; mt < 4; ++mt) mma16(acc[mt][nt], wf[nt], xf[mt]);
-      }
-    }
-    if (tp == t0 + 2) M2T_CONV_STAMP(2);
-    if (live) {
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        float v[16];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
-        if (bias) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += Bs[16 * g + e];
-        }
-        if constexpr (NRES >= 1) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += r1[mt][e >> 3].get(e & 7);
-        }
-        if constexpr (NRES >= 2) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += r2[mt][e >> 3].get(e & 7);
-        }
-        store16f(y + off0 + mt * offs, v);
-      }
-    }
-    if (tp == t0 + 2) M2T_CONV_STAMP(3);
-    lds_barrier();            // both halo buffers are free for the next pair
-    if (tp == t0 + 2) M2T_CONV_STAMP(4);
-  }
-}
-
 // bf16 takes the pipelined kernel: at most this many workgroups (8 per CU: with more tiles a workgroup walks several)
 constexpr int C3_PIPE_MAX_BLOCKS = 2048;
-constexpr int C3_WREG_BLOCKS = 512;      // the register-resident-weights kernel: 2 workgroups per CU
 
 int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias, const void* res1, const void* res2,
-                       void* y, int B, int H, int W, hipStream_t st, bool persistent, int variant) {
+                       void* y, int B, int H, int W, hipStream_t st) {
   if (H % C3_TH || W % C3_TW) return m2t_set_error(-2, "conv3x3_c64: H%8 or W%16");
   const long long ntiles = (long long)B * (H / C3_TH) * (W / C3_TW);
-  if (dt != M2T_F32 && persistent && ntiles >= 512) {
-    const size_t sh = sizeof(bf16_t) * C3_LD * (9 * 64 + 2 * (C3_TH + 2) * (C3_TW + 2));   // weights + one halo tile per wave group
-    if (int rc__ = m2t_ensure_dynamic_lds((const void*)conv3x3_c64_persistent_kernel, (int)sh)) return rc__;
-    int nblk = 256;
-    const int tpb = (int)ceil_divll(ntiles, nblk);
-    nblk = (int)ceil_divll(ntiles, tpb);
-    M2T_LAUNCH_TIMED(conv3x3_c64_persistent_kernel, dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
-                       (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, B, H, W, tpb);
-    M2T_LAUNCH_CHECK();
-    return 0;
-  }
-  if (dt != M2T_F32 && variant == 2 && H % C3V_T == 0 && W % C3V_T == 0 && (long long)B * (H / C3V_T) * (W / C3V_T) >= 512) {
-    // v2: 16 x 16 tiles, 4 x 4 register blocking, swizzled LDS, weights resident; one 8-wave workgroup per CU
-    const int nt16 = B * (H / C3V_T) * (W / C3V_T);
-    int tpb = ceil_div(nt16, 256);
-    tpb += tpb & 1;                                          // whole pairs
-    const int nblk = ceil_div(nt16, tpb);
-    const int xcd_order = (nblk % 8 == 0 && nblk * tpb == nt16) ? 1 : 0;
-    const size_t sh = sizeof(bf16_t) * 64 * (9 * 64 + 2 * C3V_HP) + 64 * sizeof(float);
-    if (res2 && !res1) return m2t_set_error(-2, "conv3x3_c64: res2 without res1");
-#define GO_V2(N_)                                                                                                          \
-    {                                                                                                                      \
-      if (int rc__ = m2t_ensure_dynamic_lds((const void*)conv3x3_c64_v2_kernel<N_>, (int)sh)) return rc__;                 \
-      M2T_LAUNCH_TIMED(conv3x3_c64_v2_kernel<N_>, dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias, \
-                       (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, B, H, W, tpb, xcd_order);                     \
-    }
-    if (res2) GO_V2(2) else if (res1) GO_V2(1) else GO_V2(0)
-#undef GO_V2
-    M2T_LAUNCH_CHECK();
-    return 0;
-  }
-  if (dt != M2T_F32 && variant == 0 && ntiles >= 1024) {
-    // weights register-resident, two workgroups per CU, each walking >= 2 tiles
-    const int tpb = (int)ceil_divll(ntiles, C3_WREG_BLOCKS);
-    const int nblk = (int)ceil_divll(ntiles, tpb);
-    const int xcd_order = (nblk % 8 == 0 && (long long)nblk * tpb == ntiles) ? 1 : 0;
-    M2T_LAUNCH_TIMED(conv3x3_c64_wreg_kernel, dim3(nblk), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
-                     (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, B, H, W, tpb, xcd_order);
-    M2T_LAUNCH_CHECK();
-    return 0;
-  }
   if (dt != M2T_F32) {
     const int tpb = (int)ceil_divll(ntiles, C3_PIPE_MAX_BLOCKS);
     const int nblk = (int)ceil_divll(ntiles, tpb);

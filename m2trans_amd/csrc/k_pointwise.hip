@@ -280,108 +280,7 @@ __global__ void __launch_bounds__(64) instnorm_stats2_kernel(const float* __rest
   mean[b * 64 + ch] = r.mean;
   rstd[b * 64 + ch] = 1.0f / sqrtf(r.m2 / r.n + eps);   // biased variance
 }
-// ---------------------------------------------------------------------------------------
-// Single-stage variant: ONE 512-thread workgroup per (image, 16-channel chunk plane) -- a dense [P][16] run of the P64
-// layout -- so mean / rstd come out of the same launch (no partials, no second kernel on the critical path of every
-// block).  64 workgroups at batch 16 stream 0.5 MB each with 256 B per lane in flight; the 33.5 MB map was just written
-// by the conv, so most of it is still in L2 / MALL.  Same two-pass batches of 16 pixels per thread and division-free
-// block merge as stage 1 above.  Option norm_single_stage; measured SLOWER at batch 16 (see norm_single_stage()).
-// ---------------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(512) instnorm_stats_whole_kernel(const T* __restrict__ x, float* __restrict__ mean,
-                                                                    float* __restrict__ rstd, int P, float eps) {
-  const int k = blockIdx.x, b = blockIdx.y;
-  const long long npix = (long long)gridDim.y * P;
-  const T* base = x + ((long long)k * npix + (long long)b * P) * 16;
-  const int half = threadIdx.x & 1, pl = threadIdx.x >> 1;   // 256 pixel lanes x 2 channel halves
-  Wf w[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) { w[c].n = 0.f; w[c].mean = 0.f; w[c].m2 = 0.f; }
-  for (int pb = pl; pb < P; pb += 256 * 16) {
-    float v[16][8];
-    int cnt = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int p = pb + 256 * i;                 // branch-free: a load under a lane-dependent branch is waited for on the spot
-      load8f(base + (long long)min(p, P - 1) * 16 + half * 8, v[i]);
-      if (p < P) ++cnt;
-      else {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[i][c] = 0.f;
-      }
-    }
-    const float fn = (float)cnt, inv = 1.0f / fn;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sum += v[i][c];
-      Wf q; q.n = fn; q.mean = sum * inv; q.m2 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { const float d = v[i][c] - q.mean; q.m2 += (i < cnt) ? d * d : 0.f; }
-      w[c] = wf_merge(w[c], q);
-    }
-  }
-  __shared__ float sh[2][8][2][8];
-  const int wvi = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float nn[8], nm[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    nn[c] = w[c].n; nm[c] = w[c].n * w[c].mean;
-#pragma unroll
-    for (int o = 2; o < 64; o <<= 1) { nn[c] += __shfl_xor(nn[c], o); nm[c] += __shfl_xor(nm[c], o); }
-  }
-  if (lane < 2) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { sh[0][wvi][half][c] = nn[c]; sh[1][wvi][half][c] = nm[c]; }
-  }
-  __syncthreads();
-  float N[8], mean_b[8], dev[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    float a = 0.f, m = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { a += sh[0][q][half][c]; m += sh[1][q][half][c]; }
-    N[c] = a;
-    mean_b[c] = m / fmaxf(a, 1.f);
-    const float d = w[c].mean - mean_b[c];
-    dev[c] = w[c].m2 + w[c].n * d * d;
-#pragma unroll
-    for (int o = 2; o < 64; o <<= 1) dev[c] += __shfl_xor(dev[c], o);
-  }
-  __syncthreads();
-  if (lane < 2) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) sh[0][wvi][half][c] = dev[c];
-  }
-  __syncthreads();
-  if (threadIdx.x < 2) {             // thread = channel half; its own N / mean_b are the chunk totals of that half
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float m2 = 0.f;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) m2 += sh[0][q][half][c];
-      const int ch = b * 64 + k * 16 + half * 8 + c;
-      mean[ch] = mean_b[c];
-      rstd[ch] = 1.0f / sqrtf(m2 / N[c] + eps);   // biased variance
-    }
-  }
-}
-// mode: -1 default (= two-stage), else a bit mask: 1 = statistics single-stage, 2 = backward sums single-stage.
-// Measured at batch 16 / 128x128 (64 workgroups of 0.5 / 1 MB): +15 us (statistics) and +21 us (backward sums) PER LAUNCH
-// against the two-stage path (step 5.76 / 5.81 vs 5.64 ms): 64 CUs cannot pull a 33 MB map as fast as 512 workgroups on
-// 256 CUs, and the saved 5 us fold kernel does not pay for it.  Kept as an option for larger batches per GPU.
-static bool norm_single_stage(int mode, int bit, int B, int P, size_t es) {
-  (void)B; (void)P; (void)es;
-  return mode >= 0 && (mode & bit) != 0;
-}
-int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float* part, int B, int P, hipStream_t st, int single_stage) {
-  if (norm_single_stage(single_stage, 1, B, P, dt == M2T_F32 ? 4 : 2)) {
-    if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_stats_whole_kernel<float>, dim3(4, B), dim3(512), 0, st, (const float*)x, mean, rstd, P, 1e-5f);
-    else hipLaunchKernelGGL(instnorm_stats_whole_kernel<bf16_t>, dim3(4, B), dim3(512), 0, st, (const bf16_t*)x, mean, rstd, P, 1e-5f);
-    M2T_LAUNCH_CHECK();
-    return 0;
-  }
+int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float* part, int B, int P, hipStream_t st) {
   const int nsplit = M2T_NORM_SPLIT;
   if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_stats1_kernel<float>, dim3(nsplit, B), dim3(256), 0, st, (const float*)x, part, P, nsplit);
   else hipLaunchKernelGGL(instnorm_stats1_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, st, (const bf16_t*)x, part, P, nsplit);
@@ -865,135 +764,15 @@ __global__ void __launch_bounds__(256) instnorm_bwd_apply_kernel(const T* __rest
     store8f(gx + o64, r);
   }
 }
-// apply with the second reduction stage folded in: every workgroup of image b first folds the 32 partials of the 64
-// channels itself (64 threads, all loads in flight at once, the SAME fixed tree as instnorm_bwd_red2_kernel -> identical
-// bits) and keeps mean / rstd / s in LDS; saves the 5 us fold launch and its gap on the critical path of every block.
-template <typename T>
-__global__ void __launch_bounds__(256) instnorm_bwd_apply_fold_kernel(const T* __restrict__ gn, const T* __restrict__ x,
-                                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                      const float* __restrict__ part, const T* __restrict__ gres,
-                                                                      T* __restrict__ gx, int B, int P, int nsplit, float invP) {
-  static_assert(M2T_NORM_SPLIT == 32, "the fixed tree below is written for 32 partials");
-  __shared__ float cs[64][4];                     // mean, rstd, s1, s2
-  const int b = blockIdx.y;
-  if (threadIdx.x < 64) {
-    const int ch = threadIdx.x;
-    const float* o = part + ((long long)b * nsplit * 64 + ch) * 2;
-    float2 v[M2T_NORM_SPLIT];
-#pragma unroll
-    for (int q = 0; q < M2T_NORM_SPLIT; ++q)
-      v[q] = (q < nsplit) ? *reinterpret_cast<const float2*>(o + (long long)q * 128) : make_float2(0.f, 0.f);
-#pragma unroll
-    for (int st = 1; st < M2T_NORM_SPLIT; st <<= 1)
-#pragma unroll
-      for (int q = 0; q < M2T_NORM_SPLIT; q += 2 * st) { v[q].x += v[q + st].x; v[q].y += v[q + st].y; }
-    cs[ch][0] = mean[b * 64 + ch];
-    cs[ch][1] = rstd[b * 64 + ch];
-    cs[ch][2] = v[0].x * invP;
-    cs[ch][3] = v[0].y * invP;
-  }
-  __syncthreads();
-  const long long npix = (long long)B * P;
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < P * 8; t += gridDim.x * blockDim.x) {
-    const int cgp = t & 7;
-    const int pix = b * P + (t >> 3);
-    float g[8], v[8], r[8];
-    const long long o64 = p64(npix, pix, cgp * 8);
-    load8f(gn + o64, g);
-    load8f(x + o64, v);
-    load8f(gres + o64, r);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const float* k4 = cs[cgp * 8 + c];
-      const float rs = k4[1];
-      const float xh = (v[c] - k4[0]) * rs;
-      r[c] += rs * (g[c] - k4[2] - xh * k4[3]);
-    }
-    store8f(gx + o64, r);
-  }
-}
-// single-stage reduction (see instnorm_stats_whole_kernel): one 512-thread workgroup per (image, chunk plane) sums
-// g_n and g_n * xhat over the P pixels and writes s = (mean_p g_n, mean_p g_n xhat) directly
-template <typename T>
-__global__ void __launch_bounds__(512) instnorm_bwd_red_whole_kernel(const T* __restrict__ gn, const T* __restrict__ x,
-                                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                      float* __restrict__ s, int P, float invP) {
-  const int k = blockIdx.x, b = blockIdx.y;
-  const long long npix = (long long)gridDim.y * P;
-  const long long off = ((long long)k * npix + (long long)b * P) * 16;
-  const int half = threadIdx.x & 1, pl = threadIdx.x >> 1;
-  float mu[8], rs[8], s1[8], s2[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    mu[c] = mean[b * 64 + k * 16 + half * 8 + c]; rs[c] = rstd[b * 64 + k * 16 + half * 8 + c];
-    s1[c] = 0.f; s2[c] = 0.f;
-  }
-  int p = pl;
-  for (; p + 256 * 7 < P; p += 256 * 8) {          // eight pixels per trip: sixteen 16-byte loads in flight per lane
-    float g[8][8], v[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      load8f(gn + off + (long long)(p + 256 * i) * 16 + half * 8, g[i]);
-      load8f(x + off + (long long)(p + 256 * i) * 16 + half * 8, v[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { s1[c] += g[i][c]; s2[c] += g[i][c] * ((v[i][c] - mu[c]) * rs[c]); }
-  }
-  for (; p < P; p += 256) {
-    float g[8], v[8];
-    load8f(gn + off + (long long)p * 16 + half * 8, g);
-    load8f(x + off + (long long)p * 16 + half * 8, v);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { s1[c] += g[c]; s2[c] += g[c] * ((v[c] - mu[c]) * rs[c]); }
-  }
-  __shared__ float sh[8][2][8][2];
-  const int wvi = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-#pragma unroll
-    for (int o = 2; o < 64; o <<= 1) { s1[c] += __shfl_xor(s1[c], o); s2[c] += __shfl_xor(s2[c], o); }
-  }
-  if (lane < 2) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { sh[wvi][half][c][0] = s1[c]; sh[wvi][half][c][1] = s2[c]; }
-  }
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    const int h2 = threadIdx.x >> 3, c = threadIdx.x & 7;
-    float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { a1 += sh[q][h2][c][0]; a2 += sh[q][h2][c][1]; }
-    const int ch = b * 64 + k * 16 + threadIdx.x;
-    s[ch * 2 + 0] = a1 * invP;
-    s[ch * 2 + 1] = a2 * invP;
-  }
-}
 int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean, const float* rstd, const void* gres,
-                        void* gx, float* part, float* s, int B, int P, hipStream_t st, int single_stage) {
+                        void* gx, float* part, float* s, int B, int P, hipStream_t st) {
   if ((long long)B * P * 8 >= (1LL << 31)) return m2t_set_error(-2, "instnorm_bwd: B*P too large for 32-bit indexing");
   const int nsplit = M2T_NORM_SPLIT;
-  if (norm_single_stage(single_stage, 2, B, 2 * P, dt == M2T_F32 ? 4 : 2)) {
-    if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_red_whole_kernel<float>, dim3(4, B), dim3(512), 0, st, (const float*)gn, (const float*)x, mean, rstd, s, P, 1.0f / (float)P);
-    else hipLaunchKernelGGL(instnorm_bwd_red_whole_kernel<bf16_t>, dim3(4, B), dim3(512), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, s, P, 1.0f / (float)P);
-    M2T_LAUNCH_CHECK();
-  } else {
   if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_red1_kernel<float>, dim3(nsplit, B), dim3(256), 0, st, (const float*)gn, (const float*)x, mean, rstd, part, P, nsplit);
   else hipLaunchKernelGGL(instnorm_bwd_red1_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, part, P, nsplit);
   M2T_LAUNCH_CHECK();
-  if (single_stage >= 0 && (single_stage & 4)) {
-    // option bit 2: the fold rides in the apply kernel.  Measured SLOWER (5.64 vs 5.56 ms per step): the 1024-workgroup
-    // apply with its 16 KB prologue per workgroup loses more than the 5 us launch it saves; default is the separate fold.
-    const int gx_ = std::max(1, std::min(ceil_div(P * 8, 256), std::max(1024 / std::max(B, 1), 8)));   // ~1024 workgroups: the prologue re-reads 16 KB of partials each
-    if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_apply_fold_kernel<float>, dim3(gx_, B), dim3(256), 0, st, (const float*)gn, (const float*)x, mean, rstd, part, (const float*)gres, (float*)gx, B, P, nsplit, 1.0f / (float)P);
-    else hipLaunchKernelGGL(instnorm_bwd_apply_fold_kernel<bf16_t>, dim3(gx_, B), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, part, (const bf16_t*)gres, (bf16_t*)gx, B, P, nsplit, 1.0f / (float)P);
-    M2T_LAUNCH_CHECK();
-    return 0;
-  }
   hipLaunchKernelGGL(instnorm_bwd_red2_kernel, dim3(B), dim3(64), 0, st, part, s, nsplit, 1.0f / (float)P);
   M2T_LAUNCH_CHECK();
-  }
   const int g = grid_for((long long)B * P * 8);
   if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)gn, (const float*)x, mean, rstd, s, (const float*)gres, (float*)gx, B, P);
   else hipLaunchKernelGGL(instnorm_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, s, (const bf16_t*)gres, (bf16_t*)gx, B, P);

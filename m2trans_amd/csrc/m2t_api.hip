@@ -34,54 +34,73 @@ int m2t_ensure_dynamic_lds(const void* kernel, int bytes) {
 }
 
 // ---- optional per-kernel timing with HIP events on the launch stream -------------------------
+// The enable mask and the event pool are process-wide (an atomic and a mutex-protected pool): the C ABI is entered from
+// the caller's thread for m2t_forward and from the autograd engine's worker thread for m2t_backward (model(x);
+// loss.backward()), and both must land in the same table.  Only the "a dispatch-timed scope is open" state is per thread.
+#include <atomic>
+#include <mutex>
 namespace {
 struct ProfRec { hipEvent_t a, b; int cat; };
 struct ProfState {
-  unsigned long long mask = 0;
+  std::atomic<unsigned long long> mask{0};
+  std::mutex mu;
   std::vector<ProfRec> pool;
   size_t used = 0;
-  bool open = false, taken = false;      // a dispatch-timed scope is open / its events went out with a launch
 };
-thread_local ProfState g_prof;           // per calling thread, like the error string: no process-global mutable state
+ProfState g_prof;
+struct ProfOpen { long long slot = -1; bool taken = false; };
+thread_local ProfOpen g_open;             // the record of the scope this thread has open
+long long prof_claim(int cat) {           // next free record, or -1 (mask off / pool exhausted)
+  if (!((g_prof.mask.load(std::memory_order_relaxed) >> cat) & 1ull)) return -1;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  if (g_prof.used >= g_prof.pool.size()) return -1;
+  g_prof.pool[g_prof.used].cat = -1;      // becomes `cat` once both events are on a stream
+  return (long long)g_prof.used++;
+}
 }
 void m2t_prof_begin(int cat, hipStream_t st) {
-  if (!((g_prof.mask >> cat) & 1ull) || g_prof.used >= g_prof.pool.size()) return;
-  ProfRec& r = g_prof.pool[g_prof.used];
-  r.cat = cat;
-  if ((M2T_PROF_DISPATCH_CATS >> cat) & 1ull) { g_prof.open = true; g_prof.taken = false; return; }
-  (void)hipEventRecord(r.a, st);
+  g_open.slot = prof_claim(cat);
+  g_open.taken = false;
+  if (g_open.slot < 0) return;
+  if ((M2T_PROF_DISPATCH_CATS >> cat) & 1ull) return;           // the launcher takes the events (m2t_prof_take)
+  (void)hipEventRecord(g_prof.pool[(size_t)g_open.slot].a, st);
 }
 bool m2t_prof_take(hipEvent_t* a, hipEvent_t* b) {
-  if (!g_prof.open || g_prof.taken) return false;
-  g_prof.taken = true;
-  *a = g_prof.pool[g_prof.used].a; *b = g_prof.pool[g_prof.used].b;
+  if (g_open.slot < 0 || g_open.taken) return false;
+  g_open.taken = true;
+  *a = g_prof.pool[(size_t)g_open.slot].a; *b = g_prof.pool[(size_t)g_open.slot].b;
   return true;
 }
 void m2t_prof_end(int cat, hipStream_t st) {
-  if (!((g_prof.mask >> cat) & 1ull) || g_prof.used >= g_prof.pool.size()) return;
+  if (g_open.slot < 0) return;
+  ProfRec& r = g_prof.pool[(size_t)g_open.slot];
   if ((M2T_PROF_DISPATCH_CATS >> cat) & 1ull) {
-    if (g_prof.open && g_prof.taken) ++g_prof.used;     // a scope whose launcher did not take the events is dropped
-    g_prof.open = g_prof.taken = false;
-    return;
+    if (g_open.taken) r.cat = cat;         // a scope whose launcher did not take the events stays unlabelled (dropped)
+  } else {
+    (void)hipEventRecord(r.b, st);
+    r.cat = cat;
   }
-  (void)hipEventRecord(g_prof.pool[g_prof.used].b, st);
-  ++g_prof.used;
+  g_open.slot = -1;
+  g_open.taken = false;
 }
 extern "C" int m2t_profile_enable(unsigned long long category_mask) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
   if (category_mask && g_prof.pool.empty()) {
     g_prof.pool.resize(16384);
     for (auto& r : g_prof.pool) {
       if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess)
         return m2t_set_error(M2T_ERR_STATE, "m2t_profile_enable: hipEventCreate failed");
+      r.cat = -1;
     }
   }
-  g_prof.mask = category_mask;
+  g_prof.mask.store(category_mask, std::memory_order_relaxed);
   g_prof.used = 0;
   return 0;
 }
-// total milliseconds and launch count of one category since m2t_profile_enable; the caller must
-// have synchronised the stream
+// total milliseconds and launch count of one category since m2t_profile_enable, over every thread that launched; the
+// caller must have synchronised the streams
 extern "C" int m2t_profile_read(int cat, double* total_ms, long long* count) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
   double t = 0.0; long long n = 0;
   for (size_t i = 0; i < g_prof.used; ++i) {
     if (g_prof.pool[i].cat != cat) continue;
@@ -111,34 +130,17 @@ struct m2t_plan {
   std::map<std::string, long long> pk;       // packed weight offsets (elements of T)
   long long npacked = 0;
   bool have_seed = false, have_acts = false;
+  // ---- options (m2t_set_option; include/m2t.h documents each) ----
   bool use_side = true;
-  bool debug_skip_side = false;    // timing experiments only: skip every parameter-gradient kernel (results are WRONG)      // halo gather + qkv dgrad GEMM + prep_bwd as one kernel (k_branch.hip)
-  bool use_persistent_conv = false;  // bf16 conv3x3 with LDS-resident weights: bit-identical, measured a tie (see k_conv.hip)
-  bool use_fused_tail_bwd = true;  // x4 bf16: k_tail_bwd.hip instead of four HR kernels
-  bool tail_wgrad_main = false;    // tail weight gradients on the side stream (same-box A/B: +0.5 % over the main stream)
-  int gate_branch = 1;             // 1: after the C = 256, C = 256 and C = 64 attention launches of the block.  Round 1 (GEMM + halo gather on
-                                   // the main chain): 2 was best (6.17 ms against 6.24 for 0, 6.34 for 3, 6.23 ungated); with the projection
-                                   // data gradient inside the (longer, LDS-filling) attention kernels: 1 = 5.49 ms, 2 = 5.60, 3 = 5.62, 0 = 5.68,
-                                   // ungated 5.64 (config 1; +1 % at batch 32 as well)
-  bool use_gated_side = true;      // see the side-stream schedule in m2t_backward
-  int side_conv_pos = 1;           // the block's conv weight gradient: 0 first at the gate, 1 after the gated branches (same-box A/B:
-                                   // +1.9 % over 0: the 512-thread, LDS-heavy kernel then meets the C = 16 instead of the C = 64 attention), 2 after the last attention (+1.8 %)
+  bool debug_skip_side = false;        // timing experiments only: skip every parameter-gradient kernel (results are WRONG)
+  bool use_fused_tail_bwd = true;      // x4 bf16: k_tail_bwd.hip instead of four HR kernels
+  bool use_fused_tail_fwd = false;     // x4 bf16: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored
+  int gate_branch = 1;                 // side-stream gate: -1 ungated, else the branch (3..0) behind whose attention launch a block's
+                                       // parameter-gradient work is released.  Same-box A/B (config 1): 1 = 5.49 ms, 2 = 5.60, 3 = 5.62,
+                                       // 0 = 5.68, ungated 5.64
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
-  bool use_fused_tail_fwd = false;     // bf16 x4: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored;
-                                       // the fused tail backward then recomputes them (needs fused_tail_bwd).  Bit-identical and
-                                       // 1.6 GB less HBM traffic per step, but SLOWER (same-box A/B 5.73 vs 5.67 ms): the erf behind
-                                       // GELU is paid 1.56x (halo) in the forward and again in the backward (389 + 426 us against
-                                       // 280 + 170 + 340 us), and a stored bf16 is cheaper to re-read than an erf is to re-evaluate
-  int conv_variant = 1;                // bf16 conv3x3: 1 = tap-pipelined kernel, 0 = weight slices register-resident (conv3x3_c64_wreg_kernel:
-                                       // bit-identical; same-box A/B 5.73 vs 5.69 ms per step, i.e. no gain: kept as an option)
-  int norm_single_stage = 0;           // InstanceNorm reductions: bit 0 / bit 1 = forward statistics / backward sums by one workgroup per (image, chunk)
-  bool fused_dgrad_gather_in_prep = true;   // ring rows of the fused data gradient added by branch_prep_bwd on load (0: separate gather launch)
-  bool last_block_conv_first = false;  // see the gate in m2t_backward (measured: 5.51 vs 5.48 ms, neutral at batch 32)
-  int side_priority = 0;               // stream priority of the side stream: 0 default, 1 lowest, -1 highest (set before the first m2t_backward)
-  int wgrad_big_tiles = -1;            // C = 256 qkv weight gradient: 128 x 128 output tiles instead of 64 x 64 (k_gemm.hip); value = target
-                                       // workgroups, 0 = off, -1 = auto: 256 from 24 576 rows on (batch 32: 9.82 vs 9.93 ms; batch 16: 5.53 vs 5.49)
-  bool merged_rel_reduce = false;      // the rel-pos partial reductions of a block's four branches in one launch: measured SLOWER (5.48 vs 5.44 ms; batch 32: 10.03 vs 9.85)
-  bool use_fused_c16_dgrad = false;    // ... and inside the wave-per-window C = 16 backward kernel (k_attn_c16.hip): a tie at batch 16, -0.3 % at batch 32
+  int wgrad_big_tiles = -1;            // C = 256 qkv weight gradient: 128 x 128 output tiles (k_gemm.hip); value = target workgroups,
+                                       // 0 = off, -1 = auto: 256 from 24 576 rows on (batch 32: 9.82 vs 9.93 ms; batch 16: 5.53 vs 5.49)
   bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside the attention backward kernel (k_attn_res.hip)
   bool use_fused_c16_fwd = true;       // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip)
   bool use_fused_attn_fwd = true;      // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip)
@@ -152,28 +154,11 @@ struct m2t_plan {
   // (tail, block pairs from the last to the first, head); one event each, recorded behind the bucket's reduction
   std::vector<std::pair<long long, long long>> buckets;
   std::vector<hipEvent_t> bucket_events;
-  int side_cus = 0;                // CUs the side stream may use (0 = all; masking measured slower: 9.1-20 ms vs 8.7 ms)
   std::vector<hipEvent_t> events;
-  int ensure_side(hipStream_t caller) {
+  int ensure_side(hipStream_t) {
     if (side) return 0;
-    // The parameter-gradient kernels are filler.  They run on a CU-masked stream (side_cus of the chip's CUs; the
-    // mask bits interleave over the XCDs) so that main-chain workgroups always find empty CUs: a 160 KB-LDS
-    // attention workgroup otherwise starves until a concurrent wgrad kernel has drained completely.
-    int ncu = 0, dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    const char* ev = getenv("M2T_SIDE_CUS");
-    int cus = ev ? atoi(ev) : side_cus;
-    // (a CU-masked stream is a BLOCKING stream: against the legacy default stream it would serialise)
-    if (cus > 0 && cus < ncu && caller != nullptr) {
-      std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
-      for (int i = 0; i < cus; ++i) mask[i / 32] |= 1u << (i % 32);
-      if (hipExtStreamCreateWithCUMask(&side, (uint32_t)mask.size(), mask.data()) != hipSuccess) return -1;
-    } else if (side_priority != 0) {
-      int lo = 0, hi = 0;                          // (numerically larger = lower priority)
-      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-      if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, side_priority > 0 ? lo : hi) != hipSuccess) return -1;
-    } else if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return -1;
+    // (a CU-masked side stream and stream priorities were both measured and are slower: profiles/README.md, round 2)
+    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return -1;
     events.resize(192);
     for (auto& e : events)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
@@ -316,7 +301,6 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
     p->add_ws("gqkv" + std::to_string(i), BP * 48, es);
     p->add_ws("win" + std::to_string(i), BP * 50, es);
     p->add_ws("relw" + std::to_string(i), (size_t)(BP / 64) * 10 * 16, 4);
-    p->add_ws("relwB" + std::to_string(i), (size_t)(BP / 64) * 10 * 16, 4);   // odd blocks: the merged rel-pos reduction of a block may lag into the next one
   }
   p->add_ws("rel_part", 32 * 10 * 256, 4);
   {
@@ -374,6 +358,20 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
   if (k.rfind("wsn:", 0) == 0) { auto it = p->ws.find(k.substr(4)); return it == p->ws.end() ? -1 : (long long)it->second.n; }
   if (k.rfind("packed:", 0) == 0) { auto it = p->pk.find(k.substr(7)); return it == p->pk.end() ? -1 : it->second; }
   // which stored tensors the current options leave unwritten (tests read the workspace by name)
+  if (k.rfind("opt:", 0) == 0) {        // the options in force (profile.py prices the kernels that actually run)
+    const std::string o = k.substr(4);
+    if (o == "side_stream") return p->use_side;
+    if (o == "gate_branch") return p->gate_branch + 1000;      // (offset: -1 is the "unknown key" value of this function)
+    if (o == "wgrad_big_tiles") return p->wgrad_big_tiles + 1000;
+    if (o == "fused_tail_bwd") return p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
+    if (o == "fused_tail_fwd") return p->use_fused_tail_fwd && p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
+    if (o == "resident_attn_bwd") return p->use_resident_attn_bwd && p->dt != M2T_F32;
+    if (o == "fused_attn_fwd") return p->use_fused_attn_fwd && p->dt != M2T_F32;
+    if (o == "fused_c16_fwd") return p->use_fused_c16_fwd && p->dt != M2T_F32;
+    if (o == "fused_qkv_dgrad") return p->use_fused_qkv_dgrad && p->use_resident_attn_bwd && p->dt != M2T_F32;
+    if (o == "debug_skip_side") return p->debug_skip_side;
+    return -1;
+  }
   if (k == "stores_t2") return (p->scale == 4 && !(p->dt != M2T_F32 && p->use_fused_tail_fwd && p->use_fused_tail_bwd)) ? 1 : 0;
   return -1;
 }
@@ -414,7 +412,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     float* mean = (float*)WSP(k + "mean");
     float* rstd = (float*)WSP(k + "rstd");
     void* xc = WSP(k + "xc");
-    CK(launch_instnorm_stats(dt, X, mean, rstd, (float*)WSP("norm_part"), B, (int)p->P, st, p->norm_single_stage));
+    CK(launch_instnorm_stats(dt, X, mean, rstd, (float*)WSP("norm_part"), B, (int)p->P, st));
     for (int i = 0; i < 4; ++i) {
       const int C = BR_C[i], L = BR_L[i];
       const int h = H >> L, w = W >> L;
@@ -454,7 +452,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     // x = feed_forward(xc) + x (:164); the last block also folds in `res + x` (:70)
     { M2TProfScope ps(M2T_PROF_CONV3_FWD, st);
       CK(launch_conv3x3_c64(dt, xc, packed_ptr(p, workspace, k + "wf"), params + p->poff.at(pre + "feed_forward.0.bias"), X,
-                            (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st, p->use_persistent_conv, p->conv_variant)); }
+                            (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st)); }
   }
   void* Y = WSP("X" + std::to_string(p->nb));
   const int r0 = (s == 4) ? 2 : s;
@@ -603,9 +601,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   const void* last_der = (s == 4) ? WSP("t2der") : WSP("t1der");
   void* g_last = (s == 4) ? WSP("g_t2pre") : WSP("g_t1pre");
   const bool skip = p->debug_skip_side;
-  // the tail's three weight-gradient kernels stream the high-resolution tensors at HBM speed, like the main-chain
-  // kernels they would overlap with: on the main stream they cost the same wall time and are not slowed 2-3x
-  hipStream_t tws = p->tail_wgrad_main ? st : sd;
+  hipStream_t tws = sd;      // tail weight gradients: side stream (same-box A/B: +0.5 % over the main stream)
   fork();
   if (!skip) CK(launch_head_im2col(dt, x, WSP("head_cols"), B, p->H0, p->W0, H, W, sd));
   const bool fused_tail = p->use_fused_tail_bwd && s == 4 && dt != M2T_F32;
@@ -669,16 +665,14 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     ga.M = BP; ga.N = 64; ga.K = N0; ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_PLAIN, ga, st)); }
   }
-  if (p->tail_wgrad_main || fused_tail) fork();     // the reduction (side stream) follows the main-stream producers
+  if (fused_tail) fork();     // the reduction (side stream) follows the main-stream producer
   CK(flush());
   mark_bucket();
   // ---- body, last block first.  gy = gradient of X[b+1] ----
   void* gy = WSP("gT");
   void* gnext[2] = {WSP("gA"), WSP("gB")};
   void* gqkv_buf[4] = {WSP("gqkv0"), WSP("gqkv1"), WSP("gqkv2"), WSP("gqkv3")};
-  float* relw_set[2][4] = {{(float*)WSP("relw0"), (float*)WSP("relw1"), (float*)WSP("relw2"), (float*)WSP("relw3")},
-                           {(float*)WSP("relwB0"), (float*)WSP("relwB1"), (float*)WSP("relwB2"), (float*)WSP("relwB3")}};
-  hipEvent_t rel_done[2] = {nullptr, nullptr};      // the merged rel-pos reduction that last read relw_set[parity] has run
+  float* relw_buf[4] = {(float*)WSP("relw0"), (float*)WSP("relw1"), (float*)WSP("relw2"), (float*)WSP("relw3")};
   void* win_buf[4] = {WSP("win0"), WSP("win1"), WSP("win2"), WSP("win3")};
   hipEvent_t branch_done[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t conv_done_prev = nullptr;      // side finished reading gy of the previously processed block
@@ -689,7 +683,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   // (default 2 = behind both C = 256 launches): the conv / qkv weight gradients then run under the halo gathers, the
   // C = 64 / C = 16 attention (which lose less than the step gains), the data-gradient GEMMs and the norm backward.  Each branch has its own gqkv / win / relw
   // buffers, so the lag is harmless.
-  const bool gated = p->use_gated_side && sd != st;
+  const bool gated = p->gate_branch >= 0 && sd != st;
   const int gate = p->gate_branch;          // branch index after whose attention launch the block's side work is released
   for (int b = p->nb - 1; b >= 0; --b) {
     const std::string k = "b" + std::to_string(b) + ".";
@@ -701,9 +695,6 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     void* gxc = WSP("gxc");
     void* gn = WSP("gn");
     void* gy_blk = gy;
-    float** relw_buf = relw_set[b & 1];
-    const bool merged_rel = p->merged_rel_reduce;
-    m2t_rel_desc4 rel_descs{};
     // feed_forward conv: weight / bias gradients on the side stream, data gradient on the main one
     auto side_conv = [&]() -> int {
       if (skip) return 0;
@@ -715,7 +706,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       return 0;
     };
     auto fused_dgrad = [&](int i) -> bool {    // projection data gradient inside the attention backward kernel (k_attn_res.hip)
-      return dt != M2T_F32 && p->use_fused_qkv_dgrad && p->use_resident_attn_bwd && (BR_C[i] >= 64 || p->use_fused_c16_dgrad);
+      return dt != M2T_F32 && p->use_fused_qkv_dgrad && p->use_resident_attn_bwd && BR_C[i] >= 64;
     };
     auto side_branch = [&](int i) -> int {     // qkv weight gradient + rel-pos partial reduction of branch i
       if (skip) return 0;
@@ -734,15 +725,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       defer(slabs, p->poff.at(an + "qkv_conv.weight"), ns, 3LL * C * C, 0, 0, 0, 0);
       ARENA(relp, (size_t)32 * 10 * C);
       int nsp = 0;
-      if (merged_rel) {
-        // one launch for the block's four branches, issued with the last one (i = 0); each block parity has its own relw set
-        m2t_rel_desc& rd = rel_descs.d[i];
-        rel_reduce1_plan((int)(M / 64), C, &rd);
-        rd.relw = relw_buf[i]; rd.part = relp; nsp = rd.nsplit;
-        if (i == 0) { CK(launch_rel_reduce1_multi(rel_descs, 4, sd)); rel_done[b & 1] = side_marker(); }
-      } else {
-        CK(launch_rel_reduce1(relw_buf[i], relp, (int)(M / 64), C, &nsp, sd));
-      }
+      CK(launch_rel_reduce1(relw_buf[i], relp, (int)(M / 64), C, &nsp, sd));
       defer(relp, p->poff.at(an + "rel_h"), nsp, 10LL * C, 4, C, 0, 0);     // rel_h then rel_w are adjacent parameters
       return 0;
     };
@@ -752,7 +735,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       CK(side_conv());
       conv_done = side_marker();
     }
-    { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st, p->use_persistent_conv, p->conv_variant)); }
+    { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st)); }
     for (int i = 3; i >= 0; --i) {
       const int C = BR_C[i], L = BR_L[i];
       const int h = H >> L, w = W >> L;
@@ -765,18 +748,13 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       void* win = win_buf[i];
       float* relw = relw_buf[i];
       main_wait(branch_done[i]);             // the side consumers of this branch's buffers (previous block) are done
-      if (merged_rel && i == 3) { main_wait(rel_done[b & 1]); rel_done[b & 1] = nullptr; }   // ... and of this parity's relw set (two blocks ago)
       // gradient of IWT^L is DWT^L: applied while the kernel loads g_xc[chunk i]
       // dK|dV stay window-major in `win`; the fused tail kernel gathers them once per row, writes them back
       // into gqkv for the weight-gradient GEMM, multiplies by Wqkv and applies IWT / branch mixing.
       // (gathering inside the TILED GEMM / wgrad loaders, M2T_A_HALO, was measured slower: the gather is then
       //  repeated once per column-block.)
       const void* gxc_i = (const char*)gxc + (size_t)i * BP * 16 * p->esz;       // chunk i of the P64 gradient: a dense plane
-      if (fused_dgrad(i) && C == 16) {
-        M2TProfScope ps(M2T_PROF_ATTN_BWD_16, st);
-        CK(launch_window_attn_bwd_c16(qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, st, packed_ptr(p, workspace, k + "w1T"),
-                                      WSP("gd"), WSP("gdwin")));
-      } else if (fused_dgrad(i)) {
+      if (fused_dgrad(i)) {
         M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256, st);
         CK(launch_window_attn_bwd_resident(qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, L, st,
                                            packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "TF"), WSP("gd"), WSP("gdwin")));
@@ -789,29 +767,22 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         branch_done[i] = side_marker();
       } else if (i == gate) {
         fork();                              // the gate: the LDS-hungry attention kernels of this block are on their way
-        // the LAST block processed (b == 0) has no next block to collide with: its conv weight gradient goes first, so the
-        // side stream's lag behind the main chain (fully exposed at the end of the step) is that much shorter
-        const int conv_pos = (b == 0 && p->last_block_conv_first) ? 0 : p->side_conv_pos;
-        if (conv_pos == 0) { CK(side_conv()); conv_done = side_marker(); }
+        // gated branches first, then the block's conv weight gradient (512 threads, 80 KB of LDS: +1.9 % over putting it
+        // first, where it met the C = 64 attention)
         for (int j = 3; j >= gate; --j) {
           CK(side_branch(j));
           branch_done[j] = side_marker();
         }
-        if (conv_pos == 1 || (conv_pos == 2 && gate == 0)) { CK(side_conv()); conv_done = side_marker(); }
+        CK(side_conv());
+        conv_done = side_marker();
       } else if (i < gate) {
         fork();
         CK(side_branch(i));
         branch_done[i] = side_marker();
-        if (p->side_conv_pos == 2 && i == 0 && !(b == 0 && p->last_block_conv_first)) { CK(side_conv()); conv_done = side_marker(); }
       }
       if (fused_dgrad(i)) {
         // own-window products are in gd; add the ring rows of the (<= 3) neighbouring windows to the border pixels
-        if (p->fused_dgrad_gather_in_prep) {
-          CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st, WSP("gdwin")));
-        } else {
-          CK(launch_halo_gather(dt, WSP("gdwin"), WSP("gd"), B, h, w, C, C, 0, st));
-          CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st));
-        }
+        CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st, WSP("gdwin")));
       } else {
         m2t_gemm_args ga{};
         ga.A = gqkv; ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
@@ -823,7 +794,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     void* gx = gnext[b & 1];
     // gx's buffer was the gy of block b+1: its conv-wgrad / colsum on the side stream must be done
     main_wait(conv_done_prev);
-    CK(launch_instnorm_bwd(dt, gn, X, mean, rstd, gy, gx, (float*)WSP("norm_part"), (float*)WSP("norm_s"), B, (int)p->P, st, p->norm_single_stage));
+    CK(launch_instnorm_bwd(dt, gn, X, mean, rstd, gy, gx, (float*)WSP("norm_part"), (float*)WSP("norm_s"), B, (int)p->P, st));
     conv_done_prev = conv_done;
     gy = gx;
     if ((b & 1) == 0) { CK(flush()); mark_bucket(); }
@@ -877,28 +848,17 @@ extern "C" int m2t_stream_wait_bucket(m2t_plan* p, int bucket, void* stream) {
 extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (!p || !key) return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: null");
   p->red_uploaded = false;     // the deferred-reduction table depends on the schedule: rebuild it on the next backward
-  if (std::string(key) == "side_stream") { p->use_side = (value != 0); return 0; }
-  if (std::string(key) == "persistent_conv") { p->use_persistent_conv = (value != 0); return 0; }
-  if (std::string(key) == "fused_tail_bwd") { p->use_fused_tail_bwd = (value != 0); return 0; }
-  if (std::string(key) == "tail_wgrad_main") { p->tail_wgrad_main = (value != 0); return 0; }
-  if (std::string(key) == "side_conv_pos") { if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "side_conv_pos: 0..2"); p->side_conv_pos = (int)value; return 0; }
-  if (std::string(key) == "gate_branch") { if (value < 0 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: 0..3"); p->gate_branch = (int)value; return 0; }
-  if (std::string(key) == "gated_side") { p->use_gated_side = (value != 0); return 0; }
-  if (std::string(key) == "side_cus") { if (p->side) return m2t_set_error(M2T_ERR_STATE, "m2t_set_option: side_cus must be set before the first backward"); p->side_cus = (int)value; return 0; }
-  if (std::string(key) == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
-  if (std::string(key) == "norm_single_stage") { p->norm_single_stage = (int)value; return 0; }
-  if (std::string(key) == "dgrad_gather_in_prep") { p->fused_dgrad_gather_in_prep = (value != 0); return 0; }
-  if (std::string(key) == "last_block_conv_first") { p->last_block_conv_first = (value != 0); return 0; }
-  if (std::string(key) == "side_priority") { p->side_priority = (int)value; return 0; }
-  if (std::string(key) == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
-  if (std::string(key) == "merged_rel_reduce") { p->merged_rel_reduce = (value != 0); return 0; }
-  if (std::string(key) == "fused_c16_dgrad") { p->use_fused_c16_dgrad = (value != 0); return 0; }
-  if (std::string(key) == "fused_qkv_dgrad") { p->use_fused_qkv_dgrad = (value != 0); return 0; }
-  if (std::string(key) == "fused_c16_fwd") { p->use_fused_c16_fwd = (value != 0); return 0; }
-  if (std::string(key) == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
-  if (std::string(key) == "fused_tail_fwd") { p->use_fused_tail_fwd = (value != 0); p->have_acts = false; return 0; }
-  if (std::string(key) == "conv_variant") { if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "conv_variant: 0..2"); p->conv_variant = (int)value; return 0; }
-  if (std::string(key) == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
+  const std::string k(key);
+  if (k == "side_stream") { p->use_side = (value != 0); return 0; }
+  if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }
+  if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
+  if (k == "fused_tail_bwd") { p->use_fused_tail_bwd = (value != 0); return 0; }
+  if (k == "fused_tail_fwd") { p->use_fused_tail_fwd = (value != 0); p->have_acts = false; return 0; }
+  if (k == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
+  if (k == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
+  if (k == "fused_c16_fwd") { p->use_fused_c16_fwd = (value != 0); return 0; }
+  if (k == "fused_qkv_dgrad") { p->use_fused_qkv_dgrad = (value != 0); return 0; }
+  if (k == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
   return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");
 }
 

@@ -60,8 +60,7 @@ struct M2TProfScope {
 int launch_dwt(int dt, int L, const void* src, int lds_, int c0, void* dst, int ldd, int d0, int B, int H, int W,
                int C, bool inverse, hipStream_t st);
 int launch_pixel_shuffle_nchw(const float* in, float* out, int B, int C, int H, int W, int r, int inverse, hipStream_t st);
-// single_stage: -1 / 0 two-stage; bit 0 = statistics, bit 1 = backward sums by one workgroup per (image, chunk plane)
-int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float* part, int B, int P, hipStream_t st, int single_stage = -1);
+int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float* part, int B, int P, hipStream_t st);
 int launch_branch_prep(int dt, int L, const void* x, const float* mean, const float* rstd, const void* xc, int k,
                        void* xin, void* d, int B, int H, int W, hipStream_t st);
 int launch_branch_post(int dt, int L, const void* a, const void* xin, void* xc, int k, int B, int H, int W, hipStream_t st);
@@ -70,7 +69,7 @@ int launch_branch_post_bwd(int dt, int L, const void* gxc, int k, void* ga, int 
 int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, int k, int B, int H, int W, hipStream_t st,
                            const void* gdwin = nullptr);
 int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean, const float* rstd, const void* gres,
-                        void* gx, float* part, float* s, int B, int P, hipStream_t st, int single_stage = -1);
+                        void* gx, float* part, float* s, int B, int P, hipStream_t st);
 int launch_add(int dt, const void* a, const void* b, void* o, long long n, hipStream_t st);
 int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* part, int max_part_blocks, float* out,
                   int accumulate, hipStream_t st, int unshuf = 0, int gH = 0, int gW = 0, int gr = 1, int gC = 64,
@@ -128,9 +127,7 @@ int launch_head_conv_fwd(int dt, const float* x, const float* w, const float* b,
 int launch_head_im2col(int dt, const float* x, void* cols, int B, int H0, int W0, int H, int W, hipStream_t st);   // cols [B*H*W][32] (T)
 // 64->64 3x3, zero padding.  wp: packed [9][64 out][64 in] (T). y = conv(x) + bias + res1 + res2 (each optional)
 int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias, const void* res1, const void* res2,
-                       void* y, int B, int H, int W, hipStream_t st,
-                       bool persistent = true,    // bf16: weights-resident (LDS) persistent kernel when there are enough tiles
-                       int variant = 1);          // bf16: 1 = tap-pipelined kernel (default), 0 = weights in registers (>= 1024 tiles)
+                       void* y, int B, int H, int W, hipStream_t st);
 int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, float* bias_slabs, int* nslab, int B, int H,
                              int W, hipStream_t st);   // bias_slabs [nslab][64]: column sums of gy
 // tail conv 64->3, reflect padding, input = the stored activation gelu(t); output NCHW fp32 [B][3][H][W]
@@ -177,11 +174,8 @@ int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const fl
 // C = 16, bf16, no fused DWT: one wave per window (k_attn_c16.hip)
 int launch_window_attn_fwd_c16(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0, const void* res,
                                int ldr, int B, int h, int w, hipStream_t st);
-// wT != nullptr: Wqkv^T [16][48] bf16 (M2T_PACK_TRANSPOSE); the projection data gradient is taken in the same launch:
-// own pixels -> gd [pixel][16], ring keys -> gdwin [window][36][16]
 int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
-                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st, const void* wT = nullptr,
-                               void* gd = nullptr, void* gdwin = nullptr);
+                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st);
 int launch_window_attn_fwd_resident(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0,
                                     const void* res, int ldr, int B, int h, int w, int C, int post_levels, hipStream_t st);
 // the resident kernel alone (bf16); M2T_UNSUPPORTED when (C, dwt_levels) has no instantiation
@@ -205,11 +199,6 @@ int launch_window_attn_fused_fwd(const void* x, const void* wfrag, const float* 
 // relw [nwin][10][C] per-window partials -> grel_h / grel_w (torch layouts)
 int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st);
 int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int* nsplit_out, hipStream_t st);
-// the first stage of up to four branches in one launch; rel_reduce1_plan fills nwin / ncol / wps / nsplit (same split rule)
-struct m2t_rel_desc { const float* relw; float* part; int nwin, ncol, wps, nsplit; };
-struct m2t_rel_desc4 { m2t_rel_desc d[4]; };
-void rel_reduce1_plan(int nwin, int C, m2t_rel_desc* d);
-int launch_rel_reduce1_multi(const m2t_rel_desc4& a, int n, hipStream_t st);
 
 // ---- k_swin.hip (MedCLIP image tower = Swin-T forward, losses.py:68-69) --------------------
 int launch_swin_patchify(int dt, const float* src, const float* src_b, int n_a, int Hs, int Ws, const int* crops, int n, void* out,

@@ -231,6 +231,7 @@ class SemanticLoss(nn.Module):
                 _lib.check(_lib.load().m2t_semantic_loss(_lib.ptr(emb), _lib.ptr(text), B, self.N_patches, _lib.ptr(per),
                                                          _lib.ptr(tot), _lib.stream_ptr()), "m2t_semantic_loss")
         self.last_per_sample = per
+        self.last_embeddings = emb            # [2B,512]: SR rows then HR rows, unit norm (kept for inspection)
         return tot
 
     def __call__(self, x: torch.Tensor, y: torch.Tensor, batch_tokens: str) -> torch.Tensor:

@@ -73,13 +73,15 @@ def read_all():
 
 
 def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8, fused_attn_fwd: bool | None = None,
-                     fused_tail_fwd: bool = False, fused_qkv_dgrad: bool | None = None):
+                     fused_tail_fwd: bool = False, fused_qkv_dgrad: bool | None = None, fused_c16_fwd: bool | None = None):
     """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr.
     fused_attn_fwd (default: bf16 mode): the C = 64 / 256 branches run qkv projection + attention as one kernel, so
     the forward `gemm_qkv` / `attn_fwd_*` categories are then empty (the C = 16 branch runs InstanceNorm apply +
     projection + attention as `attn_fused_c16`).  fused_tail_fwd: option "fused_tail_fwd" of the plan (default off)."""
     if fused_attn_fwd is None:
         fused_attn_fwd = dtype == "bf16"
+    if fused_c16_fwd is None:             # plan option "fused_c16_fwd": the C = 16 branch has its own fused kernel
+        fused_c16_fwd = dtype == "bf16"
     if fused_qkv_dgrad is None:          # plan option "fused_qkv_dgrad" (default on in bf16 mode): C = 64 / 256 branches
         fused_qkv_dgrad = dtype == "bf16"
     es = 2 if dtype == "bf16" else 4
@@ -100,7 +102,7 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         # reads q|k|v (3C) and the output gradient (C), writes dq|dK|dV (3C); with the projection data gradient inside the
         # kernel also g_d (C) and 2 M 3C C more FLOPs
         add(f"attn_bwd_c{C_}", nb * (win * 64000.0 * C_ + (2.0 * M * C_ * 3 * C_ if dg else 0.0)), nb * M * (8 if dg else 7) * C_ * es, nb)
-        if fused_attn_fwd:
+        if (fused_c16_fwd if C_ == 16 else fused_attn_fwd):
             # reads x (+ the residual rows for C >= 64; for C = 16 the residual IS x), writes qkv + out (+ d1 for C = 16)
             add(f"attn_fused_c{C_}", nb * (win * 25600.0 * C_ + 2.0 * M * C_ * 3 * C_), nb * M * 6 * C_ * es, nb)
         else:
@@ -144,14 +146,22 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
     return w
 
 
+def plan_options(plan) -> dict:
+    """The kernel-selection options in force on a plan (m2t_plan_query("opt:<key>")): which kernels ran decides which
+    rows of `algorithmic_work` apply."""
+    return {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_tail_fwd", "fused_qkv_dgrad", "fused_c16_fwd")}
+
+
 def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_file: str | None = None,
-                    source_stamp: str | None = None, workload: str | None = None):
+                    source_stamp: str | None = None, workload: str | None = None, plan=None):
     """Roofline object for the dominant (largest total time) kernel category measured in the
     timed region, plus a compact table of the others.  `traffic` (PMC bytes per launch) comes from a separate
     rocprofv3 --pmc collection (tools/pmc_traffic.py -> profiles/pmc_traffic.json); it is reported only when that
     file was collected on THIS build (same kernel-source stamp) and workload, otherwise null."""
     t = read_all()
-    work = algorithmic_work(B, lr, scale, dtype)
+    opts = plan_options(plan) if plan is not None else {}
+    work = algorithmic_work(B, lr, scale, dtype, fused_attn_fwd=opts.get("fused_attn_fwd"), fused_tail_fwd=bool(opts.get("fused_tail_fwd", False)),
+                            fused_qkv_dgrad=opts.get("fused_qkv_dgrad"), fused_c16_fwd=opts.get("fused_c16_fwd"))
     traffic = {}
     if pmc_file and os.path.exists(pmc_file):
         try:

@@ -43,7 +43,6 @@ class TrainStep:
         # the SemanticLoss forward needs only sr (final after m2t_forward): it runs on its own stream under the backward pass
         self.overlap_semantic = bool(overlap_semantic)
         self.sem_stream = None
-        self.sem_low_priority = True        # +0.3 % at configs[2]: the encoder's kernels yield to the backward pass
         self.lr = float(lr)
         self.betas = (float(betas[0]), float(betas[1]))
         self.eps = float(eps)
@@ -58,6 +57,7 @@ class TrainStep:
                 torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         self.world_size = int(world_size)
         self.step_count = 0
+        self.scheduler_last_epoch = 0          # CosineAnnealingLR.last_epoch of the run (checkpoint.py keeps it across save / resume)
         flat = model.flat_params
         if not flat.is_cuda:
             raise _lib.M2TError("TrainStep needs the model on a HIP device (model.to('cuda'))")
@@ -111,9 +111,8 @@ class TrainStep:
                 # stream once for the crop table) follows the forward pass on a second stream and is joined afterwards
                 main = torch.cuda.current_stream(lr_img.device)
                 if self.sem_stream is None:
-                    # lowest priority the device offers: the encoder only fills what the backward pass leaves free
-                    # (out-of-range priorities are mapped to the nearest valid one: 10 = the lowest)
-                    self.sem_stream = torch.cuda.Stream(device=lr_img.device, priority=10 if self.sem_low_priority else 0)
+                    # (normal priority: PyTorch-ROCm exposes no priority below the default one)
+                    self.sem_stream = torch.cuda.Stream(device=lr_img.device)
                 self.sem_stream.wait_event(fwd_done)
                 with torch.cuda.stream(self.sem_stream):
                     self.clip_loss = self.semantic_loss.batch(sr, hr_img, captions) * self.lambda_clip

@@ -76,3 +76,37 @@ def hip_forward_trace(plan, scale, n_blocks, B, H, W):
             t[nm] = ws_nchw(plan, nm, B, H * 4, W * 4, 64)
     t["srpre"] = plan.ws_tensor("srpre", dtype=torch.float32).view(B, 3, H * scale, W * scale).cpu().clone()
     return t
+
+
+def smooth_hr(B, size, seed, device="cpu"):
+    """Band-limited synthetic 'tissue' in [0,1] (the bf16 quality tests): a low-frequency Fourier field, a few soft-edged
+    blobs and mild speckle that the x4 box down-sampling removes only partly -- an image family on which the network
+    reaches >= 25 dB within a few hundred steps, so that PSNR differences mean something."""
+    import torch.nn.functional as F
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    yy = torch.linspace(0, 1, size).view(1, 1, size, 1)
+    xx = torch.linspace(0, 1, size).view(1, 1, 1, size)
+    img = torch.zeros(B, 1, size, size)
+    for _ in range(12):
+        fx, fy = (torch.rand(B, 1, 1, 1, generator=g) * 14 - 7), (torch.rand(B, 1, 1, 1, generator=g) * 14 - 7)
+        ph = torch.rand(B, 1, 1, 1, generator=g) * 6.283
+        amp = torch.rand(B, 1, 1, 1, generator=g) * 0.12
+        img = img + amp * torch.sin(6.283 * (fx * xx + fy * yy) + ph)
+    for _ in range(5):
+        cx, cy = torch.rand(B, 1, 1, 1, generator=g), torch.rand(B, 1, 1, 1, generator=g)
+        r = 0.05 + 0.2 * torch.rand(B, 1, 1, 1, generator=g)
+        a = (torch.rand(B, 1, 1, 1, generator=g) - 0.5) * 0.6
+        d = ((xx - cx) ** 2 + (yy - cy) ** 2).sqrt()
+        img = img + a * torch.sigmoid((r - d) * 60.0)
+    speck = torch.randn(B, 1, size // 2, size // 2, generator=g)
+    speck = F.interpolate(speck, size=(size, size), mode="bilinear", align_corners=False) * 0.03
+    img = (0.45 + img + speck).clamp(0, 1)
+    tint = torch.tensor([1.0, 0.97, 0.94]).view(1, 3, 1, 1)
+    return (img * tint).clamp(0, 1).to(device)
+
+
+def smooth_pair(B, lr_size, scale, seed, device="cpu"):
+    """(LR, HR) with LR = avg_pool(HR, scale)."""
+    import torch.nn.functional as F
+    hr = smooth_hr(B, lr_size * scale, seed, device)
+    return F.avg_pool2d(hr, scale).contiguous(), hr

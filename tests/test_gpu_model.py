@@ -101,7 +101,7 @@ def test_forward_backward_vs_reference_golden(golden_dir, name):
 @pytest.mark.parametrize("scale,nb,B,H0,W0", [(4, 2, 2, 32, 32), (3, 1, 1, 40, 56), (2, 1, 2, 32, 32)])
 def test_backward_fp32_every_parameter(scale, nb, B, H0, W0):
     """Every parameter gradient, element-wise, against CPU autograd through the oracle
-    (gradients <= 1e-4 relative... stated here: 5e-4 of the tensor's max)."""
+    (gradients <= 1e-4 relative, of the tensor's largest element)."""
     model, p = build_model(scale, nb, "fp32")
     x = O.closed_form_image(B, 3, H0, W0)
     hr = O.closed_form_image(B, 3, H0 * scale, W0 * scale, phase=0.7)
@@ -111,7 +111,7 @@ def test_backward_fp32_every_parameter(scale, nb, B, H0, W0):
     loss.backward()
     assert abs(float(loss) - float(loss_o)) < 1e-5
     rows = [(n, rel(q.grad, g_o[n])) for n, q in model.named_parameters() if q.requires_grad]
-    bad = [(n, e) for n, e in rows if not (e < 5e-4)]
+    bad = [(n, e) for n, e in rows if not (e < 1e-4)]
     assert not bad, "\n".join(f"{n:40s} {e:.3e}" for n, e in rows)
 
 
@@ -163,11 +163,10 @@ def test_bf16_forward_close_to_fp32_oracle():
 
 def test_bf16_fast_kernels_match_plain_kernels():
     """A/B inside bf16 mode, at a size where every specialised kernel is live (512 conv tiles, 1024 C=16
-    windows): weights-resident persistent conv3x3, whole-window-resident / wave-per-window attention backward and
-    the gated side-stream schedule against the plain kernels on one stream.  The persistent conv keeps the
-    accumulation order of the plain one, so the forward is bit-identical; the attention-backward variants round
-    P / dS at different points, so the gradients agree to bf16 noise (stated: rel-rms <= 2e-2 per tensor, or
-    <= 1e-3 of the whole gradient for the tiny-norm ones)."""
+    windows): whole-window-resident / wave-per-window attention backward, the fused tail backward and the gated
+    side-stream schedule against the plain kernels on one stream.  The forward is untouched (bit-identical); the
+    attention-backward variants round P / dS at different points, so the gradients agree to bf16 noise (stated:
+    rel-rms <= 2e-2 per tensor, or <= 1e-3 of the whole gradient for the tiny-norm ones)."""
     from m2trans_amd import _lib
     scale, nb, B, H, W = 4, 2, 4, 128, 128
     x = O.closed_form_image(B, 3, H, W).cuda()
@@ -176,8 +175,8 @@ def test_bf16_fast_kernels_match_plain_kernels():
     for fast in (1, 0):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
-        for key in (b"persistent_conv", b"resident_attn_bwd", b"gated_side", b"side_stream", b"fused_tail_bwd"):
-            _lib.check(_lib.load().m2t_set_option(plan.handle, key, fast), "m2t_set_option")
+        for key, val in ((b"resident_attn_bwd", fast), (b"gate_branch", 1 if fast else -1), (b"side_stream", fast), (b"fused_tail_bwd", fast)):
+            _lib.check(_lib.load().m2t_set_option(plan.handle, key, val), "m2t_set_option")
         sr = model(x)
         torch.nn.L1Loss()(sr, hr).backward()
         outs.append((sr.detach().clone(), {n: q.grad.detach().double().cpu() for n, q in model.named_parameters() if q.requires_grad}))
@@ -470,85 +469,35 @@ def test_fused_c16_branch_forward_matches_the_three_kernel_path():
     assert rms_rel(a["sr"], b["sr"]) < 5e-2
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_single_stage_instance_norm_reductions_match_the_two_stage_path(dtype):
-    """Option norm_single_stage: one workgroup per (image, chunk plane) computes mean / rstd (forward) and the two
-    backward sums directly, instead of partials + a fold kernel (the default from batch 16 on).  Same two-pass batches,
-    another merge tree: statistics agree to fp32 rounding (1e-6 relative), and so do the step's outputs."""
-    from m2trans_amd import _lib
-    from tests.test_gpu_baseline_configs import fwd_bwd
-    scale, nb, B, H0, W0 = 4, 2, 2, 60, 90
-    x = O.closed_form_image(B, 3, H0, W0).cuda()
-    hr = O.closed_form_image(B, 3, H0 * scale, W0 * scale, phase=0.7).cuda()
-    outs = []
-    for single in (3, 0):
-        model, _ = build_model(scale, nb, dtype)
-        plan = model._plan_for(x)
-        _lib.check(_lib.load().m2t_set_option(plan.handle, b"norm_single_stage", single), "m2t_set_option")
-        sr, _, grads = fwd_bwd(model, x, hr, hr.numel())
-        t = {"mean0": plan.ws_tensor("b0.mean", dtype=torch.float32).cpu().clone(),
-             "rstd1": plan.ws_tensor("b0.rstd", dtype=torch.float32).cpu().clone(), "sr": sr.cpu(), "grad": grads.cpu()}
-        outs.append(t)
-    a, b = outs
-    assert rel(a["mean0"], b["mean0"]) < 1e-5 and rel(a["rstd1"], b["rstd1"]) < 1e-5, (rel(a["mean0"], b["mean0"]), rel(a["rstd1"], b["rstd1"]))
-    tol = 1e-4 if dtype == "fp32" else 3e-2          # bf16: a 1e-7 change of a statistic flips roundings downstream
-    assert rms_rel(a["sr"], b["sr"]) < tol and rms_rel(a["grad"], b["grad"]) < tol, (rms_rel(a["sr"], b["sr"]), rms_rel(a["grad"], b["grad"]))
-
-
 def test_fused_projection_data_gradient_matches_the_gemm_path():
     """bf16, C = 64 / 256 branches: the data gradient of the qkv projection taken inside the attention backward kernel
     (option fused_qkv_dgrad, default; the window multiplies its own dq | dK | dV contributions by Wqkv^T and the
     overlap-add over neighbouring windows happens on the C-wide product) against halo gather + GEMM.  Linear in dK | dV,
     so only the bf16 rounding points differ (per-window partial products are rounded before the overlap-add):
     every parameter gradient within 2e-2 of the GEMM path, the whole gradient within 3e-3.  Reflect-padded input with
-    border / edge / interior windows in every branch."""
+    border / edge / interior windows in every branch.  (The ring rows are added by branch_prep_bwd while it loads the
+    row; the separate gather launch that did the same bits was retired in round 3.)"""
     from m2trans_amd import _lib
     from tests.test_gpu_baseline_configs import fwd_bwd
     scale, nb, B, H0, W0 = 4, 2, 2, 60, 90
     x = O.closed_form_image(B, 3, H0, W0).cuda()
     hr = O.closed_form_image(B, 3, H0 * scale, W0 * scale, phase=0.7).cuda()
     outs = []
-    for fused, in_prep in ((1, 1), (0, 1), (1, 0)):
+    for fused in (1, 0):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_qkv_dgrad", fused), "m2t_set_option")
-        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_c16_dgrad", 1), "m2t_set_option")     # default off: covered here
-        _lib.check(_lib.load().m2t_set_option(plan.handle, b"dgrad_gather_in_prep", in_prep), "m2t_set_option")
+        assert plan.query("opt:fused_qkv_dgrad") == fused
         sr, loss, grads = fwd_bwd(model, x, hr, hr.numel())
         outs.append((sr.cpu(), grads.cpu(), model.param_offsets()))
-    (sa, ga, offs), (sb, gb, _), (sc, gc, _) = outs
+    (sa, ga, offs), (sb, gb, _) = outs
     assert torch.equal(sa, sb)                                  # the forward pass is untouched
-    assert torch.equal(ga, gc)                                  # ring rows added by branch_prep_bwd on load == separate gather launch
     total = float(gb.double().norm())
     assert float((ga.double() - gb.double()).norm()) / total < 3e-3, float((ga.double() - gb.double()).norm()) / total
     for n, (o, k) in offs.items():
         a, b = ga[o:o + k].double(), gb[o:o + k].double()
         d = float((a - b).norm())
         assert d <= 2e-2 * float(b.norm()) or d <= 1e-5 * total, (n, d / max(float(b.norm()), 1e-30), d / total)
-
-
-def test_conv3x3_register_resident_weights_kernel_is_bit_identical():
-    """bf16 3x3 conv: the default kernel (weight slices register-resident, several tiles per workgroup, next halo tile in
-    flight under the taps) keeps the tile / lane mapping and the accumulation order of the tap-pipelined kernel, so the
-    whole step -- forward through eight of them, backward through eight data gradients -- must agree bit for bit.  Sizes:
-    128x128 batch 8 (1024 tiles: 2 per workgroup, XCD-aware order) and 96x160 batch 9 (1080 tiles: ragged last workgroup;
-    540 16x16 tiles for variant 2: an odd number per workgroup, so the last pair has an idle group)."""
-    from m2trans_amd import _lib
-    for (B, H, W) in ((8, 128, 128), (9, 96, 160)):
-        scale, nb = 4, 2
-        x = O.closed_form_image(B, 3, H, W).cuda()
-        hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
-        outs = []
-        for variant in (0, 1, 2):          # 2 = 16x16 tiles, swizzled LDS, resident weights (k_conv.hip conv3x3_c64_v2_kernel)
-            model, _ = build_model(scale, nb, "bf16")
-            plan = model._plan_for(x)
-            _lib.check(_lib.load().m2t_set_option(plan.handle, b"conv_variant", variant), "m2t_set_option")
-            sr = model(x)
-            torch.nn.L1Loss()(sr, hr).backward()
-            outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone()))
-        for o in outs[1:]:
-            assert torch.equal(outs[0][0], o[0])
-            assert torch.equal(outs[0][1], o[1])
 
 
 def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():

@@ -368,3 +368,29 @@ def test_roofline_work_table_matches_the_profiler_categories():
     bwd_keys = ["attn_bwd_c16", "attn_bwd_c64", "attn_bwd_c256", "gemm_qkv_dgrad"]
     assert abs(tot(w, fwd_keys) - tot(w0, fwd_keys)) < 1e-3 * tot(w0, fwd_keys)
     assert abs(tot(w, bwd_keys) - tot(w0, bwd_keys)) < 1e-3 * tot(w0, bwd_keys)
+
+
+def test_bench_plain_multi_gpu_launch_builds_the_torchrun_child():
+    """`python bench.py --gpus N` without a launcher (the driver's SCALE command): the parent -- before any GPU call --
+    starts the ranks as a child process under torch.distributed.run and relays its status; it never re-execs."""
+    import subprocess
+    import sys
+    import bench
+    cmd = bench.child_command(["--gpus", "4", "--steps", "7", "--warmup", "2"], 4, 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "os.exec" not in src and "execv" not in src
+    # no GPU here: the parent must fail loudly (non-zero, no JSON line, no fallback) instead of running on fewer devices
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "{" not in r.stdout
+    assert "only" in r.stderr and "visible" in r.stderr
+    # under a launcher whose WORLD_SIZE disagrees with --gpus the rank refuses as well
+    env.update(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
