@@ -67,10 +67,13 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "fused_tail_fwd"    [0] bf16 x4: tail.3 expansion + PixelShuffle + GELU + tail conv in one kernel (k_tail_fwd.hip); gelu(t2) and
  *                           gelu'(t2) are then never stored and the fused tail backward recomputes them per tile (needs
  *                           "fused_tail_bwd"); m2t_plan_query("stores_t2") tells whether ws:t2act / ws:t2der are written
- *   "resident_attn_bwd" [1] bf16: whole-window-resident / wave-per-window attention backward kernels
+ *   "attn_bwd"          [2] bf16 attention backward: 0 = chunked kernels + halo gather + data-gradient GEMM, 1 = whole-window-
+ *                           resident / wave-per-window kernels, 2 = 1 + the data gradient of the qkv projection inside the
+ *                           C = 64 / 256 kernels (k_attn_res.hip)
+ *   "conv_rows"         [1] bf16 conv3x3 64 -> 64 (forward and data gradient): row-streaming kernel fed by LDS-DMA with the weights in
+ *                           registers (k_conv.hip); 0 = the 8 x 16 tile kernel it replaced.  Bit-identical
  *   "fused_attn_fwd"    [1] bf16, C = 64 / 256: qkv projection + window attention + IWT / residual in one kernel per window
  *   "fused_c16_fwd"     [1] bf16, C = 16: InstanceNorm apply + qkv projection + window attention + residual, one wave per window
- *   "fused_qkv_dgrad"   [1] bf16, C = 64 / 256: the data gradient of the qkv projection inside the attention backward kernel
  *   "debug_skip_side"   [0] timing experiments only: skips every parameter-gradient kernel (results are WRONG) */
 int m2t_set_option(m2t_plan* p, const char* key, long long value);
 /* Gradient buckets for communication overlap (replaces the reduce-to-GPU-0 of nn.DataParallel, train.py:73):

@@ -363,13 +363,297 @@ __global__ void __launch_bounds__(256, 4) conv3x3_c64_pipe_kernel(const T* __res
     M2T_CONV_STAMP(3);
   }
 }
+// ---------------------------------------------------------------------------------------
+// Row-streaming kernel (bf16, round 3; the default): a workgroup owns a 32-pixel-wide column strip segment and walks
+// DOWN it two output rows per step.  What bounded the tile kernels above: with one tile per workgroup all ~1024
+// co-resident workgroups run in lockstep -- everyone loads, everyone multiplies, everyone fetches residuals, everyone
+// stores -- so the memory system idles during the products and vice versa, and every tile re-reads a 10 x 18 halo for
+// 8 x 16 outputs (1.41x).  Here
+//   * the input rows AND the residual rows stream through LDS rings by LDS-DMA (global_load_lds_dwordx4: no registers, no
+//     ds_write, requests stay in flight across barriers): the row pair D steps ahead and the residual rows DR steps ahead
+//     are always outstanding; each input row is fetched once per segment (read amplification (RS + 2) / RS x 34 / 32 =
+//     1.13 .. 1.2 instead of 1.41);
+//   * out-of-image pixels (zero padding of the conv, models/M2Trans_network.py:124-126) come from a zero page in HBM:
+//     the source address is selected per lane, no branch around a load;
+//   * the packed weights stay in REGISTERS for the whole segment: wave w owns the 32 output channels of half (w & 1)
+//     (two permuted 16-row MFMA tiles, so a lane ends with 8 consecutive channels = one 16-byte store) of output row
+//     (w >> 1) of the step: 36 A-fragments; per k-step two B-fragment reads from LDS feed four MFMAs;
+//   * one barrier per step; stores drain under the next steps.
+// The LDS image of a row is the linear P64 image the DMA writes ([plane][36 pixels][16 channels]: 32-byte pixel stride,
+// conflict-free for the 16-byte B-fragment reads).  Same products in the same order as conv3x3_c64_kernel
+// (tap-major, 32-deep k-steps, bias, res1, res2, one rounding): identical bits.
+// The DMA is issued from inline asm ON PURPOSE: with __builtin_amdgcn_global_load_lds hipcc (ROCm 7.2) drains every
+// outstanding DMA (s_waitcnt vmcnt(0)) at the next use of any register a plain global load wrote, which serialises the
+// ring.  Hidden in asm the compiler neither counts nor waits for it; the loop below contains no compiler-visible load
+// at all (weights are forced complete before it, residuals come through LDS), and the single wait per step is
+// "all but the n youngest" with n from a running count of what this wave has issued (vmcnt retires in order and counts
+// DMA and stores alike).
+// ---------------------------------------------------------------------------------------
+#ifndef C3R_STAMP
+#define C3R_STAMP(i) do { } while (0)   // scratch/bench_conv_rows.hip -DSTAMPS records s_memtime per phase (wave 0 lane 0; counted in `issued`)
+#endif
+#define C3R_SW 32                       // strip width (output pixels)
+#define C3R_PXP 36                      // pixels per LDS plane-row: 34 real (1-pixel halo each side) + 2 padding
+#define C3R_ROWB (4 * C3R_PXP * 32)     // bytes of one ring row (4 planes x 36 px x 16 ch x 2 B) = 4608; a row pair = 9 KiB = 9 DMAs
+#define C3R_RESB (2 * 4 * C3R_SW * 32)  // residual rows of one step: 2 rows x 4 planes x 32 px x 32 B = 8 KiB = 8 DMAs
+
+__device__ __forceinline__ void c3r_wait_vm(int n) {       // s_waitcnt vmcnt(n): all but the n youngest are done
+  switch (n) {
+#define C3R_W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+    C3R_W(0) C3R_W(1) C3R_W(2) C3R_W(3) C3R_W(4) C3R_W(5) C3R_W(6) C3R_W(7) C3R_W(8) C3R_W(9) C3R_W(10) C3R_W(11) C3R_W(12)
+    C3R_W(13) C3R_W(14) C3R_W(15) C3R_W(16) C3R_W(17) C3R_W(18) C3R_W(19) C3R_W(20) C3R_W(21) C3R_W(22) C3R_W(23) C3R_W(24)
+    C3R_W(25) C3R_W(26) C3R_W(27) C3R_W(28) C3R_W(29) C3R_W(30) C3R_W(31) C3R_W(32) C3R_W(33) C3R_W(34) C3R_W(35) C3R_W(36)
+    C3R_W(37) C3R_W(38) C3R_W(39) C3R_W(40) C3R_W(41) C3R_W(42) C3R_W(43) C3R_W(44) C3R_W(45) C3R_W(46) C3R_W(47) C3R_W(48)
+#undef C3R_W
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;    // (more than 48 younger operations never happens at D <= 4)
+  }
+}
+// one 1-KiB LDS-DMA piece: lane l's 16 bytes at gsrc land at LDS byte address lds_dst + 16 l (lds_dst wave-uniform).
+// M0 is compiler-reserved and not preserved around an asm statement: saved and restored inside the same statement.
+__device__ __forceinline__ void c3r_dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int NRES, int D, int DR>   // residual tensors (0: data gradient, 1: forward, 2: last block); DMA depth of the input rows / residual rows, in steps
+__global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                                  const float* __restrict__ bias, const bf16_t* __restrict__ res1,
+                                                                  const bf16_t* __restrict__ res2, bf16_t* __restrict__ y,
+                                                                  const bf16_t* __restrict__ zero_page, int B, int H, int W, int RS) {
+  using T = bf16_t;
+  static_assert(DR >= 1 && DR <= D, "the residual rows are issued no earlier than the input rows they go with");
+  constexpr int NR = 2 * D + 4;                       // ring rows: a pair in flight never overwrites a row a slower wave still reads
+  constexpr int NS = DR + 1;                          // residual slots
+  constexpr int NM = D + 2;                           // issue marks kept
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* ring = smem;
+  unsigned char* rring = smem + NR * C3R_ROWB;
+  float* bias_s = reinterpret_cast<float*>(smem + NR * C3R_ROWB + ((NRES > 0) ? NRES : 0) * NS * C3R_RESB);
+  const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ring;
+  const unsigned rring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)rring;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  const int nseg = H / RS, nsx = W / C3R_SW;
+  const int L = xcd_block_index();                    // vertically adjacent segments (shared halo rows) behind one L2
+  const int seg = L % nseg, sx = (L / nseg) % nsx, b = L / (nseg * nsx);
+  const int x0 = sx * C3R_SW, y0 = seg * RS;
+  const long long npix = (long long)B * H * W;
+  const long long pb = (long long)b * H * W;
+  const int NQ = RS / 2 + 1;                          // row pairs of the segment: pair k = input rows y0 + 2k - 1, y0 + 2k
+  const int nsteps = RS / 2;
+
+  if (tid < 64) bias_s[tid] = bias ? bias[tid] : 0.f;
+  int issued = 0;                                     // vector-memory operations this wave has issued (restarts after the prologue)
+  C3R_STAMP(0);
+
+  // ---- DMA descriptors.  Input rows: instruction i (0..8) of a pair is issued by wave i % 4; chunk c = 64 i + lane ----
+  const int ndma = (wv == 0) ? 3 : 2;
+  long long src_off[3];                               // element offset of this lane's chunk at image row 0 (valid columns only)
+  int src_rr[3];                                      // row of the pair (0 / 1); -1: a padding / out-of-image column (always the zero page)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int c = 64 * (wv + 4 * j) + lane;           // (j == 2 is used by wave 0 only)
+    const int rr = c / (4 * 2 * C3R_PXP), rem = c % (4 * 2 * C3R_PXP);
+    const int pl = rem / (2 * C3R_PXP), rem2 = rem % (2 * C3R_PXP);
+    const int px = rem2 >> 1, hf = rem2 & 1;
+    const int col = x0 - 1 + px;
+    const bool ok = px < C3R_SW + 2 && col >= 0 && col < W;
+    src_rr[j] = ok ? rr : -1;
+    src_off[j] = ((long long)pl * npix + pb + (ok ? col : 0)) * 16 + hf * 8;
+  }
+  // residual rows: instruction i (0..7) of a step is issued by wave i % 4; chunk c = 64 i + lane = (row, plane, pixel, half)
+  long long rsrc_off[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = 64 * (wv + 4 * j) + lane;
+    const int rr = c >> 8, pl = (c >> 6) & 3, px = (c & 63) >> 1, hf = c & 1;
+    rsrc_off[j] = ((long long)pl * npix + pb + (long long)(y0 + rr) * W + x0 + px) * 16 + hf * 8;
+  }
+  auto issue_pair = [&](int k) {                      // k >= NQ: a dummy pair (zero page -> a ring slot nobody reads): keeps the cadence
+    const int row0 = y0 + 2 * k - 1;
+    const unsigned dst = ring_lds + ((2 * k) % NR) * C3R_ROWB;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (j < ndma) {
+        const int row = row0 + (src_rr[j] > 0 ? 1 : 0);
+        const bool ok = src_rr[j] >= 0 && k < NQ && row >= 0 && row < H;
+        const T* src = ok ? (x + src_off[j] + (long long)row * W * 16) : zero_page;
+        c3r_dma16(src, dst + 1024 * (wv + 4 * j));
+      }
+    }
+    issued += ndma;
+  };
+  auto issue_res = [&](int t) {                       // residual rows of step t (t >= nsteps: the rows of the last step again, never read)
+    if constexpr (NRES > 0) {
+      const long long roff = (long long)(2 * min(t, nsteps - 1)) * W * 16;
+      const unsigned dst = rring_lds + (t % NS) * (NRES * C3R_RESB);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        c3r_dma16(res1 + rsrc_off[j] + roff, dst + 1024 * (wv + 4 * j));
+        if constexpr (NRES > 1) c3r_dma16(res2 + rsrc_off[j] + roff, dst + C3R_RESB + 1024 * (wv + 4 * j));
+      }
+      issued += 2 * NRES;
+    }
+  };
+
+  // ---- prologue: residual rows of steps 0 .. DR - 1 and row pairs 0 .. D go out first, the weights behind them ----
+#pragma unroll
+  for (int t = 0; t < DR; ++t) issue_res(t);
+#pragma unroll
+  for (int k = 0; k <= D; ++k) issue_pair(k);
+  // ---- the wave's weights: A-fragments of output channels 32 (wv & 1) + 8 (lr >> 2) + 4 nt + (lr & 3), all 18 k-steps.
+  // wp is in M2T_PACK_CONV3_ROWS order: every wave load is one contiguous 1 KB (16 rows x 64 B per load -- the shape of the
+  // [tap][oc][ic] layout -- kept the address unit busy for ~20 k cycles per workgroup: 10 us of a 30 us kernel) ----
+  Frag8<T> wreg[9][2][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        wreg[tap][kc][nt] = load8(wp + ((((tap * 2 + (wv & 1)) * 2 + kc) * 2 + nt) * 64 + lane) * 8);
+
+  // every weight fragment is in its registers before the loop: the compiler places its waits for these plain loads HERE
+  // (vmcnt retires in order, so the DMAs issued before them have landed as well) and has no plain load left to wait for
+  // inside the loop, where such a wait would drain the ring
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) asm volatile("" :: "v"(wreg[tap][kc][nt].v));
+  issued = 0;                                         // nothing is outstanding any more: the count restarts
+  C3R_STAMP(1);
+  int mark[NM];                                       // mark[t % NM] = `issued` once everything step t reads from LDS has been issued
+#pragma unroll
+  for (int t = 0; t < NM; ++t) mark[t] = 0;           // steps 0 .. D - 1 read what the prologue fetched
+
+  const int rrw = wv >> 1;                            // this wave's output row within the step
+  const int laneA = (g >> 1) * (C3R_PXP * 32) + lr * 32 + (g & 1) * 16;       // B-fragment byte offset inside a ring row
+  const int plane_o = 2 * (wv & 1) + (g >> 1);                                  // output plane of this lane's 8 channels
+  const long long obase = ((long long)plane_o * npix + pb) * 16 + (g & 1) * 8;
+  const int laneR = rrw * (4 * C3R_SW * 32) + plane_o * (C3R_SW * 32) + lr * 32 + (g & 1) * 16;   // residual bytes of (row, plane, pixel, half)
+
+#pragma unroll 1
+  for (int s = 0; s < nsteps; ++s) {
+    // the row pair s + 1 and the residual rows of step s have landed: everything this wave issued up to mark[s] is done ...
+    c3r_wait_vm(issued - mark[s % NM]);
+    lds_barrier();                                    // ... and so has every other wave's share; all waves are done with step s - 1
+    C3R_STAMP(2 + 3 * s);
+    // (marks only grow, so the later of a step's two fetches -- its residual rows when DR < D -- is the one that stays)
+    issue_res(s + DR);
+    if constexpr (NRES > 0) mark[(s + DR) % NM] = issued;        // step s + DR: its residual rows are out (its row pairs went earlier)
+    issue_pair(s + 1 + D);
+    if constexpr (NRES == 0 || DR == D) mark[(s + D) % NM] = issued;   // step s + D reads pairs s + D, s + D + 1
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int rowoff[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) rowoff[ky] = ((2 * s + rrw + ky) % NR) * C3R_ROWB;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        Frag8<T> xf[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          xf[mt] = load8(reinterpret_cast<const T*>(ring + rowoff[ky] + laneA + kc * (2 * C3R_PXP * 32) + (16 * mt + kx) * 32));
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wreg[tap][kc][nt], xf[mt]);
+      }
+    }
+    C3R_STAMP(3 + 3 * s);
+    // ---- epilogue: + bias + res1 + res2 (this order), one rounding, 16-byte stores ----
+    const int orow = y0 + 2 * s + rrw;
+    float bv[8];
+    {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(&bias_s[32 * (wv & 1) + 8 * g]);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(&bias_s[32 * (wv & 1) + 8 * g + 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
+    }
+    const unsigned char* rslot = rring + (s % NS) * (((NRES > 0) ? NRES : 1) * C3R_RESB) + laneR;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float v[8];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+      }
+      if constexpr (NRES > 0) {
+        const Frag8<T> r1 = load8(reinterpret_cast<const T*>(rslot + mt * (16 * 32)));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r1.get(e);
+      }
+      if constexpr (NRES > 1) {
+        const Frag8<T> r2 = load8(reinterpret_cast<const T*>(rslot + C3R_RESB + mt * (16 * 32)));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r2.get(e);
+      }
+      store8f(y + obase + ((long long)orow * W + x0 + 16 * mt + lr) * 16, v);
+    }
+    issued += 2;
+    C3R_STAMP(4 + 3 * s);
+  }
+  // (the dummy pairs / residual rows still in flight target LDS only; the wave ends when its counter drains)
+}
+
 // bf16 takes the pipelined kernel: at most this many workgroups (8 per CU: with more tiles a workgroup walks several)
 constexpr int C3_PIPE_MAX_BLOCKS = 2048;
 
+// segment length of the row-streaming kernel: >= 512 workgroups (2 per CU) when the map allows it, segments of 16..64 rows
+static int c3r_force_rs = 0;       // scratch/bench_conv_rows.hip only: overrides the segment length
+static int c3r_rows_per_segment(int B, int H, int W) {
+  if (c3r_force_rs > 0) return (H % c3r_force_rs == 0) ? c3r_force_rs : 0;
+  const long long strips = (long long)B * (W / C3R_SW);
+  int rs = 64;
+  while (rs > 16 && (H % rs != 0 || strips * (H / rs) < 512)) rs >>= 1;
+  return (H % rs == 0) ? rs : 0;
+}
+template <int NRES, int D, int DR>
+static int go_c3r(const void* x, const void* wp /* M2T_PACK_CONV3_ROWS(_T) */, const float* bias, const void* res1, const void* res2, void* y, const void* zero_page,
+                  int B, int H, int W, int rs, hipStream_t st) {
+  constexpr int NR = 2 * D + 4;
+  const size_t sh = (size_t)NR * C3R_ROWB + (size_t)NRES * (DR + 1) * C3R_RESB + 64 * sizeof(float);
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)conv3x3_c64_rows_kernel<NRES, D, DR>, (int)sh)) return rc__;
+  const int nblk = B * (W / C3R_SW) * (H / rs);
+  M2T_LAUNCH_TIMED((conv3x3_c64_rows_kernel<NRES, D, DR>), dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
+                   (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, (const bf16_t*)zero_page, B, H, W, rs);
+  return 0;
+}
+
 int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias, const void* res1, const void* res2,
-                       void* y, int B, int H, int W, hipStream_t st) {
+                       void* y, int B, int H, int W, hipStream_t st, const void* wrows, const void* zero_page, int variant) {
   if (H % C3_TH || W % C3_TW) return m2t_set_error(-2, "conv3x3_c64: H%8 or W%16");
   const long long ntiles = (long long)B * (H / C3_TH) * (W / C3_TW);
+  if (res2 && !res1) return m2t_set_error(-2, "conv3x3_c64: res2 without res1");
+  if (dt != M2T_F32 && wrows && zero_page && variant != 1 && W % C3R_SW == 0 && (long long)B * H * W * 64 < (1LL << 31)) {
+    const int rs = c3r_rows_per_segment(B, H, W);
+    if (rs > 0) {
+      int rc;
+      // LDS per workgroup (two per CU): ring 46 080 B + residual slots: <= 79 104 B
+      if (res2) rc = go_c3r<2, 3, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+      else if (res1) rc = go_c3r<1, 3, 3>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+      else rc = go_c3r<0, 3, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+      if (rc) return rc;
+      M2T_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   if (dt != M2T_F32) {
     const int tpb = (int)ceil_divll(ntiles, C3_PIPE_MAX_BLOCKS);
     const int nblk = (int)ceil_divll(ntiles, tpb);

@@ -1181,6 +1181,14 @@ __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ mas
         const int ks = f % nks, tile = f / nks;
         si = (long long)(16 * tile + (l & 15)) * d.d1 + 32 * ks + 8 * (l >> 4) + j;
       } break;
+      case M2T_PACK_CONV3_ROWS:         // src torch [O=64][I=64][3][3] -> the A-fragments of conv3x3_c64_rows_kernel (k_conv.hip):
+      case M2T_PACK_CONV3_ROWS_T: {     // [tap][half][kc][nt][64 lanes][8]; _T: the data-gradient weights (flipped taps, O <-> I)
+        const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
+        const int nt = f & 1, kc = (f >> 1) & 1, h = (f >> 2) & 1, tap = f >> 3;
+        const int row = 32 * h + 8 * ((l & 15) >> 2) + 4 * nt + (l & 3);     // output channel of the product
+        const int k = 32 * kc + 8 * (l >> 4) + j;                             // contraction channel
+        si = (d.kind == M2T_PACK_CONV3_ROWS) ? ((long long)row * 64 + k) * 9 + tap : ((long long)k * 64 + row) * 9 + (8 - tap);
+      } break;
       case M2T_PACK_FRAG16_T: {         // src [K=d1][N=d0] -> fragments of the transpose [N/16][K/32][64][8]
         const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
         const int nks = d.d1 >> 5;

@@ -138,10 +138,11 @@ struct m2t_plan {
   int gate_branch = 1;                 // side-stream gate: -1 ungated, else the branch (3..0) behind whose attention launch a block's
                                        // parameter-gradient work is released.  Same-box A/B (config 1): 1 = 5.49 ms, 2 = 5.60, 3 = 5.62,
                                        // 0 = 5.68, ungated 5.64
-  bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)
+  bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)         } option "attn_bwd":
+  bool use_conv_rows = true;           // bf16 conv3x3 64 -> 64: row-streaming LDS-DMA kernel (k_conv.hip) instead of the tile kernel
   int wgrad_big_tiles = -1;            // C = 256 qkv weight gradient: 128 x 128 output tiles (k_gemm.hip); value = target workgroups,
                                        // 0 = off, -1 = auto: 256 from 24 576 rows on (batch 32: 9.82 vs 9.93 ms; batch 16: 5.53 vs 5.49)
-  bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside the attention backward kernel (k_attn_res.hip)
+  bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside that kernel                } 0 / 1 / 2
   bool use_fused_c16_fwd = true;       // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip)
   bool use_fused_attn_fwd = true;      // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip)
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
@@ -247,6 +248,8 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
     const std::string pre = "body." + std::to_string(b) + ".feed_forward.0.weight";
     p->add_pack("b" + std::to_string(b) + ".wf", pre, M2T_PACK_CONV3, 64 * 64 * 9, 64, 64, 0);
     p->add_pack("b" + std::to_string(b) + ".wfT", pre, M2T_PACK_CONV3_T, 64 * 64 * 9, 64, 64, 0);
+    p->add_pack("b" + std::to_string(b) + ".wfR", pre, M2T_PACK_CONV3_ROWS, 64 * 64 * 9, 64, 64, 0);      // conv3x3_c64_rows_kernel (bf16)
+    p->add_pack("b" + std::to_string(b) + ".wfTR", pre, M2T_PACK_CONV3_ROWS_T, 64 * 64 * 9, 64, 64, 0);
   }
   {
     const int r0 = (s == 4) ? 2 : s;
@@ -260,6 +263,7 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   // ---- workspace ----
   const size_t es = p->esz;
   const long long BP = (long long)B * p->P;
+  p->add_ws("zero_page", 256, 1);          // source of every out-of-image pixel the LDS-DMA kernels stage (k_conv.hip)
   p->add_ws("pack_descs", p->descs.size() * sizeof(m2t_pack_desc), 1);
   p->add_ws("packed", p->npacked, es);
   for (int b = 0; b <= n_blocks; ++b) p->add_ws("X" + std::to_string(b), BP * 64, es);
@@ -365,7 +369,8 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "wgrad_big_tiles") return p->wgrad_big_tiles + 1000;
     if (o == "fused_tail_bwd") return p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
     if (o == "fused_tail_fwd") return p->use_fused_tail_fwd && p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
-    if (o == "resident_attn_bwd") return p->use_resident_attn_bwd && p->dt != M2T_F32;
+    if (o == "attn_bwd") return p->dt == M2T_F32 ? 0 : (p->use_resident_attn_bwd ? (p->use_fused_qkv_dgrad ? 2 : 1) : 0);
+    if (o == "conv_rows") return p->use_conv_rows && p->dt != M2T_F32;
     if (o == "fused_attn_fwd") return p->use_fused_attn_fwd && p->dt != M2T_F32;
     if (o == "fused_c16_fwd") return p->use_fused_c16_fwd && p->dt != M2T_F32;
     if (o == "fused_qkv_dgrad") return p->use_fused_qkv_dgrad && p->use_resident_attn_bwd && p->dt != M2T_F32;
@@ -383,6 +388,8 @@ extern "C" int m2t_plan_init_workspace(m2t_plan* p, void* workspace, void* strea
   if (!p || !workspace) return m2t_set_error(M2T_ERR_ARG, "m2t_plan_init_workspace: null");
   hipError_t e = hipMemcpyAsync(WSP("pack_descs"), p->descs.data(), p->descs.size() * sizeof(m2t_pack_desc),
                                 hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+  e = hipMemsetAsync(WSP("zero_page"), 0, 256, (hipStream_t)stream);
   if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
   e = hipStreamSynchronize((hipStream_t)stream);   // the host table may be freed/moved afterwards
   if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
@@ -452,7 +459,8 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     // x = feed_forward(xc) + x (:164); the last block also folds in `res + x` (:70)
     { M2TProfScope ps(M2T_PROF_CONV3_FWD, st);
       CK(launch_conv3x3_c64(dt, xc, packed_ptr(p, workspace, k + "wf"), params + p->poff.at(pre + "feed_forward.0.bias"), X,
-                            (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st)); }
+                            (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st,
+                            packed_ptr(p, workspace, k + "wfR"), WSP("zero_page"), p->use_conv_rows ? 0 : 1)); }
   }
   void* Y = WSP("X" + std::to_string(p->nb));
   const int r0 = (s == 4) ? 2 : s;
@@ -735,7 +743,8 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       CK(side_conv());
       conv_done = side_marker();
     }
-    { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st)); }
+    { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st,
+                                                                        packed_ptr(p, workspace, k + "wfTR"), WSP("zero_page"), p->use_conv_rows ? 0 : 1)); }
     for (int i = 3; i >= 0; --i) {
       const int C = BR_C[i], L = BR_L[i];
       const int h = H >> L, w = W >> L;
@@ -854,10 +863,13 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
   if (k == "fused_tail_bwd") { p->use_fused_tail_bwd = (value != 0); return 0; }
   if (k == "fused_tail_fwd") { p->use_fused_tail_fwd = (value != 0); p->have_acts = false; return 0; }
-  if (k == "resident_attn_bwd") { p->use_resident_attn_bwd = (value != 0); return 0; }
+  if (k == "attn_bwd") {
+    if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "attn_bwd: 0..2");
+    p->use_resident_attn_bwd = value >= 1; p->use_fused_qkv_dgrad = value == 2; return 0;
+  }
+  if (k == "conv_rows") { p->use_conv_rows = (value != 0); return 0; }
   if (k == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
   if (k == "fused_c16_fwd") { p->use_fused_c16_fwd = (value != 0); return 0; }
-  if (k == "fused_qkv_dgrad") { p->use_fused_qkv_dgrad = (value != 0); return 0; }
   if (k == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
   return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");
 }

@@ -13,7 +13,9 @@ enum m2t_pack_kind {
   M2T_PACK_SHUF_ROWS = 4, M2T_PACK_SHUF_ROWS_T = 5,
   M2T_PACK_FRAG16 = 6,    // src [N = d0][K = d1] -> MFMA A-operand fragment order [N/16][K/32][64 lanes][8]: element j of lane l of
                           // fragment (tile, ks) is src[16 tile + (l & 15)][32 ks + 8 (l >> 4) + j]; one wave load = 1 KB contiguous
-  M2T_PACK_FRAG16_T = 7   // the same fragments of the TRANSPOSE: src is [K = d1][N = d0] (element = src[32 ks + 8 (l >> 4) + j][16 tile + (l & 15)])
+  M2T_PACK_FRAG16_T = 7,  // the same fragments of the TRANSPOSE: src is [K = d1][N = d0] (element = src[32 ks + 8 (l >> 4) + j][16 tile + (l & 15)])
+  M2T_PACK_CONV3_ROWS = 8,    // 64 -> 64 3x3 conv weight as the register-resident A-fragments of conv3x3_c64_rows_kernel:
+  M2T_PACK_CONV3_ROWS_T = 9   // [tap][channel half][k-chunk][tile][64 lanes][8], one contiguous 1 KB per wave load (_T: data gradient)
 };
 struct m2t_red_desc {      // one deferred slab reduction: grads[dst_off + perm(e)] = sum_s arena[src_off + s*n + e]
   long long src_off, dst_off, n;
@@ -127,7 +129,10 @@ int launch_head_conv_fwd(int dt, const float* x, const float* w, const float* b,
 int launch_head_im2col(int dt, const float* x, void* cols, int B, int H0, int W0, int H, int W, hipStream_t st);   // cols [B*H*W][32] (T)
 // 64->64 3x3, zero padding.  wp: packed [9][64 out][64 in] (T). y = conv(x) + bias + res1 + res2 (each optional)
 int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias, const void* res1, const void* res2,
-                       void* y, int B, int H, int W, hipStream_t st);
+                       void* y, int B, int H, int W, hipStream_t st,
+                       const void* wrows = nullptr,       // bf16: the same weight in M2T_PACK_CONV3_ROWS(_T) order and ...
+                       const void* zero_page = nullptr,   // ... >= 64 zero bytes in device memory -> the row-streaming kernel
+                       int variant = 0);                  // 1: force the tile kernel (conv3x3_c64_pipe_kernel) for A/B tests
 int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, float* bias_slabs, int* nslab, int B, int H,
                              int W, hipStream_t st);   // bias_slabs [nslab][64]: column sums of gy
 // tail conv 64->3, reflect padding, input = the stored activation gelu(t); output NCHW fp32 [B][3][H][W]

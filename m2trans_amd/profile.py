@@ -52,7 +52,7 @@ KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these cate
     "final_conv_dgrad": "tail_bwd_fused_kernel (tail conv dgrad+wgrad, GELU', tail.3 dgrad+wgrad)",
 }
 MERGED = {"conv3x3_fwd+dgrad": ("conv3x3_fwd", "conv3x3_dgrad")}
-MERGED_KERNEL = {"conv3x3_fwd+dgrad": "conv3x3_c64_pipe_kernel (64->64 3x3 conv: forward and data gradient are the same kernel and tile shape)"}
+MERGED_KERNEL = {"conv3x3_fwd+dgrad": "conv3x3_c64_rows_kernel (64->64 3x3 conv, row-streaming LDS-DMA kernel: forward and data gradient are the same kernel)"}
 HBM_PEAK_GBS = 8000.0
 MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
 ALL_MASK = (1 << len(CATS)) - 1
@@ -149,7 +149,9 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
 def plan_options(plan) -> dict:
     """The kernel-selection options in force on a plan (m2t_plan_query("opt:<key>")): which kernels ran decides which
     rows of `algorithmic_work` apply."""
-    return {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_tail_fwd", "fused_qkv_dgrad", "fused_c16_fwd")}
+    o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_tail_fwd", "fused_c16_fwd", "conv_rows")}
+    o["fused_qkv_dgrad"] = plan.query("opt:attn_bwd") == 2
+    return o
 
 
 def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_file: str | None = None,

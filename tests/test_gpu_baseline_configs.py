@@ -84,12 +84,20 @@ def check_vs_oracle(scale, lr, B, dtype, nb=8, verbose=True):
     sr, loss, grads = fwd_bwd(model, x.cuda(), hr.cuda(), hr.numel())
     if dtype == "fp32":
         loss_o, sr_o, g_o = O.l1_loss_and_grads(x, hr, p, scale, nb)
-        rows = grad_table(model, grads, g_o)
-        # forward <= 1e-4; gradients: 1e-4 of each tensor's norm (1e-8 of the whole gradient for the rel-pos
-        # tensors whose gradient is a sum over every window that cancels to ~1e-7 of the total)
+        # forward <= 1e-4, gradients <= 1e-4 relative.  At full depth and size BOTH fp32 evaluations -- torch on the
+        # CPU and the exact-fp32 MFMA path here -- carry ~1e-4 of summation-order rounding on the small attention tensors, so
+        # the yardstick is the fp64 evaluation of the same restatement: each HIP gradient tensor must be within 1e-4 of it, or
+        # no further from it than 3x the fp32 oracle itself is (or 1e-8 of the whole gradient: the rel-pos tensors, sums over
+        # every window that cancel to ~1e-7 of the total)
+        _, _, g64 = O.l1_loss_and_grads(x.double(), hr.double(), {k: v.double() for k, v in p.items()}, scale, nb)
+        rows = grad_table(model, grads, g64)
+        own = {n: float((g_o[n].double() - g64[n]).norm()) / (float(g64[n].norm()) + 1e-300) for n in g64}
         assert rel(sr, sr_o) < 1e-4, rel(sr, sr_o)
         assert abs(loss - float(loss_o)) < 1e-5
-        bad = [r for r in rows if not (r[1] < 1e-4 or r[2] < 1e-8)]
+        bad = [r + (own[r[0]],) for r in rows if not (r[1] < 1e-4 or r[1] < 3.0 * own[r[0]] or r[2] < 1e-8)]
+        worst = max(rows, key=lambda r: r[1] / max(own[r[0]], 1e-30))
+        print(f"fp32 gradients vs the fp64 oracle: worst HIP / torch-fp32 error ratio {worst[1] / max(own[worst[0]], 1e-30):.2f} ({worst[0]}: "
+              f"{worst[1]:.2e} vs {own[worst[0]]:.2e})")
         stage_txt = ""
     else:
         from tests.gpu_util import hip_forward_trace

@@ -175,7 +175,7 @@ def test_bf16_fast_kernels_match_plain_kernels():
     for fast in (1, 0):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
-        for key, val in ((b"resident_attn_bwd", fast), (b"gate_branch", 1 if fast else -1), (b"side_stream", fast), (b"fused_tail_bwd", fast)):
+        for key, val in ((b"attn_bwd", 2 if fast else 0), (b"gate_branch", 1 if fast else -1), (b"side_stream", fast), (b"fused_tail_bwd", fast)):
             _lib.check(_lib.load().m2t_set_option(plan.handle, key, val), "m2t_set_option")
         sr = model(x)
         torch.nn.L1Loss()(sr, hr).backward()
@@ -486,8 +486,8 @@ def test_fused_projection_data_gradient_matches_the_gemm_path():
     for fused in (1, 0):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
-        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_qkv_dgrad", fused), "m2t_set_option")
-        assert plan.query("opt:fused_qkv_dgrad") == fused
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"attn_bwd", 2 if fused else 1), "m2t_set_option")
+        assert plan.query("opt:attn_bwd") == (2 if fused else 1)
         sr, loss, grads = fwd_bwd(model, x, hr, hr.numel())
         outs.append((sr.cpu(), grads.cpu(), model.param_offsets()))
     (sa, ga, offs), (sb, gb, _) = outs
@@ -498,6 +498,30 @@ def test_fused_projection_data_gradient_matches_the_gemm_path():
         a, b = ga[o:o + k].double(), gb[o:o + k].double()
         d = float((a - b).norm())
         assert d <= 2e-2 * float(b.norm()) or d <= 1e-5 * total, (n, d / max(float(b.norm()), 1e-30), d / total)
+
+
+def test_row_streaming_conv3x3_is_bit_identical_to_the_tile_kernel():
+    """bf16 3x3 conv 64 -> 64: the row-streaming kernel (LDS-DMA rings for the input and residual rows, weights in registers,
+    option conv_rows, default) keeps the products and their order of the tile kernel, so the whole step -- eight forward
+    convs, eight data gradients -- must agree bit for bit.  Sizes: 128x128 batch 8 (256 segments of 32 rows), 96x160 batch 3
+    (segments of 32 rows, 5 strips, first / last strip at the image border) and 60x90 reflect-padded to 64x96 batch 2
+    (segments of 16 rows)."""
+    from m2trans_amd import _lib
+    for (B, H, W) in ((8, 128, 128), (3, 96, 160), (2, 60, 90)):
+        scale, nb = 4, 2
+        x = O.closed_form_image(B, 3, H, W).cuda()
+        hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+        outs = []
+        for rows in (1, 0):
+            model, _ = build_model(scale, nb, "bf16")
+            plan = model._plan_for(x)
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"conv_rows", rows), "m2t_set_option")
+            assert plan.query("opt:conv_rows") == rows
+            sr = model(x)
+            torch.nn.L1Loss()(sr, hr).backward()
+            outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone()))
+        assert torch.equal(outs[0][0], outs[1][0]), (B, H, W)
+        assert torch.equal(outs[0][1], outs[1][1]), (B, H, W)
 
 
 def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():

@@ -25,7 +25,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 
-def smooth_hr(B, size, seed, device):
+def smooth_hr(B, size, seed, device, noise=0.026):
     """Band-limited synthetic 'tissue': low-frequency Fourier field + a few soft-edged blobs + mild speckle that
     survives the x4 box down-sampling only partly.  Values in [0,1]."""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -45,7 +45,9 @@ def smooth_hr(B, size, seed, device):
         img = img + a * torch.sigmoid((r - d) * 60.0)
     speck = torch.randn(B, 1, size // 2, size // 2, generator=g)
     speck = F.interpolate(speck, size=(size, size), mode="bilinear", align_corners=False) * 0.03
-    img = (0.45 + img + speck).clamp(0, 1)
+    # full-resolution white speckle: the x4 box filter leaves a quarter of its amplitude in the LR image, the rest is
+    # unrecoverable detail -- it caps the reachable PSNR-Y near 33 dB, the published CCA-US x4 operating point (32.72 dB)
+    img = (0.45 + img + speck + noise * torch.randn(B, 1, size, size, generator=g)).clamp(0, 1)
     tint = torch.tensor([1.0, 0.97, 0.94]).view(1, 3, 1, 1)
     return (img * tint).clamp(0, 1).to(device)
 
@@ -77,6 +79,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-4, help="learning rate of the compared steps (the reference's, train.py:81)")
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--held", type=int, default=8, help="held-out batches of 2 images")
+    ap.add_argument("--decay-steps", type=int, default=200, help="second comparison: this many steps with the rate annealed --lr -> 1e-6 (end of training)")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--json", default=None)
     args = ap.parse_args()
@@ -133,27 +136,31 @@ def main():
         print(row, flush=True)
     # N identical steps from the same state, fp32 vs bf16 compute
     state = (m32.flat_params.clone(), ts.exp_avg.clone(), ts.exp_avg_sq.clone(), ts.step_count)
-    res = {}
-    # "fp32+eps": the fp32 arm again from weights perturbed by 1e-6 relative -- how far two fp32 trajectories drift apart
-    # on their own (the noise floor of this comparison)
-    for dt, model in (("fp32", m32), ("bf16", m16), ("fp32+eps", m32)):
-        model.flat_params.copy_(state[0])
-        if dt == "fp32+eps":
-            g = torch.Generator(device="cpu").manual_seed(99)
-            model.flat_params.mul_(1.0 + 1e-6 * torch.randn(model.flat_params.numel(), generator=g).to(dev))
-        t = TrainStep(model, lr=args.lr, world_size=1)
-        t.exp_avg.copy_(state[1]); t.exp_avg_sq.copy_(state[2]); t.step_count = state[3]
-        losses = []
-        for s in range(args.steps):
-            l, h = pair(args.batch, lr_size, scale, 500000 + s, dev)
-            losses.append(float(t.step(l, h)))
-        res[dt] = {"psnr_y": held_psnr(model), "last_loss": losses[-1]}
-        print(dt, res[dt], flush=True)
-    d = abs(res["fp32"]["psnr_y"] - res["bf16"]["psnr_y"])
-    out["drift"].update({"steps": args.steps, "lr": args.lr, "psnr_y_fp32": round(res["fp32"]["psnr_y"], 4), "psnr_y_bf16": round(res["bf16"]["psnr_y"], 4),
-                         "abs_delta_dB": round(d, 4), "psnr_y_fp32_perturbed_1e-6": round(res["fp32+eps"]["psnr_y"], 4),
-                         "noise_floor_dB": round(abs(res["fp32"]["psnr_y"] - res["fp32+eps"]["psnr_y"]), 4)})
-    print("DRIFT", out["drift"], flush=True)
+    def arms(n_steps, decay):
+        res = {}
+        # "fp32+eps": the fp32 arm again from weights perturbed by 1e-6 relative -- how far two fp32 trajectories drift apart
+        # on their own (the noise floor of this comparison)
+        for dt, model in (("fp32", m32), ("bf16", m16), ("fp32+eps", m32)):
+            model.flat_params.copy_(state[0])
+            if dt == "fp32+eps":
+                g = torch.Generator(device="cpu").manual_seed(99)
+                model.flat_params.mul_(1.0 + 1e-6 * torch.randn(model.flat_params.numel(), generator=g).to(dev))
+            t = TrainStep(model, lr=args.lr, world_size=1)
+            t.exp_avg.copy_(state[1]); t.exp_avg_sq.copy_(state[2]); t.step_count = state[3]
+            for s in range(n_steps):
+                if decay:
+                    t.set_lr(1e-6 + 0.5 * (args.lr - 1e-6) * (1.0 + math.cos(math.pi * s / n_steps)))
+                l, h = pair(args.batch, lr_size, scale, 500000 + s, dev)
+                t.step(l, h)
+            res[dt] = held_psnr(model)
+        tag = f"{n_steps} steps, " + ("lr annealed to 1e-6" if decay else f"lr {args.lr}")
+        row = {"schedule": tag, "psnr_y_fp32": round(res["fp32"], 4), "psnr_y_bf16": round(res["bf16"], 4),
+               "abs_delta_dB": round(abs(res["fp32"] - res["bf16"]), 4), "noise_floor_dB": round(abs(res["fp32"] - res["fp32+eps"]), 5)}
+        print("DRIFT", row, flush=True)
+        return row
+
+    out["drift"]["constant_lr"] = arms(args.steps, False)
+    out["drift"]["annealed"] = arms(args.decay_steps, True)
     if args.json:
         json.dump(out, open(args.json, "w"), indent=1)
 
