@@ -164,6 +164,26 @@ int m2t_semantic_loss(const float* emb, const float* text, int B, int n_patches,
 /* F.interpolate(mode='bicubic', align_corners=True) (losses.py:53-54): src [NC,Hin,Win] -> dst [NC,Hout,Wout]. */
 int m2t_bicubic_resize(const float* src, float* dst, int NC, int Hin, int Win, int Hout, int Wout, void* stream);
 
+/* ---- SemanticLoss text tower (losses.py:22-25,64-65,74): medmodel.encode_text ---------------------------------
+ * BERT-base forward (Bio_ClinicalBERT geometry: 12 layers x 768, 12 heads, 3072 intermediate, vocab 28 996, LayerNorm eps
+ * 1e-12, erf GELU) -> mean over the tokens of hidden states 1, 2 and -1 -> Linear(768, 512, no bias) -> unit L2 norm, as the
+ * un-vendored `medclip` package defines MedCLIPTextModel.forward / MedCLIPModel.encode_text (PARITY UNPINNED: package and
+ * checkpoint absent from the reference tree).  Forward only (torch.no_grad() in the reference, losses.py:63).
+ * Weights: ONE flat float32 buffer in the order of m2t_text_param_name(): HF BertModel checkpoint names of transformers
+ * 4.24 without `pooler.*`, then "projection_head.weight" [512,768]. */
+typedef struct m2t_text m2t_text;
+int m2t_text_create(m2t_text** out, int max_seqs, int max_len /* <= 128 */, int dtype);
+void m2t_text_destroy(m2t_text* p);
+/* "workspace_bytes", "num_params", "num_param_tensors", "max_seqs", "max_len", "param:<name>", "numel:<name>" */
+long long m2t_text_query(const m2t_text* p, const char* key);
+const char* m2t_text_param_name(const m2t_text* p, int index);
+int m2t_text_load_weights(m2t_text* p, const float* weights, void* workspace, void* stream);
+/* ids_host, mask_host: int[n][len] in HOST memory (tokenizer output; position ids are 0..len-1 and token types 0, BertModel's
+ * defaults).  The reference passes outputs['token_type_ids'] in the input_ids slot (losses.py:65): a caller that wants the
+ * reference's value passes those zeros here.  -> emb [n][512] float32 on the device, unit norm. */
+int m2t_text_encode(m2t_text* p, const int* ids_host, const int* mask_host, int n, int len, float* emb, void* workspace,
+                    void* stream);
+
 /* ---- util/rlutrans.py TransBlock (dead code in the reference: nothing imports it) --------------------
  * TransBlock.forward (util/rlutrans.py:82-87) for dim = 64, 8 heads: x + EffAttention(LayerNorm(x)) (:30-67: reduce,
  * qkv, softmax attention inside token chunks of length N // 16, proj), then x + Mlp(LayerNorm(x)) (:11-27: 64 -> 16,
@@ -186,6 +206,13 @@ int m2t_transblock_forward(const float* params, const float* x, float* y, int B,
 size_t m2t_eval_metrics_scratch_bytes(int B, int H, int W, int crop);
 int m2t_eval_metrics(const float* sr, const float* hr, int B, int H, int W, int crop, float rgb_range,
                      const float* window_host, void* scratch, double* out, void* stream);
+
+/* piq.gmsd(hr, sr, data_range=1., reduction='none') of the same loop (test.py:98): gradient magnitude similarity deviation of
+ * the 2x2-pooled luminance (0.299 R + 0.587 G + 0.114 B), Prewitt gradients, t = 170 / 255^2, population standard deviation of
+ * the similarity map.  x, y: float32 NCHW [B,3,H,W] on the device; out: double[B] on the device.  The dependency (`piq`) is
+ * absent from the reference tree: PARITY UNPINNED, checked against an fp64 restatement of the published algorithm. */
+size_t m2t_eval_gmsd_scratch_bytes(int B);
+int m2t_eval_gmsd(const float* x, const float* y, int B, int H, int W, float data_range, void* scratch, double* out, void* stream);
 
 /* ---- training input pipeline --------------------------------------------------------------------
  * datas/us1k.py:16-36 crop_patch + utils.py ndarray2tensor + the /255 of datas/us1k.py:169, for n samples at once,

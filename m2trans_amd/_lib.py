@@ -41,10 +41,18 @@ SIGNATURES = {
     "m2t_swin_encode_pair": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, C.POINTER(_i), _i, _vp, _vp, _vp]),
     "m2t_semantic_loss": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "m2t_bicubic_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "m2t_text_create": (_i, [C.POINTER(_vp), _i, _i, _i]),
+    "m2t_text_destroy": (None, [_vp]),
+    "m2t_text_query": (_ll, [_vp, C.c_char_p]),
+    "m2t_text_param_name": (C.c_char_p, [_vp, _i]),
+    "m2t_text_load_weights": (_i, [_vp, _vp, _vp, _vp]),
+    "m2t_text_encode": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), _i, _i, _vp, _vp, _vp]),
     "m2t_transblock_workspace_bytes": (C.c_size_t, [_i, _i, _i]),
     "m2t_transblock_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "m2t_eval_metrics_scratch_bytes": (C.c_size_t, [_i, _i, _i, _i]),
     "m2t_eval_metrics": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    "m2t_eval_gmsd_scratch_bytes": (C.c_size_t, [_i]),
+    "m2t_eval_gmsd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "m2t_crop_patches": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m2t_image_to_tensor": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "m2t_box_mix": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),

@@ -177,3 +177,89 @@ extern "C" int m2t_eval_metrics(const float* sr, const float* hr, int B, int H, 
   M2T_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// GMSD of the eval loop: piq.gmsd(hr, sr, data_range=1., reduction='none') (test.py:98; Xue et al. 2014 as the `piq`
+// package implements it -- PARITY UNPINNED: `piq` is not vendored by the reference nor installed here, the oracle in
+// tests/test_metrics.py restates the published algorithm in fp64):
+//   gray = 0.299 R + 0.587 G + 0.114 B (rgb2yiq Y) of x / data_range; zero-pad bottom / right to even size;
+//   2 x 2 average pooling; Prewitt gradients ([-1 0 1] x 3 / 3 and its transpose, zero padding 1);
+//   gm = sqrt(gx^2 + gy^2); gms = (2 gm_x gm_y + t) / (gm_x^2 + gm_y^2 + t), t = 170 / 255^2;
+//   GMSD = sqrt(mean((gms - mean(gms))^2)) over the pooled map.
+// The map arithmetic is fp32 like the dependency's; the two spatial moments are accumulated in fp64.
+// ---------------------------------------------------------------------------------------
+namespace {
+constexpr int GMSD_CHUNKS = 256;
+__device__ __forceinline__ float gmsd_pooled(const float* img, long long plane, int H, int W, int py, int px, int hp, int wp, float inv_range) {
+  if (py < 0 || py >= hp || px < 0 || px >= wp) return 0.f;            // zero padding of the Prewitt convolution
+  float a = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int y = 2 * py + dy, x = 2 * px + dx;
+      float g = 0.f;
+      if (y < H && x < W) {                                              // the pad row / column of an odd-sized image is zero
+        const long long o = (long long)y * W + x;
+        g = 0.299f * (img[o] * inv_range) + 0.587f * (img[plane + o] * inv_range) + 0.114f * (img[2 * plane + o] * inv_range);
+      }
+      a += g;
+    }
+  return a * 0.25f;
+}
+__global__ __launch_bounds__(256) void eval_gmsd_kernel(const float* __restrict__ xr, const float* __restrict__ yr, int H, int W, int hp, int wp,
+                                                        float inv_range, double* __restrict__ partial) {
+  __shared__ double red[4];
+  const int b = blockIdx.y;
+  const long long plane = (long long)H * W, n = (long long)hp * wp;
+  const float* xs = xr + (long long)b * 3 * plane;
+  const float* ys = yr + (long long)b * 3 * plane;
+  const float t = 170.0f / (255.0f * 255.0f);
+  double s1 = 0.0, s2 = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int py = (int)(i / wp), px = (int)(i % wp);
+    float gm[2];
+#pragma unroll
+    for (int im = 0; im < 2; ++im) {
+      const float* img = im ? ys : xs;
+      float v[3][3];
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) v[dy][dx] = gmsd_pooled(img, plane, H, W, py + dy - 1, px + dx - 1, hp, wp, inv_range);
+      const float gx = ((v[0][2] - v[0][0]) + (v[1][2] - v[1][0]) + (v[2][2] - v[2][0])) * (1.0f / 3.0f);
+      const float gy = ((v[2][0] - v[0][0]) + (v[2][1] - v[0][1]) + (v[2][2] - v[0][2])) * (1.0f / 3.0f);
+      gm[im] = sqrtf(gx * gx + gy * gy);
+    }
+    const float gms = (2.0f * gm[0] * gm[1] + t) / (gm[0] * gm[0] + gm[1] * gm[1] + t);
+    s1 += (double)gms;
+    s2 += (double)gms * (double)gms;
+  }
+  const double a = block_sum_256(s1, red);
+  const double q = block_sum_256(s2, red);
+  if (threadIdx.x == 0) { partial[((long long)b * GMSD_CHUNKS + blockIdx.x) * 2] = a; partial[((long long)b * GMSD_CHUNKS + blockIdx.x) * 2 + 1] = q; }
+}
+__global__ __launch_bounds__(256) void eval_gmsd_finalize_kernel(const double* __restrict__ partial, double n, double* __restrict__ out) {
+  __shared__ double red[4];
+  const int b = blockIdx.x;
+  const double a = block_sum_256(partial[((long long)b * GMSD_CHUNKS + threadIdx.x) * 2], red);
+  const double q = block_sum_256(partial[((long long)b * GMSD_CHUNKS + threadIdx.x) * 2 + 1], red);
+  if (threadIdx.x == 0) {
+    const double mean = a / n;
+    out[b] = sqrt(fmax(q / n - mean * mean, 0.0));
+  }
+}
+}  // namespace
+
+extern "C" size_t m2t_eval_gmsd_scratch_bytes(int B) { return B < 1 ? 0 : sizeof(double) * 2 * (size_t)B * GMSD_CHUNKS; }
+extern "C" int m2t_eval_gmsd(const float* x, const float* y, int B, int H, int W, float data_range, void* scratch, double* out, void* stream) {
+  if (!x || !y || !scratch || !out || B < 1 || B > 65535 || H < 2 || W < 2 || !(data_range > 0.f))
+    return m2t_set_error(M2T_ERR_ARG, "m2t_eval_gmsd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int hp = (H + (H & 1 ? 1 : (W & 1))) / 2, wp = (W + (W & 1 ? 1 : (H & 1))) / 2;   // piq pads BOTH dims by max(H % 2, W % 2)
+  eval_gmsd_kernel<<<dim3(GMSD_CHUNKS, B), 256, 0, st>>>(x, y, H, W, hp, wp, 1.0f / data_range, (double*)scratch);
+  M2T_LAUNCH_CHECK();
+  eval_gmsd_finalize_kernel<<<B, 256, 0, st>>>((const double*)scratch, (double)hp * wp, out);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}

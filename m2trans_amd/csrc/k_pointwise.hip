@@ -1144,12 +1144,16 @@ int launch_adam(float* p, const float* g, float* m, float* v, long long n, float
 // =======================================================================================
 template <typename T>
 __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ master, T* __restrict__ packed,
-                                                   const m2t_pack_desc* __restrict__ descs) {
-  const m2t_pack_desc d = descs[blockIdx.y];
+                                                   const m2t_pack_desc* __restrict__ descs, const int2* __restrict__ blocks) {
+  // one workgroup per M2T_PACK_CHUNK output elements: blocks[i] = (descriptor, chunk).  (16 workgroups per descriptor --
+  // 48 dependent gathers per thread on the 196 608-element attention weights -- took 98 us at the head of every step)
+  const int2 bk = blocks[blockIdx.x];
+  const m2t_pack_desc d = descs[bk.x];
   const float* s = master + d.src_off;
   T* o = packed + d.dst_off;
   const int n = (int)d.n;                  // every packed tensor has < 2^31 elements: 32-bit index math (64-bit division is a software loop)
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+  const int e0 = bk.y * M2T_PACK_CHUNK, e1 = min(n, e0 + M2T_PACK_CHUNK);
+  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
     long long si = e;
     switch (d.kind) {
       case M2T_PACK_COPY: break;
@@ -1199,9 +1203,9 @@ __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ mas
     o[e] = from_f<T>(s[si]);
   }
 }
-int launch_pack(int dt, const float* master, void* packed, const m2t_pack_desc* descs, int ndesc, hipStream_t st) {
-  if (dt == M2T_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(16, ndesc), dim3(256), 0, st, master, (float*)packed, descs);
-  else hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(16, ndesc), dim3(256), 0, st, master, (bf16_t*)packed, descs);
+int launch_pack(int dt, const float* master, void* packed, const m2t_pack_desc* descs, const void* blocks, int nblocks, hipStream_t st) {
+  if (dt == M2T_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(nblocks), dim3(256), 0, st, master, (float*)packed, descs, (const int2*)blocks);
+  else hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, st, master, (bf16_t*)packed, descs, (const int2*)blocks);
   M2T_LAUNCH_CHECK();
   return 0;
 }

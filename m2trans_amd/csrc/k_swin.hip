@@ -49,7 +49,8 @@ int launch_swin_patchify(int dt, const float* src, const float* src_b, int n_a, 
 // ---------------------------------------------------------------------------------------
 template <typename T, int G, int NV>
 __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, T* __restrict__ y, long long M, int C) {
+                                                        const float* __restrict__ beta, T* __restrict__ y, long long M, int C,
+                                                        float eps) {
   constexpr int RPW = 64 / G;                      // rows per wave
   const int lane = threadIdx.x & 63, gl = lane % G, sub = lane / G;
   const long long wave = (blockIdx.x * (long long)blockDim.x + threadIdx.x) >> 6;
@@ -91,7 +92,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
         for (int e = 0; e < 8; ++e) { const float d = act[v] ? v8[u][v][e] - mean : 0.f; q += d * d; }
 #pragma unroll
       for (int o = 1; o < G; o <<= 1) q += __shfl_xor(q, o);
-      const float rstd = 1.0f / sqrtf(q * invC + 1e-5f);
+      const float rstd = 1.0f / sqrtf(q * invC + eps);
       if (r0 + u * nw * RPW + sub < M) {
 #pragma unroll
         for (int v = 0; v < NV; ++v)
@@ -105,12 +106,12 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const T* __restrict__ x,
     }
   }
 }
-int launch_layernorm(int dt, const void* x, const float* gamma, const float* beta, void* y, long long M, int C, hipStream_t st) {
+int launch_layernorm(int dt, const void* x, const float* gamma, const float* beta, void* y, long long M, int C, hipStream_t st, float eps) {
   if (C % 8 || C > 1536) return m2t_set_error(-2, "layernorm: C must be a multiple of 8, at most 1536");
 #define LN_GO(T_, G_, NV_)                                                                                           \
   {                                                                                                                  \
     const int g = (int)std::min<long long>(ceil_divll(M, 4 * (64 / G_)), 2048);   /* gamma / beta are re-read per thread */ \
-    hipLaunchKernelGGL((layernorm_kernel<T_, G_, NV_>), dim3(g), dim3(256), 0, st, (const T_*)x, gamma, beta, (T_*)y, M, C); \
+    hipLaunchKernelGGL((layernorm_kernel<T_, G_, NV_>), dim3(g), dim3(256), 0, st, (const T_*)x, gamma, beta, (T_*)y, M, C, eps); \
   }
 #define LN_T(T_)                                                                                                     \
   if (C <= 128) LN_GO(T_, 16, 1) else if (C <= 256) LN_GO(T_, 32, 1) else if (C <= 512) LN_GO(T_, 64, 1)             \

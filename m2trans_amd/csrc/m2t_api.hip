@@ -127,6 +127,7 @@ struct m2t_plan {
   std::map<std::string, WsTensor> ws;
   size_t ws_bytes = 0;
   std::vector<m2t_pack_desc> descs;
+  std::vector<int> pack_blocks;              // (descriptor, chunk) pairs: one workgroup of the packing kernel each
   std::map<std::string, long long> pk;       // packed weight offsets (elements of T)
   long long npacked = 0;
   bool have_seed = false, have_acts = false;
@@ -265,6 +266,9 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   const long long BP = (long long)B * p->P;
   p->add_ws("zero_page", 256, 1);          // source of every out-of-image pixel the LDS-DMA kernels stage (k_conv.hip)
   p->add_ws("pack_descs", p->descs.size() * sizeof(m2t_pack_desc), 1);
+  for (size_t i = 0; i < p->descs.size(); ++i)
+    for (long long c = 0; c * M2T_PACK_CHUNK < p->descs[i].n; ++c) { p->pack_blocks.push_back((int)i); p->pack_blocks.push_back((int)c); }
+  p->add_ws("pack_blocks", p->pack_blocks.size() * sizeof(int), 1);
   p->add_ws("packed", p->npacked, es);
   for (int b = 0; b <= n_blocks; ++b) p->add_ws("X" + std::to_string(b), BP * 64, es);
   for (int b = 0; b < n_blocks; ++b) {
@@ -389,6 +393,8 @@ extern "C" int m2t_plan_init_workspace(m2t_plan* p, void* workspace, void* strea
   hipError_t e = hipMemcpyAsync(WSP("pack_descs"), p->descs.data(), p->descs.size() * sizeof(m2t_pack_desc),
                                 hipMemcpyHostToDevice, (hipStream_t)stream);
   if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+  e = hipMemcpyAsync(WSP("pack_blocks"), p->pack_blocks.data(), p->pack_blocks.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
   e = hipMemsetAsync(WSP("zero_page"), 0, 256, (hipStream_t)stream);
   if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
   e = hipStreamSynchronize((hipStream_t)stream);   // the host table may be freed/moved afterwards
@@ -409,7 +415,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
   const long long BP = (long long)B * p->P;
   (void)keep_activations;   // v1 keeps every activation in the workspace either way
   // (re-packing on the side stream under the head conv was measured: -0.4 %, both kernels are bound by workgroup launch rate)
-  CK(launch_pack(dt, params, WSP("packed"), (const m2t_pack_desc*)WSP("pack_descs"), (int)p->descs.size(), st));
+  CK(launch_pack(dt, params, WSP("packed"), (const m2t_pack_desc*)WSP("pack_descs"), WSP("pack_blocks"), (int)(p->pack_blocks.size() / 2), st));
   CK(launch_head_conv_fwd(dt, x, params + p->poff.at("head.weight"), params + p->poff.at("head.bias"), WSP("X0"), B,
                           p->H0, p->W0, H, W, st));
   for (int b = 0; b < p->nb; ++b) {

@@ -7,6 +7,7 @@
 #define M2T_NORM_SPLIT 32     // pixel splits per image in the InstanceNorm reductions
 #define M2T_LOSS_BLOCKS 1024  // partial sums of the L1 loss
 #define M2T_MAX_SLABS 1024    // split-M slabs of a weight-gradient GEMM
+#define M2T_PACK_CHUNK 2048   // output elements one workgroup of the weight-packing kernel converts
 
 enum m2t_pack_kind {
   M2T_PACK_COPY = 0, M2T_PACK_TRANSPOSE = 1, M2T_PACK_CONV3 = 2, M2T_PACK_CONV3_T = 3,
@@ -82,7 +83,8 @@ int launch_clamp_l1(const float* pre, const float* hr, float* sr, float* gpre, f
                     int Wp, int Hs, int Ws, float R, float loss_scale, float gscale, hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
                 int step, float gscale, hipStream_t st);
-int launch_pack(int dt, const float* master, void* packed, const m2t_pack_desc* descs, int ndesc, hipStream_t st);
+// blocks: device table int2[nblocks] = (descriptor index, chunk of M2T_PACK_CHUNK output elements)
+int launch_pack(int dt, const float* master, void* packed, const m2t_pack_desc* descs, const void* blocks, int nblocks, hipStream_t st);
 int launch_layout(int dt, const float* nchw, void* nhwc, float* nchw_out, int B, int C, int HW, int inverse, hipStream_t st);
 
 // ---- k_gemm.hip -------------------------------------------------------------------------
@@ -208,7 +210,8 @@ int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int*
 // ---- k_swin.hip (MedCLIP image tower = Swin-T forward, losses.py:68-69) --------------------
 int launch_swin_patchify(int dt, const float* src, const float* src_b, int n_a, int Hs, int Ws, const int* crops, int n, void* out,
                          hipStream_t st);
-int launch_layernorm(int dt, const void* x, const float* gamma, const float* beta, void* y, long long M, int C, hipStream_t st);
+int launch_layernorm(int dt, const void* x, const float* gamma, const float* beta, void* y, long long M, int C, hipStream_t st,
+                     float eps = 1e-5f);     // (Swin / TransBlock: 1e-5; BERT: 1e-12)
 // fused Swin MLP (bf16, C = 96 / 192): X <- X + fc2(gelu(fc1(LayerNorm(X)) + b1)) + b2, weights in FRAG16 order
 int launch_swin_mlp_fused(void* X, const float* gamma, const float* beta, const void* w1f, const float* b1, const void* w2f,
                           const float* b2, long long M, int C, hipStream_t st);

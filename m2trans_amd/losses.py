@@ -16,8 +16,10 @@ evaluated without gradient (losses.py:63): the term shifts the logged loss, not 
 PARITY UNPINNED: the `medclip` package, its Swin/BERT checkpoints and tokenizer are not vendored
 by the reference.  Weights are therefore injected (``load_state_dict`` with HF swin-tiny names,
 4.24 or 5.x spelling, plus ``projection_head.weight``); text features are injected per caption
-(``set_text_features``) -- they are constants of the frozen text tower.  A caption without an injected
-text feature RAISES (``synthetic_text=True`` opts into a deterministic hash stand-in for benchmarks).
+(``set_text_features``) or computed by the text tower built here (``load_text_encoder`` / ``load_medclip_state_dict``:
+BERT-base forward + the MedCLIP head behind ``m2t_text_*``, with the reference's input_ids quirk of losses.py:65; the
+tokenizer is a host callable) -- they are constants of the frozen text tower, cached per caption.  A caption with neither
+RAISES (``synthetic_text=True`` opts into a deterministic hash stand-in for benchmarks).
 """
 from __future__ import annotations
 
@@ -123,6 +125,83 @@ class SwinEncoder:
             pass
 
 
+class TextEncoder:
+    """m2t_text handle + workspace + flat weights: ``medmodel.encode_text`` (losses.py:65,74) = BERT-base -> mean of hidden
+    states 1, 2, -1 -> Linear(768, 512) -> unit norm, as hand-written kernels behind ``m2t_text_*`` (csrc/m2t_text.hip)."""
+
+    def __init__(self, max_seqs: int, max_len: int, dtype: int, device):
+        lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(lib.m2t_text_create(C.byref(h), max_seqs, max_len, dtype), "m2t_text_create")
+        self.handle, self.max_seqs, self.max_len, self.dtype, self.device = h, max_seqs, max_len, dtype, device
+        self.names: List[str] = []
+        self.slots: Dict[str, tuple] = {}
+        for i in range(self.query("num_param_tensors")):
+            n = lib.m2t_text_param_name(h, i).decode()
+            self.names.append(n)
+            self.slots[n] = (self.query("param:" + n), self.query("numel:" + n))
+        self.flat = torch.zeros(self.query("num_params"), dtype=torch.float32, device=device)
+        self.workspace = torch.empty(self.query("workspace_bytes"), dtype=torch.uint8, device=device)
+        self.loaded = False
+
+    def query(self, key: str) -> int:
+        v = _lib.load().m2t_text_query(self.handle, key.encode())
+        if v < 0:
+            raise KeyError(key)
+        return int(v)
+
+    def load(self, state: Dict[str, torch.Tensor]):
+        """HF BertModel names (transformers 4.24), optionally behind the MedCLIP checkpoint's ``text_model.model.`` /
+        ``text_model.`` prefixes (or ``bert.`` / ``model.``), plus ``projection_head.weight``; ``pooler.*``,
+        ``embeddings.position_ids`` and anything else are ignored; a word-embedding table with fewer rows than the
+        Bio_ClinicalBERT vocabulary fills the first rows."""
+        seen = set()
+        for k, v in state.items():
+            for prefix in ("text_model.model.", "text_model.", "model.", "bert."):
+                if k.startswith(prefix) and k[len(prefix):] in self.slots:
+                    k = k[len(prefix):]
+                    break
+            if k not in self.slots:
+                continue
+            o, n = self.slots[k]
+            if k == "embeddings.word_embeddings.weight" and v.dim() == 2 and v.shape[1] == 768 and v.numel() < n:
+                self.flat[o:o + v.numel()].copy_(v.reshape(-1).to(self.flat))
+            elif v.numel() != n:
+                raise M2TError(f"shape mismatch for {k}: {tuple(v.shape)}")
+            else:
+                self.flat[o:o + n].copy_(v.reshape(-1).to(self.flat))
+            seen.add(k)
+        missing = [n for n in self.names if n not in seen]
+        if missing:
+            raise M2TError(f"missing text-tower weights: {missing[:5]} ... ({len(missing)})")
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().m2t_text_load_weights(self.handle, _lib.ptr(self.flat), _lib.ptr(self.workspace),
+                                                         _lib.stream_ptr()), "m2t_text_load_weights")
+        self.loaded = True
+
+    def encode(self, input_ids, attention_mask) -> torch.Tensor:
+        """input_ids, attention_mask: [n, len] integer arrays (host) -> [n,512] unit-norm embeddings on the device."""
+        if not self.loaded:
+            raise M2TError("TextEncoder: weights not loaded")
+        ids = torch.as_tensor(input_ids, dtype=torch.int32).reshape(-1, torch.as_tensor(input_ids).shape[-1]).contiguous().cpu()
+        mask = torch.as_tensor(attention_mask, dtype=torch.int32).reshape(ids.shape).contiguous().cpu()
+        n, ln = ids.shape
+        emb = torch.empty(n, 512, dtype=torch.float32, device=self.device)
+        ip, mp = C.cast(ids.data_ptr(), C.POINTER(C.c_int)), C.cast(mask.data_ptr(), C.POINTER(C.c_int))
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.load().m2t_text_encode(self.handle, ip, mp, n, ln, _lib.ptr(emb), _lib.ptr(self.workspace),
+                                                   _lib.stream_ptr()), "m2t_text_encode")
+        return emb
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().m2t_text_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 def hash_text_feature(caption: str) -> torch.Tensor:
     """Deterministic stand-in for the frozen text tower (NOT the MedCLIP embedding)."""
     seed = int.from_bytes(hashlib.sha256(caption.encode("utf-8")).digest()[:8], "little") % (2 ** 31)
@@ -146,6 +225,10 @@ class SemanticLoss(nn.Module):
         self._state: Optional[Dict[str, torch.Tensor]] = None
         self._text: Dict[str, torch.Tensor] = {}
         self._text_dev = None
+        self._tenc: Optional[TextEncoder] = None
+        self._text_state: Optional[Dict[str, torch.Tensor]] = None
+        self._by_count: Dict[int, torch.Tensor] = {}       # text feature per token count (see _text_feature)
+        self.tokenizer = None                               # callable(caption) -> {'token_type_ids': [..], 'attention_mask': [..]}
 
     # ---- injected constants -----------------------------------------------------------------
     def load_image_encoder(self, state_dict: Dict[str, torch.Tensor]):
@@ -153,6 +236,35 @@ class SemanticLoss(nn.Module):
         self._state = {k: v.detach() for k, v in state_dict.items()}
         if self._enc is not None:
             self._enc.load(self._state)
+
+    def load_text_encoder(self, state_dict: Dict[str, torch.Tensor], tokenizer=None):
+        """The MedCLIP text tower: HF BertModel names (4.24) + 'projection_head.weight' [512,768] (see TextEncoder.load),
+        and the tokenizer the reference builds with ``MedCLIPProcessor()`` (losses.py:25,64): any callable
+        ``tokenizer(caption) -> mapping with 'token_type_ids' and 'attention_mask'`` (one sequence).  The tokenizer stays
+        on the host; its vocabulary file ships with the checkpoint, not with this build."""
+        self._text_state = {k: v.detach() for k, v in state_dict.items()}
+        if tokenizer is not None:
+            self.tokenizer = tokenizer
+        self._tenc = None
+        self._by_count.clear()
+
+    def load_medclip_state_dict(self, state_dict: Dict[str, torch.Tensor], tokenizer=None):
+        """A whole MedCLIPModel checkpoint (``vision_model.*`` / ``text_model.*`` / ``logit_scale``, the file
+        pretrained/medclip-vit/readme.md:1-5 points at): both towers at once."""
+        vis = {k[len("vision_model."):] if k.startswith("vision_model.projection_head") else k: v
+               for k, v in state_dict.items() if k.startswith("vision_model.")}
+        txt = {k: v for k, v in state_dict.items() if k.startswith("text_model.")}
+        self.load_image_encoder(vis)
+        self.load_text_encoder(txt, tokenizer)
+
+    def _text_encoder(self) -> TextEncoder:
+        if self._tenc is None:
+            if self.device.type != "cuda":
+                raise M2TError("SemanticLoss (MI355X build) needs a HIP device; there is no CPU fallback")
+            code = _lib.F32 if self.compute_dtype in ("fp32", "float32") else _lib.BF16
+            self._tenc = TextEncoder(1, 128, code, self.device)
+            self._tenc.load(self._text_state)
+        return self._tenc
 
     def set_text_features(self, table: Dict[str, torch.Tensor]):
         self._text.update({k: v.detach().float().reshape(512).cpu() for k, v in table.items()})
@@ -172,6 +284,20 @@ class SemanticLoss(nn.Module):
     def _text_feature(self, caption: str) -> torch.Tensor:
         t = self._text.get(caption)
         if t is not None:
+            return t
+        if self._text_state is not None and self.tokenizer is not None:
+            # losses.py:64-65: tokenizer(text=[caption]) then encode_text(outputs['token_type_ids'], outputs['attention_mask'])
+            # -- the token-type ids (zeros) travel in the input_ids slot, so the feature is a function of the token count
+            tok = self.tokenizer(caption)
+            ids = [int(v) for v in torch.as_tensor(tok["token_type_ids"]).reshape(-1).tolist()]
+            mask = [int(v) for v in torch.as_tensor(tok["attention_mask"]).reshape(-1).tolist()]
+            key = len(ids) if (not any(ids) and all(mask)) else None
+            t = self._by_count.get(key) if key is not None else None
+            if t is None:
+                t = self._text_encoder().encode([ids], [mask])[0].cpu()
+                if key is not None:
+                    self._by_count[key] = t
+            self._text[caption] = t
             return t
         if not self.synthetic_text:
             raise M2TError(f"SemanticLoss: no text feature for caption {caption!r}: inject the MedCLIP text embeddings with "

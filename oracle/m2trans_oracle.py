@@ -441,6 +441,27 @@ def adam_update(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, step: int, lr
     return param, m, v
 
 
+def gmsd(x: Tensor, y: Tensor, data_range: float = 1.0) -> Tensor:
+    """piq.gmsd(x, y, data_range, reduction='none') as test.py:98 calls it (Xue et al. 2014, restated from the `piq`
+    package's published source; PARITY UNPINNED: `piq` is not vendored by the reference nor installed here).
+    x, y [B,3,H,W] -> [B] (computed in the input dtype; pass .double() for the yardstick)."""
+    def prep(t):
+        t = t / float(data_range)
+        g = (0.299 * t[:, 0] + 0.587 * t[:, 1] + 0.114 * t[:, 2]).unsqueeze(1)          # rgb2yiq(x)[:, :1]
+        dp = max(g.shape[2] % 2, g.shape[3] % 2)
+        g = F.pad(g, [0, dp, 0, dp])
+        return F.avg_pool2d(g, kernel_size=2, stride=2, padding=0)
+    kx = torch.tensor([[-1.0, 0.0, 1.0]] * 3, dtype=x.dtype) / 3.0
+    k = torch.stack([kx, kx.t()]).unsqueeze(1)                                          # prewitt and its transpose
+    def grad(t):
+        return torch.sqrt(torch.sum(F.conv2d(t, k, padding=1) ** 2, dim=-3, keepdim=True))
+    gx, gy = grad(prep(x)), grad(prep(y))
+    c = 170.0 / (255.0 ** 2)
+    gms = (2.0 * gx * gy + c) / (gx ** 2 + gy ** 2 + c)
+    mean = gms.mean(dim=[1, 2, 3], keepdim=True)
+    return torch.pow(gms - mean, 2).mean(dim=[1, 2, 3]).sqrt()
+
+
 # --------------------------------------------------------------------------------------
 # metric   (utils.py:121-146,179-184; test.py:101-114 / train.py:299-312)
 # --------------------------------------------------------------------------------------

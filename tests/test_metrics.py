@@ -23,6 +23,50 @@ def _pair(B, H, W, noise=0.0, seed=0):
 
 
 # ------------------------------------------------------------------------------------------------ oracle (CPU)
+def test_gmsd_oracle_anchors():
+    """GMSD (piq.gmsd, test.py:98; parity unpinned): identical images -> every similarity is 1 -> deviation 0; symmetric in its
+    arguments; a tiny case evaluated by hand (2x2-pooled luminance, Prewitt / 3 with zero padding, t = 170 / 255^2)."""
+    sr, hr = _pair(2, 64, 48, noise=0.05)
+    assert float(O.gmsd(hr.double(), hr.double()).abs().max()) == 0.0
+    a, b = O.gmsd(hr.double(), sr.double()), O.gmsd(sr.double(), hr.double())
+    assert torch.allclose(a, b, rtol=0, atol=1e-15) and float(a.min()) > 0
+    v = 0.6
+    x = torch.zeros(1, 3, 4, 4, dtype=torch.float64)
+    x[..., 2:] = v                                # left half 0, right half v -> pooled map [[0, v], [0, v]]
+    y = torch.full_like(x, 0.3)
+    g = float(O.gmsd(x, y)[0])
+    c = 170.0 / 255.0 ** 2
+    lum = lambda t: t * (0.299 + 0.587 + 0.114)
+
+    def gm(p):
+        q = np.pad(np.array(p, dtype=np.float64), 1)
+        out = np.zeros((2, 2))
+        for i in range(2):
+            for j in range(2):
+                w = q[i:i + 3, j:j + 3]
+                gx = (w[:, 2] - w[:, 0]).sum() / 3.0
+                gy = (w[2, :] - w[0, :]).sum() / 3.0
+                out[i, j] = math.sqrt(gx * gx + gy * gy)
+        return out
+    gx_, gy_ = gm([[0.0, lum(v)], [0.0, lum(v)]]), gm([[lum(0.3)] * 2] * 2)
+    gms = (2 * gx_ * gy_ + c) / (gx_ ** 2 + gy_ ** 2 + c)
+    assert abs(g - float(np.sqrt(((gms - gms.mean()) ** 2).mean()))) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,noise", [(2, 128, 128, 0.05), (1, 99, 75, 0.1), (1, 64, 51, 0.02), (3, 33, 40, 0.0)])
+def test_device_gmsd_matches_oracle(B, H, W, noise):
+    from m2trans_amd.metrics import gmsd_device
+    sr, hr = _pair(B, H, W, noise=noise, seed=W)
+    got = gmsd_device(hr.cuda(), sr.cuda(), 1.0).cpu()
+    want64 = O.gmsd(hr.double(), sr.double())
+    want32 = O.gmsd(hr, sr).double()
+    # fp32 map arithmetic (like the dependency), fp64 moments: within fp32 rounding of the fp64 formula and of the fp32 one
+    assert torch.allclose(got, want64, rtol=0, atol=2e-6), (got, want64)
+    assert torch.allclose(got, want32, rtol=0, atol=2e-6), (got, want32)
+    assert float(gmsd_device(hr.cuda(), hr.cuda()).abs().max()) == 0.0
+
+
 def test_mse_y_is_what_psnr_y_takes_the_log_of():
     sr, hr = _pair(1, 48, 40)
     assert abs(-10.0 * math.log10(float(O.mse_y(sr, hr, 4)[0])) - O.psnr_y(sr, hr, 4)) < 1e-12
@@ -136,10 +180,14 @@ def test_evaluate_loop_matches_oracle_on_model_outputs():
         hr = O.closed_form_image(1, 3, h * scale, w * scale, phase=0.1 * i + 0.05).cuda()
         pairs.append((lr, hr))
     got = evaluate(model, pairs, scale)
+    got3 = evaluate(model, pairs, scale, with_gmsd=True)
+    gs = []
     with torch.no_grad():
         for lr, hr in pairs:
             sr = model(lr).cpu()
             ps.append(O.psnr_y(sr, hr.cpu(), scale))
             ss.append(float(O.ssim_y(sr, hr.cpu(), scale, dtype=torch.float64)[0]))
+            gs.append(float(O.gmsd(hr.cpu().double(), sr.double())[0]))
     want = (round(sum(ps) / len(ps) + 5e-3, 2), round(sum(ss) / len(ss) + 5e-5, 4))
     assert got == want, (got, want)
+    assert got3[:2] == want and abs(got3[2] - round(sum(gs) / len(gs) + 5e-5, 4)) <= 1e-4, (got3, gs)
