@@ -64,14 +64,15 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "wgrad_big_tiles"   [-1] qkv weight gradient of the C = 256 branches with 128 x 128 output tiles: value = target number of
  *                           workgroups (64..512), 0 = off, -1 = auto (256 from 24 576 branch pixels on, i.e. batch >= 24)
  *   "fused_tail_bwd"    [1] bf16 x4: one fused kernel for the high-resolution half of the tail backward (k_tail_bwd.hip)
- *   "fused_tail_fwd"    [0] bf16 x4: tail.3 expansion + PixelShuffle + GELU + tail conv in one kernel (k_tail_fwd.hip); gelu(t2) and
+ *   "fused_tail_fwd"    [1] bf16 x4: tail.3 expansion + PixelShuffle + GELU + tail conv in one kernel (k_tail_fwd.hip); gelu(t2) and
  *                           gelu'(t2) are then never stored and the fused tail backward recomputes them per tile (needs
  *                           "fused_tail_bwd"); m2t_plan_query("stores_t2") tells whether ws:t2act / ws:t2der are written
  *   "attn_bwd"          [2] bf16 attention backward: 0 = chunked kernels + halo gather + data-gradient GEMM, 1 = whole-window-
  *                           resident / wave-per-window kernels, 2 = 1 + the data gradient of the qkv projection inside the
  *                           C = 64 / 256 kernels (k_attn_res.hip)
  *   "conv_rows"         [1] bf16 conv3x3 64 -> 64 (forward and data gradient): row-streaming kernel fed by LDS-DMA with the weights in
- *                           registers (k_conv.hip); 0 = the 8 x 16 tile kernel it replaced.  Bit-identical
+ *                           registers (k_conv.hip); 0 = the 8 x 16 tile kernel it replaced (3 / 4: DMA-depth / epilogue variants kept for
+ *                           A/B).  All bit-identical
  *   "fused_attn_fwd"    [1] bf16, C = 64 / 256: qkv projection + window attention + IWT / residual in one kernel per window
  *   "fused_c16_fwd"     [1] bf16, C = 16: InstanceNorm apply + qkv projection + window attention + residual, one wave per window
  *   "debug_skip_side"   [0] timing experiments only: skips every parameter-gradient kernel (results are WRONG) */

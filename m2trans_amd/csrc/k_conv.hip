@@ -416,7 +416,8 @@ __device__ __forceinline__ void c3r_dma16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int NRES, int D, int DR>   // residual tensors (0: data gradient, 1: forward, 2: last block); DMA depth of the input rows / residual rows, in steps
+template <int NRES, int D, int DR, bool PIPE>   // residual tensors (0: data gradient, 1: forward, 2: last block); DMA depth of the input rows /
+                                                 // residual rows, in steps; PIPE: epilogue of step s - 1 under the products of step s
 __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
                                                                   const float* __restrict__ bias, const bf16_t* __restrict__ res1,
                                                                   const bf16_t* __restrict__ res2, bf16_t* __restrict__ y,
@@ -537,8 +538,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* 
   const long long obase = ((long long)plane_o * npix + pb) * 16 + (g & 1) * 8;
   const int laneR = rrw * (4 * C3R_SW * 32) + plane_o * (C3R_SW * 32) + lr * 32 + (g & 1) * 16;   // residual bytes of (row, plane, pixel, half)
 
-#pragma unroll 1
-  for (int s = 0; s < nsteps; ++s) {
+  auto top = [&](int s) {
     // the row pair s + 1 and the residual rows of step s have landed: everything this wave issued up to mark[s] is done ...
     c3r_wait_vm(issued - mark[s % NM]);
     lds_barrier();                                    // ... and so has every other wave's share; all waves are done with step s - 1
@@ -548,66 +548,113 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* 
     if constexpr (NRES > 0) mark[(s + DR) % NM] = issued;        // step s + DR: its residual rows are out (its row pairs went earlier)
     issue_pair(s + 1 + D);
     if constexpr (NRES == 0 || DR == D) mark[(s + D) % NM] = issued;   // step s + D reads pairs s + D, s + D + 1
-
-    f32x4 acc[2][2];
+  };
+  auto tap_products = [&](int tap, f32x4 (&acc)[2][2], const int (&rowoff)[3]) {
+    const int ky = tap / 3, kx = tap - 3 * ky;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int kc = 0; kc < 2; ++kc) {
+      Frag8<T> xf[2];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    int rowoff[3];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) rowoff[ky] = ((2 * s + rrw + ky) % NR) * C3R_ROWB;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - 3 * ky;
-#pragma unroll
-      for (int kc = 0; kc < 2; ++kc) {
-        Frag8<T> xf[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          xf[mt] = load8(reinterpret_cast<const T*>(ring + rowoff[ky] + laneA + kc * (2 * C3R_PXP * 32) + (16 * mt + kx) * 32));
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wreg[tap][kc][nt], xf[mt]);
-      }
-    }
-    C3R_STAMP(3 + 3 * s);
-    // ---- epilogue: + bias + res1 + res2 (this order), one rounding, 16-byte stores ----
-    const int orow = y0 + 2 * s + rrw;
-    float bv[8];
-    {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(&bias_s[32 * (wv & 1) + 8 * g]);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(&bias_s[32 * (wv & 1) + 8 * g + 4]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { bv[e] = b0[e]; bv[4 + e] = b1[e]; }
-    }
-    const unsigned char* rslot = rring + (s % NS) * (((NRES > 0) ? NRES : 1) * C3R_RESB) + laneR;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float v[8];
+      for (int mt = 0; mt < 2; ++mt)
+        xf[mt] = load8(reinterpret_cast<const T*>(ring + rowoff[ky] + laneA + kc * (2 * C3R_PXP * 32) + (16 * mt + kx) * 32));
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
-      if (bias) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bv[e];
-      }
-      if constexpr (NRES > 0) {
-        const Frag8<T> r1 = load8(reinterpret_cast<const T*>(rslot + mt * (16 * 32)));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r1.get(e);
-      }
-      if constexpr (NRES > 1) {
-        const Frag8<T> r2 = load8(reinterpret_cast<const T*>(rslot + C3R_RESB + mt * (16 * 32)));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r2.get(e);
-      }
-      store8f(y + obase + ((long long)orow * W + x0 + 16 * mt + lr) * 16, v);
+        for (int mt = 0; mt < 2; ++mt) mma16(acc[mt][nt], wreg[tap][kc][nt], xf[mt]);
     }
-    issued += 2;
-    C3R_STAMP(4 + 3 * s);
+  };
+  constexpr int NRR = (NRES > 0) ? NRES : 1;
+  auto read_res = [&](int s, Frag8<T> (&rv)[NRR][2]) {           // this lane's residual rows of step s: LDS -> registers
+    if constexpr (NRES > 0) {
+      const unsigned char* rslot = rring + (s % NS) * (NRES * C3R_RESB) + laneR;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        rv[0][mt] = load8(reinterpret_cast<const T*>(rslot + mt * (16 * 32)));
+        if constexpr (NRES > 1) rv[1][mt] = load8(reinterpret_cast<const T*>(rslot + C3R_RESB + mt * (16 * 32)));
+      }
+    }
+  };
+  // epilogue of one 16-pixel tile: + bias + res1 + res2 (this order), one rounding, one 16-byte store
+  auto epi_mt = [&](int mt, const f32x4 (&acc)[2][2], const Frag8<T> (&rv)[NRR][2], int orow) {
+    float v[8];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * nt + r] = acc[mt][nt][r];
+    if (bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(&bias_s[32 * (wv & 1) + 8 * g]);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(&bias_s[32 * (wv & 1) + 8 * g + 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+    }
+    if constexpr (NRES > 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rv[0][mt].get(e);
+    }
+    if constexpr (NRES > 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += rv[1][mt].get(e);
+    }
+    store8f(y + obase + ((long long)orow * W + x0 + 16 * mt + lr) * 16, v);
+  };
+
+  if constexpr (!PIPE) {
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+      top(s);
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      int rowoff[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) rowoff[ky] = ((2 * s + rrw + ky) % NR) * C3R_ROWB;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) tap_products(tap, acc, rowoff);
+      C3R_STAMP(3 + 3 * s);
+      Frag8<T> rv[NRR][2];
+      read_res(s, rv);
+      epi_mt(0, acc, rv, y0 + 2 * s + rrw);
+      epi_mt(1, acc, rv, y0 + 2 * s + rrw);
+      issued += 2;
+      C3R_STAMP(4 + 3 * s);
+    }
+  } else {
+    // software-pipelined: the epilogue of step s - 1 (16 conversions, 2 stores per lane, ~900 cycles on its own) is issued BETWEEN
+    // the MFMAs of step s, whose matrix pipe leaves half of the wave's issue slots free; its accumulators and residual rows
+    // wait in registers across the barrier
+    f32x4 pacc[2][2];
+    Frag8<T> prv[NRR][2];
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+      top(s);
+      f32x4 acc[2][2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      int rowoff[3];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) rowoff[ky] = ((2 * s + rrw + ky) % NR) * C3R_ROWB;
+      const int porow = y0 + 2 * (s - 1) + rrw;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        tap_products(tap, acc, rowoff);
+        if (s > 0 && tap == 1) epi_mt(0, pacc, prv, porow);
+        if (s > 0 && tap == 4) epi_mt(1, pacc, prv, porow);
+      }
+      if (s > 0) issued += 2;
+      C3R_STAMP(3 + 3 * s);
+      read_res(s, prv);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) pacc[mt][nt] = acc[mt][nt];
+      C3R_STAMP(4 + 3 * s);
+    }
+    epi_mt(0, pacc, prv, y0 + 2 * (nsteps - 1) + rrw);
+    epi_mt(1, pacc, prv, y0 + 2 * (nsteps - 1) + rrw);
   }
   // (the dummy pairs / residual rows still in flight target LDS only; the wave ends when its counter drains)
 }
@@ -624,14 +671,14 @@ static int c3r_rows_per_segment(int B, int H, int W) {
   while (rs > 16 && (H % rs != 0 || strips * (H / rs) < 512)) rs >>= 1;
   return (H % rs == 0) ? rs : 0;
 }
-template <int NRES, int D, int DR>
+template <int NRES, int D, int DR, bool PIPE = false>
 static int go_c3r(const void* x, const void* wp /* M2T_PACK_CONV3_ROWS(_T) */, const float* bias, const void* res1, const void* res2, void* y, const void* zero_page,
                   int B, int H, int W, int rs, hipStream_t st) {
   constexpr int NR = 2 * D + 4;
   const size_t sh = (size_t)NR * C3R_ROWB + (size_t)NRES * (DR + 1) * C3R_RESB + 64 * sizeof(float);
-  if (int rc__ = m2t_ensure_dynamic_lds((const void*)conv3x3_c64_rows_kernel<NRES, D, DR>, (int)sh)) return rc__;
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)conv3x3_c64_rows_kernel<NRES, D, DR, PIPE>, (int)sh)) return rc__;
   const int nblk = B * (W / C3R_SW) * (H / rs);
-  M2T_LAUNCH_TIMED((conv3x3_c64_rows_kernel<NRES, D, DR>), dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
+  M2T_LAUNCH_TIMED((conv3x3_c64_rows_kernel<NRES, D, DR, PIPE>), dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
                    (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, (const bf16_t*)zero_page, B, H, W, rs);
   return 0;
 }
@@ -646,9 +693,22 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
     if (rs > 0) {
       int rc;
       // LDS per workgroup (two per CU): ring 46 080 B + residual slots: <= 79 104 B
-      if (res2) rc = go_c3r<2, 3, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
-      else if (res1) rc = go_c3r<1, 3, 3>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
-      else rc = go_c3r<0, 3, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+      // DMA depth 2 (ring of 8 rows = 36 KB + residual slots; LDS per workgroup <= 61 KB): same-box, stand-alone, batch 16:
+      // 27.8 us against 29.4 for depth 3 and 28.8 for depth 3 with the epilogue of step s - 1 issued between the products of
+      // step s (variants 3 / 4, kept for A/B); inside the two-stream step all of them tie
+      if (variant == 3) {
+        if (res2) rc = go_c3r<2, 3, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+        else if (res1) rc = go_c3r<1, 3, 3>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+        else rc = go_c3r<0, 3, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+      } else if (variant == 4) {
+        if (res2) rc = go_c3r<2, 2, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+        else if (res1) rc = go_c3r<1, 2, 2, true>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+        else rc = go_c3r<0, 2, 1, true>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+      } else {
+        if (res2) rc = go_c3r<2, 2, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+        else if (res1) rc = go_c3r<1, 2, 2>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+        else rc = go_c3r<0, 2, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+      }
       if (rc) return rc;
       M2T_LAUNCH_CHECK();
       return 0;

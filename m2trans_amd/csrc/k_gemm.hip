@@ -11,6 +11,7 @@
 // Tile product orientation: the weight rows are the MFMA "A" operand and the activation
 // rows the "B" operand, so each lane ends up with 16 CONSECUTIVE output channels of one
 // pixel -> 32/64-byte vector stores along the contiguous NHWC axis.
+#include <cstdlib>
 #include "m2t_kernels.h"
 #include "m2t_gemm_load.h"
 
@@ -108,7 +109,7 @@ gemm_nt_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, T* __r
       const int rr = sg.r * sg.r;
       float dv[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) gelu_erf_both(v[e] + bias[(c0 + e) * rr + sub], v[e], dv[e]);   // activation + derivative
+      for (int e = 0; e < 16; ++e) gelu_tail_both<T>(v[e] + bias[(c0 + e) * rr + sub], v[e], dv[e]);   // activation + derivative
       const int w = (int)(m % sg.W);
       const long long q = m / sg.W;
       const int h = (int)(q % sg.H);
@@ -378,7 +379,7 @@ tail_expand_kernel(const T* __restrict__ X, const T* __restrict__ Wp, const floa
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) gelu_erf_both(acc[mt][nt][q4] + bv[4 * nt + q4], v[4 * nt + q4], dv[4 * nt + q4]);
+          for (int q4 = 0; q4 < 4; ++q4) gelu_tail_both<T>(acc[mt][nt][q4] + bv[4 * nt + q4], v[4 * nt + q4], dv[4 * nt + q4]);
         const long long pix = pixbase[mt] + (long long)i * Wd * r + j;
         store16f(Y + pix * 64 + 16 * g, v);
         store16f(Yd + pix * 64 + 16 * g, dv);
@@ -706,6 +707,9 @@ static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_
   }
   const long long want64 = std::max<long long>(1, 512 / (tn * tk));
   int nslab = (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want64, ceil_divll(a.M, WG_BM)));
+  // whole slabs per XCD: the tn x tk tiles of a slab share its rows of G and X through ONE L2 (xcd_block_index gives every XCD a
+  // contiguous eighth of the grid); 10 slabs of 48 tiles straddled the XCD runs and re-fetched 1.5x the operand bytes from HBM
+  if (nslab > 8) nslab = nslab / 8 * 8;
   long long rps = ceil_divll(ceil_divll(a.M, nslab), WG_BM) * WG_BM;
   nslab = (int)ceil_divll(a.M, rps);
   if (sizeof(T) == 2 && a.gmode == M2T_A_PLAIN && a.xmode == M2T_A_PLAIN && !a.bias_slabs && a.ldg > 0 && a.ldx > 0 &&

@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
         for (int mt = 0; mt < 4; ++mt) {
           float av[4], dv[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gelu_erf_both(acc[mt][r] + bv[r], av[r], dv[r]);
+          for (int r = 0; r < 4; ++r) gelu_tail_both<T>(acc[mt][r] + bv[r], av[r], dv[r]);
           const int row = hr_row(16 * mt + lr, sub);
           store4(&A2[row][16 * ct + 4 * g], av);
           store4(&Gz[row][16 * ct + 4 * g], dv);

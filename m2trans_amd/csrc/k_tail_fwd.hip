@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(512) tail_fwd_fused_kernel(const bf16_t* __res
         if (m < TF_NM) {
           float av[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) av[r] = gelu_erf(acc[mt][r] + bv[r]);
+          for (int r = 0; r < 4; ++r) av[r] = gelu_tail<T>(acc[mt][r] + bv[r]);
           const int row = (2 * (m / TF_MB) + (sub >> 1)) * TF_BE + 2 * (m % TF_MB) + (sub & 1);
           store4(&A2b[row][16 * ct + 4 * g], av);
         }

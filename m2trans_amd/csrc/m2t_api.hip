@@ -135,12 +135,14 @@ struct m2t_plan {
   bool use_side = true;
   bool debug_skip_side = false;        // timing experiments only: skip every parameter-gradient kernel (results are WRONG)
   bool use_fused_tail_bwd = true;      // x4 bf16: k_tail_bwd.hip instead of four HR kernels
-  bool use_fused_tail_fwd = false;     // x4 bf16: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored
+  bool use_fused_tail_fwd = true;      // x4 bf16: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored
+                                       // (with bf16 mode's exp2 / rcp GELU: 5.30 vs 5.34 ms per step and 1.6 GB less HBM traffic;
+                                       // with the erf form of round 2 it was 1 % slower)
   int gate_branch = 1;                 // side-stream gate: -1 ungated, else the branch (3..0) behind whose attention launch a block's
                                        // parameter-gradient work is released.  Same-box A/B (config 1): 1 = 5.49 ms, 2 = 5.60, 3 = 5.62,
                                        // 0 = 5.68, ungated 5.64
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)         } option "attn_bwd":
-  bool use_conv_rows = true;           // bf16 conv3x3 64 -> 64: row-streaming LDS-DMA kernel (k_conv.hip) instead of the tile kernel
+  int use_conv_rows = 1;               // bf16 conv3x3 64 -> 64: row-streaming LDS-DMA kernel (k_conv.hip); 0 = the tile kernel; 3 / 4: A/B variants
   int wgrad_big_tiles = -1;            // C = 256 qkv weight gradient: 128 x 128 output tiles (k_gemm.hip); value = target workgroups,
                                        // 0 = off, -1 = auto: 256 from 24 576 rows on (batch 32: 9.82 vs 9.93 ms; batch 16: 5.53 vs 5.49)
   bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside that kernel                } 0 / 1 / 2
@@ -374,7 +376,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "fused_tail_bwd") return p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
     if (o == "fused_tail_fwd") return p->use_fused_tail_fwd && p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
     if (o == "attn_bwd") return p->dt == M2T_F32 ? 0 : (p->use_resident_attn_bwd ? (p->use_fused_qkv_dgrad ? 2 : 1) : 0);
-    if (o == "conv_rows") return p->use_conv_rows && p->dt != M2T_F32;
+    if (o == "conv_rows") return p->dt != M2T_F32 ? p->use_conv_rows : 0;
     if (o == "fused_attn_fwd") return p->use_fused_attn_fwd && p->dt != M2T_F32;
     if (o == "fused_c16_fwd") return p->use_fused_c16_fwd && p->dt != M2T_F32;
     if (o == "fused_qkv_dgrad") return p->use_fused_qkv_dgrad && p->use_resident_attn_bwd && p->dt != M2T_F32;
@@ -466,7 +468,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     { M2TProfScope ps(M2T_PROF_CONV3_FWD, st);
       CK(launch_conv3x3_c64(dt, xc, packed_ptr(p, workspace, k + "wf"), params + p->poff.at(pre + "feed_forward.0.bias"), X,
                             (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st,
-                            packed_ptr(p, workspace, k + "wfR"), WSP("zero_page"), p->use_conv_rows ? 0 : 1)); }
+                            packed_ptr(p, workspace, k + "wfR"), WSP("zero_page"), p->use_conv_rows >= 2 ? p->use_conv_rows : (p->use_conv_rows ? 0 : 1))); }
   }
   void* Y = WSP("X" + std::to_string(p->nb));
   const int r0 = (s == 4) ? 2 : s;
@@ -750,7 +752,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       conv_done = side_marker();
     }
     { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st,
-                                                                        packed_ptr(p, workspace, k + "wfTR"), WSP("zero_page"), p->use_conv_rows ? 0 : 1)); }
+                                                                        packed_ptr(p, workspace, k + "wfTR"), WSP("zero_page"), p->use_conv_rows >= 2 ? p->use_conv_rows : (p->use_conv_rows ? 0 : 1))); }
     for (int i = 3; i >= 0; --i) {
       const int C = BR_C[i], L = BR_L[i];
       const int h = H >> L, w = W >> L;
@@ -873,7 +875,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
     if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "attn_bwd: 0..2");
     p->use_resident_attn_bwd = value >= 1; p->use_fused_qkv_dgrad = value == 2; return 0;
   }
-  if (k == "conv_rows") { p->use_conv_rows = (value != 0); return 0; }
+  if (k == "conv_rows") { p->use_conv_rows = (int)value; return 0; }
   if (k == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
   if (k == "fused_c16_fwd") { p->use_fused_c16_fwd = (value != 0); return 0; }
   if (k == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }

@@ -173,6 +173,40 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + e) + x * (0.39894228040143267794f * ex);
 }
 
+// bf16 mode's GELU: the results are stored with 8 significant bits, so the erf behind GELU -- what the high-resolution tail
+// kernels are bound by -- is replaced by one exp2 and one rcp:
+//     Phi(t) ~ sigma(t (a + b t^2 + c t^4)),   gelu(t) = t Phi(t),   gelu'(t) = s + t s (1 - s) (a + 3 b t^2 + 5 c t^4)
+// with (a, b, c) fitted (minimax over |t| <= 9, tools/fit_gelu.py) so that |gelu - exact| <= 3.8e-5 and |gelu' - exact| <=
+// 9.3e-5: 1 % and 2.4 % of a bf16 ulp at 1.0.  c < 0, so the polynomial is evaluated at t clamped to [-8, 8] (sigma is 0 / 1
+// to 1e-12 there).  fp32 parity mode keeps the erf form above.
+#define M2T_GELU_A 1.59484566f
+#define M2T_GELU_B 7.40076173e-2f
+#define M2T_GELU_C -6.95025211e-4f
+__device__ __forceinline__ void gelu_fast_both(float x, float& act, float& der) {
+  const float tc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  const float t2 = tc * tc;
+  const float u = fmaf(fmaf(M2T_GELU_C, t2, M2T_GELU_B), t2, M2T_GELU_A);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * (tc * u));      // exp(-z), z = t u(t^2)
+  const float s = __builtin_amdgcn_rcpf(1.0f + e);                               // sigma(z)
+  act = x * s;
+  const float du = fmaf(fmaf(5.0f * M2T_GELU_C, t2, 3.0f * M2T_GELU_B), t2, M2T_GELU_A);
+  der = fmaf(act * (e * s), du, s);                                              // 1 - s = e s
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float tc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  const float t2 = tc * tc;
+  const float u = fmaf(fmaf(M2T_GELU_C, t2, M2T_GELU_B), t2, M2T_GELU_A);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * (tc * u));
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
+}
+// the tail's activation by storage type: exact (erf) for fp32 parity mode, the approximation for bf16 storage
+template <typename T> __device__ __forceinline__ void gelu_tail_both(float x, float& act, float& der) {
+  if constexpr (sizeof(T) == 2) gelu_fast_both(x, act, der); else gelu_erf_both(x, act, der);
+}
+template <typename T> __device__ __forceinline__ float gelu_tail(float x) {
+  if constexpr (sizeof(T) == 2) return gelu_fast(x); else return gelu_erf(x);
+}
+
 __device__ __forceinline__ int reflect_idx(int i, int n) {   // torch 'reflect' (no edge repeat)
   if (i < 0) i = -i;
   if (i >= n) i = 2 * n - 2 - i;

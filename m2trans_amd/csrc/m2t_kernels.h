@@ -134,7 +134,8 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
                        void* y, int B, int H, int W, hipStream_t st,
                        const void* wrows = nullptr,       // bf16: the same weight in M2T_PACK_CONV3_ROWS(_T) order and ...
                        const void* zero_page = nullptr,   // ... >= 64 zero bytes in device memory -> the row-streaming kernel
-                       int variant = 0);                  // 1: force the tile kernel (conv3x3_c64_pipe_kernel) for A/B tests
+                       int variant = 0);                  // 0: row-streaming, DMA depth 2 (default); 1: the tile kernel
+                                                          // (conv3x3_c64_pipe_kernel); 3: depth 3; 4: depth 2 + pipelined epilogue
 int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, float* bias_slabs, int* nslab, int B, int H,
                              int W, hipStream_t st);   // bias_slabs [nslab][64]: column sums of gy
 // tail conv 64->3, reflect padding, input = the stored activation gelu(t); output NCHW fp32 [B][3][H][W]

@@ -184,13 +184,34 @@ def _rw(w: Tensor, e: "_Emu | None") -> Tensor:
     return _RoundFwd.apply(w) if e is not None else w
 
 
+GELU_FAST = (1.59484566, 7.40076173e-2, -6.95025211e-4)     # csrc/m2t_common.h M2T_GELU_A / _B / _C
+
+
+def gelu_fast_both(t: Tensor):
+    """bf16 mode's GELU and GELU' (csrc/m2t_common.h gelu_fast_both): Phi(t) ~ sigma(t (a + b t^2 + c t^4)), polynomial at
+    t clamped to [-8, 8].  NOT reference arithmetic (the reference uses the exact erf GELU, models/M2Trans_network.py:44,47)."""
+    a, b, c = GELU_FAST
+    tc = t.clamp(-8.0, 8.0)
+    t2 = tc * tc
+    u = (c * t2 + b) * t2 + a
+    ex = torch.exp2(-1.4426950408889634 * (tc * u))
+    s = 1.0 / (1.0 + ex)
+    act = t * s
+    du = (5.0 * c * t2 + 3.0 * b) * t2 + a
+    return act, act * (ex * s) * du + s
+
+
 def _gelu_stored(t: Tensor, e: "_Emu | None", act_name: str, der_name: str):
     """tail expansion of the HIP path: stores gelu(t) and gelu'(t) in bf16; its backward multiplies by the STORED
     derivative (csrc/k_gemm.hip tail_expand_kernel, k_tail_bwd.hip).  Returns (activation, stored derivative)."""
     if e is None:
         return F.gelu(t), gelu_derivative(t)
-    der = _r(gelu_derivative(t).detach(), e, der_name)
-    act_v = _r(F.gelu(t).detach(), e, act_name)
+    # bf16 mode evaluates GELU / GELU' by the sigmoid-quintic approximation of csrc/m2t_common.h (gelu_fast_both: |error| <=
+    # 3.8e-5 / 9.3e-5 against the exact erf form, tests/test_host_cpu.py) -- the same formula here, so that the teacher-forced
+    # stage gates measure the kernels and not the approximation
+    fa, fd = gelu_fast_both(t.detach())
+    der = _r(fd, e, der_name)
+    act_v = _r(fa, e, act_name)
     # value = the stored activation, d(value)/dt = the stored derivative
     act = act_v + (t - t.detach()) * der
     return act, der

@@ -394,3 +394,15 @@ def test_bench_plain_multi_gpu_launch_builds_the_torchrun_child():
     env.update(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_bf16_gelu_approximation_error_bound():
+    """bf16 mode evaluates the tail's GELU / GELU' by a sigmoid-quintic approximation (csrc/m2t_common.h, restated in the
+    oracle's bf16-emulation mode): against the exact erf form of the reference (models/M2Trans_network.py:44,47) the error stays
+    below 4e-5 / 1e-4 -- 1 % / 2.5 % of a bf16 ulp at 1.0 -- over the whole line, including beyond the clamp at |t| = 8."""
+    t = torch.cat([torch.linspace(-20, 20, 400001, dtype=torch.float64), torch.tensor([-1e4, -30.0, 30.0, 1e4], dtype=torch.float64)])
+    act, der = O.gelu_fast_both(t)
+    assert float((act - torch.nn.functional.gelu(t)).abs().max()) < 4e-5
+    assert float((der - O.gelu_derivative(t)).abs().max()) < 1e-4
+    a32, d32 = O.gelu_fast_both(t.float())
+    assert float((a32.double() - act).abs().max() / 1e4) < 1e-6 and float((d32.double() - der).abs().max()) < 1e-5
