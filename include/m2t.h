@@ -74,7 +74,10 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           registers (k_conv.hip); 0 = the 8 x 16 tile kernel it replaced (3 / 4: DMA-depth / epilogue variants kept for
  *                           A/B).  All bit-identical
  *   "fused_attn_fwd"    [1] bf16, C = 64 / 256: qkv projection + window attention + IWT / residual in one kernel per window
- *   "fused_c16_fwd"     [1] bf16, C = 16: InstanceNorm apply + qkv projection + window attention + residual, one wave per window
+ *   "fused_c16_fwd"     [2] bf16, C = 16: 1 = InstanceNorm apply + qkv projection + window attention + residual in one kernel, one wave per
+ *                           window; 2 = the same and q | k | v of that branch are NOT stored: the backward kernel recomputes them from
+ *                           the branch input (identical bits; needs "attn_bwd" >= 1; m2t_plan_query("stores_qkv1") tells whether
+ *                           ws:b*.qkv1 is written); 0 = three kernels
  *   "debug_skip_side"   [0] timing experiments only: skips every parameter-gradient kernel (results are WRONG) */
 int m2t_set_option(m2t_plan* p, const char* key, long long value);
 /* Gradient buckets for communication overlap (replaces the reduce-to-GPU-0 of nn.DataParallel, train.py:73):

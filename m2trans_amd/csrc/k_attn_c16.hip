@@ -65,7 +65,13 @@ __device__ __forceinline__ void wave_sync() {
 __global__ void __launch_bounds__(256, 2) window_attn_bwd_c16_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                                   const float* __restrict__ rel_w, const bf16_t* __restrict__ go,
                                                                   int ldg, int gc0, bf16_t* __restrict__ gqkv, bf16_t* __restrict__ win,
-                                                                  float* __restrict__ relw, int h, int w, int nwin) {
+                                                                  float* __restrict__ relw, int h, int w, int nwin,
+                                                                  const bf16_t* __restrict__ dsrc, const bf16_t* __restrict__ wqkv) {
+  // dsrc != nullptr: q | k | v were NOT saved by the forward pass; they are recomputed here from the branch input d
+  // [pixel][16] (saved anyway: the weight-gradient GEMM reads it) and the packed weight wqkv [48][16], with the forward kernel's
+  // own MFMAs (window_attn_fused_c16_fwd_kernel: out^T = W x^T, one v_mfma_f32_16x16x16_bf16 per tile, rounded to bf16 as
+  // it was when stored) -- identical bits, 11 instead of 18 eight-byte loads per lane, and 25 MB less written by the forward
+  // and read here per launch at batch 16
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wi = xcd_block_index() * 4 + wv;
@@ -81,6 +87,24 @@ __global__ void __launch_bounds__(256, 2) window_attn_bwd_c16_kernel(const bf16_
   {
     bf16x4 kraw[WA_KT];
     f32x4 rel[WA_KT];
+    bf16x4 xk[WA_KT], xq[4];
+    if (dsrc) {                                   // wave-uniform: branch-free clamped loads of the d rows (keys, then queries)
+#pragma unroll
+      for (int t = 0; t < WA_KT; ++t) {
+        const int key = min(16 * t + lr, WA_NK - 1);
+        const int kr = key / 10, kc = key - kr * 10;
+        const int y = 8 * wy + kr - 1, x = 8 * wx + kc - 1;
+        const bool in = (16 * t + lr < WA_NK) && y >= 0 && y < h && x >= 0 && x < w;
+        const int yc = min(max(y, 0), h - 1), xc = min(max(x, 0), w - 1);
+        const bf16x4 v = ld4(dsrc + (img + (long long)yc * w + xc) * C16 + 4 * g);
+        xk[t] = in ? v : zero4();
+      }
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        const int q = 16 * qt + lr;
+        xq[qt] = ld4(dsrc + (img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7)) * C16 + 4 * g);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < WA_KT; ++t) {
       const int key = 16 * t + lr;
@@ -90,7 +114,7 @@ __global__ void __launch_bounds__(256, 2) window_attn_bwd_c16_kernel(const bf16_
       vA[t] = zero4();
       rel[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (key < WA_NK) {
-        if (y >= 0 && y < h && x >= 0 && x < w) {
+        if (!dsrc && y >= 0 && y < h && x >= 0 && x < w) {
           const bf16_t* pk = qkv + (img + (long long)y * w + x) * (3 * C16) + 4 * g;
           kraw[t] = ld4(pk + C16);
           vA[t] = ld4(pk + 2 * C16);
@@ -99,11 +123,31 @@ __global__ void __launch_bounds__(256, 2) window_attn_bwd_c16_kernel(const bf16_
         rel[t] = *reinterpret_cast<const f32x4*>(rp);
       }
     }
+    bf16x4 wA[3];                                 // rows 16 n + lr of [q | k | v], input channels 4g ..
+    if (dsrc) {
+#pragma unroll
+      for (int n = 0; n < 3; ++n) wA[n] = ld4(wqkv + (16 * n + lr) * C16 + 4 * g);
+#pragma unroll
+      for (int t = 0; t < WA_KT; ++t) {           // out-of-image and padding keys: x = 0 -> k = v = 0, as F.unfold pads
+        f32x4 ak = (f32x4){0.f, 0.f, 0.f, 0.f}, av = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma4(ak, wA[1], xk[t]);
+        mma4(av, wA[2], xk[t]);
+        kraw[t] = pack4(ak[0], ak[1], ak[2], ak[3]);
+        vA[t] = pack4(av[0], av[1], av[2], av[3]);
+      }
+    }
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       const int q = 16 * qt + lr;
       const long long qpix = img + (long long)(8 * wy + (q >> 3)) * w + 8 * wx + (q & 7);
-      const bf16x4 qv = ld4(qkv + qpix * (3 * C16) + 4 * g);
+      bf16x4 qv;
+      if (dsrc) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma4(a, wA[0], xq[qt]);
+        qv = pack4(a[0], a[1], a[2], a[3]);
+      } else {
+        qv = ld4(qkv + qpix * (3 * C16) + 4 * g);
+      }
       st4(&L.Qs[q][4 * g], pack4(0.25f * (float)qv[0], 0.25f * (float)qv[1], 0.25f * (float)qv[2], 0.25f * (float)qv[3]));   // exact
       st4(&L.DOs[q][4 * g], ld4(go + qpix * ldg + gc0 + 4 * g));
     }
@@ -427,7 +471,7 @@ __global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const
     f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
     mma4(a, wA[0], xn);
     const bf16x4 qr = pack4(a[0], a[1], a[2], a[3]);
-    st4(qkv + qpix * (3 * C16) + 4 * g, qr);
+    if (qkv) st4(qkv + qpix * (3 * C16) + 4 * g, qr);         // (qkv == nullptr: the backward kernel recomputes q | k | v from d)
     st4(&Qs[q][4 * g], qr);
   }
   bf16x4 kA[WA_KT];
@@ -440,7 +484,7 @@ __global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const
     const bf16x4 kraw = pack4(ak[0], ak[1], ak[2], ak[3]), vraw = pack4(av[0], av[1], av[2], av[3]);
     const int key = 16 * t + lr;
     const int kr = key / 10, kc = key - kr * 10;
-    if (key < WA_NK && kr >= 1 && kr <= 8 && kc >= 1 && kc <= 8) {          // the window's own pixels: saved for the backward pass
+    if (qkv && key < WA_NK && kr >= 1 && kr <= 8 && kc >= 1 && kc <= 8) {   // the window's own pixels: saved for the backward pass
       bf16_t* pk = qkv + (img + (long long)(8 * wy + kr - 1) * w + 8 * wx + kc - 1) * (3 * C16) + 4 * g;
       st4(pk + C16, kraw);
       st4(pk + 2 * C16, vraw);
@@ -507,12 +551,13 @@ __global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const
 }  // namespace
 
 int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
-                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st) {
+                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st, const void* d, const void* wqkv) {
+  if (!qkv && !(d && wqkv)) return m2t_set_error(-2, "window_attn_bwd_c16: needs the saved qkv, or d and the packed weight to recompute it");
   const int nwin = B * (h / 8) * (w / 8);
   const size_t sh = 4 * sizeof(C16WaveLds);
   if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_bwd_c16_kernel, (int)sh)) return rc__;
   M2T_LAUNCH_TIMED(window_attn_bwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), sh, st, (const bf16_t*)qkv, rel_h, rel_w,
-                     (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, h, w, nwin);
+                     (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, h, w, nwin, (const bf16_t*)d, (const bf16_t*)wqkv);
   M2T_LAUNCH_CHECK();
   return 0;
 }

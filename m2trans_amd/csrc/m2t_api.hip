@@ -146,7 +146,9 @@ struct m2t_plan {
   int wgrad_big_tiles = -1;            // C = 256 qkv weight gradient: 128 x 128 output tiles (k_gemm.hip); value = target workgroups,
                                        // 0 = off, -1 = auto: 256 from 24 576 rows on (batch 32: 9.82 vs 9.93 ms; batch 16: 5.53 vs 5.49)
   bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside that kernel                } 0 / 1 / 2
-  bool use_fused_c16_fwd = true;       // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip)
+  int use_fused_c16_fwd = 2;           // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip);
+                                       // 2: ... and qkv1 is not stored: the wave-per-window backward recomputes it from d1 (needs attn_bwd >= 1)
+  bool c16_recompute() const { return dt != M2T_F32 && use_fused_c16_fwd == 2 && use_resident_attn_bwd; }
   bool use_fused_attn_fwd = true;      // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip)
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
   // region; the descriptor table is identical every step, so it is uploaded once
@@ -378,11 +380,12 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "attn_bwd") return p->dt == M2T_F32 ? 0 : (p->use_resident_attn_bwd ? (p->use_fused_qkv_dgrad ? 2 : 1) : 0);
     if (o == "conv_rows") return p->dt != M2T_F32 ? p->use_conv_rows : 0;
     if (o == "fused_attn_fwd") return p->use_fused_attn_fwd && p->dt != M2T_F32;
-    if (o == "fused_c16_fwd") return p->use_fused_c16_fwd && p->dt != M2T_F32;
+    if (o == "fused_c16_fwd") return p->dt != M2T_F32 ? (p->use_fused_c16_fwd == 2 && !p->use_resident_attn_bwd ? 1 : p->use_fused_c16_fwd) : 0;
     if (o == "fused_qkv_dgrad") return p->use_fused_qkv_dgrad && p->use_resident_attn_bwd && p->dt != M2T_F32;
     if (o == "debug_skip_side") return p->debug_skip_side;
     return -1;
   }
+  if (k == "stores_qkv1") return (p->use_fused_c16_fwd != 0 && p->c16_recompute()) ? 0 : 1;
   if (k == "stores_t2") return (p->scale == 4 && !(p->dt != M2T_F32 && p->use_fused_tail_fwd && p->use_fused_tail_bwd)) ? 1 : 0;
   return -1;
 }
@@ -439,9 +442,9 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
       const float* rw = params + p->poff.at(an + "rel_w");
       {
         void* xc_i = (char*)xc + (size_t)i * BP * 16 * p->esz;       // chunk i of the P64 concat buffer: a dense plane
-        if (dt != M2T_F32 && p->use_fused_c16_fwd && i == 0) {
+        if (dt != M2T_F32 && p->use_fused_c16_fwd != 0 && i == 0) {
           // x1 = attn1(norm(x)[chunk 0]) + norm(x)[chunk 0] (:135-139): one launch, d1 and qkv1 written for the backward
-          CK(launch_window_attn_fused_c16_fwd(X, mean, rstd, packed_ptr(p, workspace, k + "w1"), rh, rw, d, qkv, xc_i, 16, 0, B, h, w, st));
+          CK(launch_window_attn_fused_c16_fwd(X, mean, rstd, packed_ptr(p, workspace, k + "w1"), rh, rw, d, p->c16_recompute() ? nullptr : qkv, xc_i, 16, 0, B, h, w, st));
           continue;
         }
         CK(launch_branch_prep(dt, L, X, mean, rstd, xc, i, WSP("xin"), d, B, H, W, st));
@@ -775,6 +778,11 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256, st);
         CK(launch_window_attn_bwd_resident(qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, L, st,
                                            packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "TF"), WSP("gd"), WSP("gdwin")));
+      } else if (C == 16 && p->c16_recompute()) {
+        // qkv1 was not stored: recomputed inside the kernel from d1 (identical bits); then the halo overlap-add as usual
+        { M2TProfScope ps(M2T_PROF_ATTN_BWD_16, st);
+          CK(launch_window_attn_bwd_c16(nullptr, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, st, WSP(k + "d1"), packed_ptr(p, workspace, k + "w1"))); }
+        CK(launch_halo_gather(dt, win, gqkv, B, h, w, 2 * C, 3 * C, C, st));
       } else {
         CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, st, L, true, p->use_resident_attn_bwd));
       }
@@ -877,7 +885,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   }
   if (k == "conv_rows") { p->use_conv_rows = (int)value; return 0; }
   if (k == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
-  if (k == "fused_c16_fwd") { p->use_fused_c16_fwd = (value != 0); return 0; }
+  if (k == "fused_c16_fwd") { if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_c16_fwd: 0..2"); p->use_fused_c16_fwd = (int)value; p->have_acts = false; return 0; }
   if (k == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
   return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");
 }

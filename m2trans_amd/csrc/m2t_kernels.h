@@ -182,8 +182,11 @@ int launch_window_attn_bwd(int dt, const void* qkv, const float* rel_h, const fl
 // C = 16, bf16, no fused DWT: one wave per window (k_attn_c16.hip)
 int launch_window_attn_fwd_c16(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0, const void* res,
                                int ldr, int B, int h, int w, hipStream_t st);
+// d != nullptr (with wqkv = the packed [48][16] weight, M2T_PACK_COPY): qkv was not saved (may be nullptr); q | k | v are
+// recomputed from the branch input d [pixel][16] with the forward kernel's own products (identical bits)
 int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
-                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st);
+                               void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st, const void* d = nullptr,
+                               const void* wqkv = nullptr);
 int launch_window_attn_fwd_resident(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0,
                                     const void* res, int ldr, int B, int h, int w, int C, int post_levels, hipStream_t st);
 // the resident kernel alone (bf16); M2T_UNSUPPORTED when (C, dwt_levels) has no instantiation
@@ -196,6 +199,7 @@ int launch_window_attn_bwd_resident(const void* qkv, const float* rel_h, const f
 int launch_halo_gather(int dt, const void* win, void* dst, int B, int h, int w, int rw, int ld, int coff, hipStream_t st);
 // k_attn_c16.hip: the whole C = 16 branch forward (InstanceNorm apply of chunk 0 + qkv projection + attention + residual), bf16.
 // x = chunk-0 plane of the block input; wqkv [48][16] (M2T_PACK_COPY); d [B*h*w][16] and qkv [B*h*w][48] are WRITTEN
+// (qkv == nullptr: not saved -- launch_window_attn_bwd_c16 then recomputes it from d)
 int launch_window_attn_fused_c16_fwd(const void* x, const float* mean, const float* rstd, const void* wqkv, const float* rel_h,
                                      const float* rel_w, void* d, void* qkv, void* out, int ldo, int oc0, int B, int h, int w,
                                      hipStream_t st);

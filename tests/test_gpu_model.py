@@ -421,6 +421,7 @@ def test_fused_qkv_attention_forward_matches_the_two_kernel_path():
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_attn_fwd", fused), "m2t_set_option")
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_c16_fwd", 1), "m2t_set_option")       # keep qkv1 stored: compared below
         with torch.no_grad():
             sr = model(x)
         torch.cuda.synchronize()
@@ -469,6 +470,27 @@ def test_fused_c16_branch_forward_matches_the_three_kernel_path():
     assert rms_rel(a["sr"], b["sr"]) < 5e-2
 
 
+def test_c16_backward_recomputes_qkv_with_identical_bits():
+    """bf16, C = 16 branch: with fused_c16_fwd = 2 (default) the forward does not store q | k | v of that branch and the
+    wave-per-window backward recomputes them from the branch input d1 with the forward kernel's own MFMAs: the whole step must
+    agree BIT FOR BIT with the stored-qkv path (fused_c16_fwd = 1).  Reflect-padded input, border / edge / interior windows."""
+    from m2trans_amd import _lib
+    from tests.test_gpu_baseline_configs import fwd_bwd
+    scale, nb, B, H0, W0 = 4, 2, 2, 60, 90
+    x = O.closed_form_image(B, 3, H0, W0).cuda()
+    hr = O.closed_form_image(B, 3, H0 * scale, W0 * scale, phase=0.7).cuda()
+    outs = []
+    for mode in (2, 1):
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(x)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_c16_fwd", mode), "m2t_set_option")
+        assert plan.query("opt:fused_c16_fwd") == mode and plan.query("stores_qkv1") == (0 if mode == 2 else 1)
+        sr, loss, grads = fwd_bwd(model, x, hr, hr.numel())
+        outs.append((sr.cpu(), grads.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 def test_fused_projection_data_gradient_matches_the_gemm_path():
     """bf16, C = 64 / 256 branches: the data gradient of the qkv projection taken inside the attention backward kernel
     (option fused_qkv_dgrad, default; the window multiplies its own dq | dK | dV contributions by Wqkv^T and the
@@ -512,7 +534,7 @@ def test_row_streaming_conv3x3_is_bit_identical_to_the_tile_kernel():
         x = O.closed_form_image(B, 3, H, W).cuda()
         hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
         outs = []
-        for rows in (1, 0):
+        for rows in (1, 0, 3, 4):          # default (DMA depth 2), tile kernel, depth 3, depth 2 + pipelined epilogue
             model, _ = build_model(scale, nb, "bf16")
             plan = model._plan_for(x)
             _lib.check(_lib.load().m2t_set_option(plan.handle, b"conv_rows", rows), "m2t_set_option")
@@ -520,8 +542,9 @@ def test_row_streaming_conv3x3_is_bit_identical_to_the_tile_kernel():
             sr = model(x)
             torch.nn.L1Loss()(sr, hr).backward()
             outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone()))
-        assert torch.equal(outs[0][0], outs[1][0]), (B, H, W)
-        assert torch.equal(outs[0][1], outs[1][1]), (B, H, W)
+        for o in outs[1:]:
+            assert torch.equal(outs[0][0], o[0]), (B, H, W)
+            assert torch.equal(outs[0][1], o[1]), (B, H, W)
 
 
 def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():
