@@ -73,7 +73,9 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "conv_rows"         [1] bf16 conv3x3 64 -> 64 (forward and data gradient): row-streaming kernel fed by LDS-DMA with the weights in
  *                           registers (k_conv.hip); 0 = the 8 x 16 tile kernel it replaced (3 / 4: DMA-depth / epilogue variants kept for
  *                           A/B).  All bit-identical
- *   "fused_attn_fwd"    [1] bf16, C = 64 / 256: qkv projection + window attention + IWT / residual in one kernel per window
+ *   "fused_attn_fwd"    [2] bf16, C = 64 / 256: 1 = qkv projection + window attention + IWT / residual in one kernel per window; 2 = the
+ *                           same and q | k | v of the C = 64 branch are NOT stored: the resident backward recomputes them from the
+ *                           branch input (identical bits; needs "attn_bwd" = 2; m2t_plan_query("stores_qkv2")); 0 = GEMM + attention
  *   "fused_c16_fwd"     [2] bf16, C = 16: 1 = InstanceNorm apply + qkv projection + window attention + residual in one kernel, one wave per
  *                           window; 2 = the same and q | k | v of that branch are NOT stored: the backward kernel recomputes them from
  *                           the branch input (identical bits; needs "attn_bwd" >= 1; m2t_plan_query("stores_qkv1") tells whether

@@ -266,14 +266,14 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
       for (int m = 0; m < TPW; ++m) {
         const int ch = 16 * (wv * TPW + m) + 4 * g;
         const bf16x4 kb = pack4(ak[t][m]);
-        if (key < 64) *reinterpret_cast<bf16x4*>(qkv + qp * (3 * C) + C + ch) = kb;
+        if (qkv && key < 64) *reinterpret_cast<bf16x4*>(qkv + qp * (3 * C) + C + ch) = kb;     // (qkv == nullptr: the backward recomputes q | k | v)
         const f32x4 r4 = *reinterpret_cast<const f32x4*>(&RelS[(ch < C / 2) ? kr : kc][ch]);
         float kh[4] = {(float)kb[0] + r4[0], (float)kb[1] + r4[1], (float)kb[2] + r4[2], (float)kb[3] + r4[3]};
         store4(&Kh[key][ch], kh);
         if (t < 4) {
           const bf16x4 qb = pack4(aq[t][m]);
           *reinterpret_cast<bf16x4*>(&Qs[key][ch]) = qb;
-          *reinterpret_cast<bf16x4*>(qkv + qp * (3 * C) + ch) = qb;
+          if (qkv) *reinterpret_cast<bf16x4*>(qkv + qp * (3 * C) + ch) = qb;
         }
       }
     }
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
         const int ch = 16 * (wv * TPW + m) + 4 * g;
         const bf16x4 vb = pack4(av[t][m]);
         *reinterpret_cast<bf16x4*>(&Xs[key][ch]) = vb;        // row 100 of Xs stays the zero row
-        if (key < 64) *reinterpret_cast<bf16x4*>(qkv + qp * (3 * C) + 2 * C + ch) = vb;
+        if (qkv && key < 64) *reinterpret_cast<bf16x4*>(qkv + qp * (3 * C) + 2 * C + ch) = vb;
       }
     }
   }

@@ -113,13 +113,19 @@ __device__ __forceinline__ void stage_go_all(bf16_t (*dst)[C + 8], const bf16_t*
 // gdwin [window][36][C].  The weight arrives as pre-packed MFMA A-fragments of Wqkv^T (M2T_PACK_FRAG16_T) straight from
 // L2 through a register ring, the B operand is a plain row read of the dq / dK^ / dV rows (dq rows gathered in key order;
 // ring keys read a zero row).  gqkv / win are still written: the weight-gradient GEMM (side stream) reads them.
-template <int C, int L, int NW, bool DG>
+// RC: q | k | v were NOT saved by the forward pass (window_attn_fused_fwd_kernel with qkv == nullptr); they are recomputed
+// here from the branch input x [pixel][C] (kept anyway: the weight-gradient GEMM reads it) with the forward kernel's own
+// products -- the same pre-packed A-fragments (M2T_PACK_FRAG16), k-step-outer, rounded to bf16 where the forward stored them --
+// so every value is bit-identical to the saved one.  The x rows of the 100 keys are staged where V will live, q waits in the
+// P region; the window then loads 12.8 KB (C = 64) instead of 33.6 KB and the forward writes 25 MB less per launch.
+template <int C, int L, int NW, bool DG, bool RC = false>
 __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                                       const float* __restrict__ rel_w, const bf16_t* __restrict__ go,
                                                                       int ldg, int gc0, bf16_t* __restrict__ gqkv,
                                                                       bf16_t* __restrict__ win, float* __restrict__ relw, int h, int w,
                                                                       const bf16_t* __restrict__ wdfrag, bf16_t* __restrict__ gd,
-                                                                      bf16_t* __restrict__ gdwin) {
+                                                                      bf16_t* __restrict__ gdwin, const bf16_t* __restrict__ xsrc,
+                                                                      const bf16_t* __restrict__ wfrag) {
   using T = bf16_t;
   using Cfg = ResCfg<C>;
   constexpr int LD = Cfg::LD, PLD = Cfg::PLD, DLD = Cfg::DLD, NTHR = NW * 64, VEC = C / 8, NT = C / 16, KH = NW / 4, TPW = NT / NW, NKC = C / 32;
@@ -144,6 +150,129 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
   const int q = 16 * qt + lr;
   const long long qpix = gm.query_pixel(q);
 
+  Frag8<T> qreg[NKC];
+  if constexpr (RC) {
+    // ---- phase 0 (recompute): x rows of the 100 keys, the rel-pos table, dO; then k | v | q by MFMA ----
+    static_assert(!RC || (sizeof(T) * 64 * LD <= Cfg::szP && sizeof(float) * 10 * C <= Cfg::szD && !Cfg::P_IN_V), "q / rel-pos staging regions");
+    T(*Xs)[LD] = Vs;                                                             // x rows (natural key order); row 100 stays zero
+    T(*Qt)[LD] = reinterpret_cast<T(*)[LD]>(smem + Cfg::offP);                   // q of the 64 queries until phase 1 has read it
+    float(*RelS)[C] = reinterpret_cast<float(*)[C]>(smem + Cfg::offD);           // T[kk][ch] = ch < C/2 ? rel_h[kk][ch] : rel_w[kk][ch - C/2]
+    constexpr int NKS = C / 32;
+    const bf16x8* wf8 = reinterpret_cast<const bf16x8*>(wfrag);
+    constexpr int XIT = (101 * VEC + NTHR - 1) / NTHR, RIT = (10 * C / 4 + NTHR - 1) / NTHR;
+    {
+      Frag8<T> xf[XIT];
+      bool ok[XIT];
+      f32x4 rf[RIT];
+#pragma unroll
+      for (int it = 0; it < XIT; ++it) {
+        const int idx = tid + it * NTHR;
+        const int key = min(idx / VEC, 100), cv = idx % VEC;
+        const int kk = min(key, 99), kr = kk / 10, kc = kk - kr * 10;
+        const int yy = 8 * gm.wy + kr - 1, xx = 8 * gm.wx + kc - 1;
+        ok[it] = (key < 100) && yy >= 0 && yy < h && xx >= 0 && xx < w;
+        const int yc = min(max(yy, 0), h - 1), xc = min(max(xx, 0), w - 1);
+        xf[it] = load8(xsrc + (((long long)gm.b * h + yc) * w + xc) * C + cv * 8);       // branch-free: clamped address, select below
+      }
+#pragma unroll
+      for (int it = 0; it < RIT; ++it) {
+        const int idx = min(tid + it * NTHR, 10 * C / 4 - 1);
+        const int kk = idx / (C / 4), c4 = (idx % (C / 4)) * 4;
+        const float* rp = (c4 < C / 2) ? (rel_h + kk * (C / 2) + c4) : (rel_w + kk * (C / 2) + (c4 - C / 2));
+        rf[it] = *reinterpret_cast<const f32x4*>(rp);
+      }
+      stage_go_all<C, L, NTHR>(DOs, go, ldg, gc0, gm, tid);
+#pragma unroll
+      for (int it = 0; it < XIT; ++it) {
+        const int idx = tid + it * NTHR;
+        if (idx < 101 * VEC) store8(&Xs[min(idx / VEC, 100)][(idx % VEC) * 8], ok[it] ? xf[it] : frag_zero<T>());
+      }
+#pragma unroll
+      for (int it = 0; it < RIT; ++it) {
+        const int idx = min(tid + it * NTHR, 10 * C / 4 - 1);
+        *reinterpret_cast<f32x4*>(&RelS[idx / (C / 4)][(idx % (C / 4)) * 4]) = rf[it];
+      }
+      if (tid < VEC) store8(&Kh[ZR][tid * 8], frag_zero<T>());
+    }
+    // this wave's weight fragments: projection p (q, k, v), channel tiles wv * TPW + m, every k-step
+    Frag8<T> wq[NKS][TPW], wk[NKS][TPW], wvv[NKS][TPW];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) {
+        wq[ks][m].v = wf8[((size_t)((0 * NT + wv * TPW + m) * NKS + ks)) * 64 + lane];
+        wk[ks][m].v = wf8[((size_t)((1 * NT + wv * TPW + m) * NKS + ks)) * 64 + lane];
+        wvv[ks][m].v = wf8[((size_t)((2 * NT + wv * TPW + m) * NKS + ks)) * 64 + lane];
+      }
+    __syncthreads();
+    f32x4 ak[WA_KT][TPW], av[WA_KT][TPW], aq[4][TPW];
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t)
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) { ak[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f}; av[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) aq[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int t = 0; t < WA_KT; ++t) {
+        const Frag8<T> bx = load8(&Xs[min(16 * t + lr, ZR)][32 * ks + 8 * g]);
+#pragma unroll
+        for (int m = 0; m < TPW; ++m) {
+          mma16(ak[t][m], wk[ks][m], bx);
+          mma16(av[t][m], wvv[ks][m], bx);
+        }
+      }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int qq = 16 * t + lr;                                                 // query qq = key ((qq >> 3) + 1, (qq & 7) + 1)
+        const Frag8<T> bx = load8(&Xs[((qq >> 3) + 1) * 10 + (qq & 7) + 1][32 * ks + 8 * g]);
+#pragma unroll
+        for (int m = 0; m < TPW; ++m) mma16(aq[t][m], wq[ks][m], bx);
+      }
+    // K^ = bf16(bf16(k) + rel) -> Kh, q -> Qt: the rounding points of the forward kernel's stores
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const int key = 16 * t + lr;
+      if (key < WA_NK) {
+        const int kr = key / 10, kc = key - kr * 10;
+#pragma unroll
+        for (int m = 0; m < TPW; ++m) {
+          const int ch = 16 * (wv * TPW + m) + 4 * g;
+          const bf16x4 kb = {(bf16_t)ak[t][m][0], (bf16_t)ak[t][m][1], (bf16_t)ak[t][m][2], (bf16_t)ak[t][m][3]};
+          const f32x4 r4 = *reinterpret_cast<const f32x4*>(&RelS[(ch < C / 2) ? kr : kc][ch]);
+          float kh4[4] = {(float)kb[0] + r4[0], (float)kb[1] + r4[1], (float)kb[2] + r4[2], (float)kb[3] + r4[3]};
+          store4(&Kh[key][ch], kh4);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int m = 0; m < TPW; ++m) {
+        float q4[4] = {aq[t][m][0], aq[t][m][1], aq[t][m][2], aq[t][m][3]};
+        store4(&Qt[16 * t + lr][16 * (wv * TPW + m) + 4 * g], q4);
+      }
+    __syncthreads();                      // every wave is done reading the x rows; K^ and q are complete
+#pragma unroll
+    for (int t = 0; t < WA_KT; ++t) {
+      const int key = 16 * t + lr;
+      if (key < WA_NK) {
+#pragma unroll
+        for (int m = 0; m < TPW; ++m) {
+          float v4[4] = {av[t][m][0], av[t][m][1], av[t][m][2], av[t][m][3]};
+          store4(&Vs[key][16 * (wv * TPW + m) + 4 * g], v4);                        // row 100 stays the zero row
+        }
+      }
+    }
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) qreg[kc] = load8(&Qt[q][kc * 32 + 8 * g]);
+    __syncthreads();
+  } else {
   // ---- phase 0: every global load of the window, then LDS ----
   constexpr int KIT = (WA_NK * VEC + NTHR - 1) / NTHR;
   {
@@ -188,11 +317,11 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
       store8(&Vs[ZR][tid * 8], frag_zero<T>());
     }
   }
-  Frag8<T> qreg[NKC];
 #pragma unroll
   for (int kc = 0; kc < NKC; ++kc) qreg[kc] = load8(qkv + qpix * (3 * C) + kc * 32 + 8 * g);
   __syncthreads();
 
+  }
   // ---- phase 1: S^T = K^ Q^T and dP^T = V dO^T for (query tile qt, key tiles t0 .. t0 + NTL - 1) ----
   const int t0 = kh * 4;
   f32x4 s[NTL], dp[NTL];
@@ -651,14 +780,14 @@ int go_fwd_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, bf16_t
   return 0;
 }
 
-template <int C, int L, int NW, bool DG = false>
+template <int C, int L, int NW, bool DG = false, bool RC = false>
 int go_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, const bf16_t* gout, int ldg, int gc0, bf16_t* gqkv,
            bf16_t* win, float* relw, int nwin, int h, int w, hipStream_t st, const bf16_t* wdfrag = nullptr, bf16_t* gd = nullptr,
-           bf16_t* gdwin = nullptr) {
+           bf16_t* gdwin = nullptr, const bf16_t* xsrc = nullptr, const bf16_t* wfrag = nullptr) {
   const size_t sh = ResCfg<C>::total;
-  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_bwd_res_kernel<C, L, NW, DG>, (int)sh)) return rc__;
-  M2T_LAUNCH_TIMED((window_attn_bwd_res_kernel<C, L, NW, DG>), dim3(nwin), dim3(NW * 64), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0,
-                     gqkv, win, relw, h, w, wdfrag, gd, gdwin);
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_bwd_res_kernel<C, L, NW, DG, RC>, (int)sh)) return rc__;
+  M2T_LAUNCH_TIMED((window_attn_bwd_res_kernel<C, L, NW, DG, RC>), dim3(nwin), dim3(NW * 64), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0,
+                     gqkv, win, relw, h, w, wdfrag, gd, gdwin, xsrc, wfrag);
   return 0;
 }
 
@@ -667,7 +796,7 @@ int go_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, const bf16
 // bf16, C in {64, 256}, dwt_levels in {0, L(C)}; returns M2T_UNSUPPORTED otherwise (the caller then uses the chunked kernel)
 int launch_window_attn_bwd_resident(const void* qkv_, const float* rel_h, const float* rel_w, const void* gout_, int ldg, int gc0,
                                     void* gqkv_, void* win_, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st,
-                                    const void* wdfrag, void* gd, void* gdwin) {
+                                    const void* wdfrag, void* gd, void* gdwin, const void* xsrc, const void* wfrag) {
   const bf16_t* qkv = (const bf16_t*)qkv_;
   const bf16_t* gout = (const bf16_t*)gout_;
   bf16_t* gqkv = (bf16_t*)gqkv_;
@@ -678,6 +807,9 @@ int launch_window_attn_bwd_resident(const void* qkv_, const float* rel_h, const 
     if (!gd || !gdwin) return m2t_set_error(-2, "window_attn_bwd_resident: fused data gradient needs gd and gdwin");
     if (C == 256 && dwt_levels == 2)
       rc = go_res<256, 2, 8, true>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st, (const bf16_t*)wdfrag, (bf16_t*)gd, (bf16_t*)gdwin);
+    else if (C == 64 && dwt_levels == 1 && xsrc && wfrag)     // q | k | v not saved: recomputed from the branch input
+      rc = go_res<64, 1, 4, true, true>(nullptr, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st, (const bf16_t*)wdfrag, (bf16_t*)gd,
+                                        (bf16_t*)gdwin, (const bf16_t*)xsrc, (const bf16_t*)wfrag);
     else if (C == 64 && dwt_levels == 1)
       rc = go_res<64, 1, 4, true>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st, (const bf16_t*)wdfrag, (bf16_t*)gd, (bf16_t*)gdwin);
     if (rc != 0) return rc;

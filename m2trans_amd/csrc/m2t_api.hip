@@ -149,7 +149,9 @@ struct m2t_plan {
   int use_fused_c16_fwd = 2;           // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip);
                                        // 2: ... and qkv1 is not stored: the wave-per-window backward recomputes it from d1 (needs attn_bwd >= 1)
   bool c16_recompute() const { return dt != M2T_F32 && use_fused_c16_fwd == 2 && use_resident_attn_bwd; }
-  bool use_fused_attn_fwd = true;      // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip)
+  int use_fused_attn_fwd = 2;          // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip);
+                                       // 2: ... and qkv2 (C = 64) is not stored: the resident backward recomputes it from d2 (needs attn_bwd = 2)
+  bool c64_recompute() const { return dt != M2T_F32 && use_fused_attn_fwd == 2 && use_resident_attn_bwd && use_fused_qkv_dgrad; }
   // deferred, batched parameter-gradient reductions (m2t_backward): slabs live in the "arena" workspace
   // region; the descriptor table is identical every step, so it is uploaded once
   std::vector<m2t_red_desc> red_descs;
@@ -379,12 +381,13 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "fused_tail_fwd") return p->use_fused_tail_fwd && p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
     if (o == "attn_bwd") return p->dt == M2T_F32 ? 0 : (p->use_resident_attn_bwd ? (p->use_fused_qkv_dgrad ? 2 : 1) : 0);
     if (o == "conv_rows") return p->dt != M2T_F32 ? p->use_conv_rows : 0;
-    if (o == "fused_attn_fwd") return p->use_fused_attn_fwd && p->dt != M2T_F32;
+    if (o == "fused_attn_fwd") return p->dt != M2T_F32 ? (p->use_fused_attn_fwd == 2 && !p->c64_recompute() ? 1 : p->use_fused_attn_fwd) : 0;
     if (o == "fused_c16_fwd") return p->dt != M2T_F32 ? (p->use_fused_c16_fwd == 2 && !p->use_resident_attn_bwd ? 1 : p->use_fused_c16_fwd) : 0;
     if (o == "fused_qkv_dgrad") return p->use_fused_qkv_dgrad && p->use_resident_attn_bwd && p->dt != M2T_F32;
     if (o == "debug_skip_side") return p->debug_skip_side;
     return -1;
   }
+  if (k == "stores_qkv2") return p->c64_recompute() ? 0 : 1;
   if (k == "stores_qkv1") return (p->use_fused_c16_fwd != 0 && p->c16_recompute()) ? 0 : 1;
   if (k == "stores_t2") return (p->scale == 4 && !(p->dt != M2T_F32 && p->use_fused_tail_fwd && p->use_fused_tail_bwd)) ? 1 : 0;
   return -1;
@@ -448,9 +451,11 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
           continue;
         }
         CK(launch_branch_prep(dt, L, X, mean, rstd, xc, i, WSP("xin"), d, B, H, W, st));
-        if (dt != M2T_F32 && p->use_fused_attn_fwd && C >= 64) {
-          // qkv projection + window attention + IWT^L / residual in one kernel; qkv is still written (the backward reads it)
-          CK(launch_window_attn_fused_fwd(d, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "F"), rh, rw, qkv, xc_i, 16, 0,
+        if (dt != M2T_F32 && p->use_fused_attn_fwd != 0 && C >= 64) {
+          // qkv projection + window attention + IWT^L / residual in one kernel; qkv is written for the backward pass unless that
+          // recomputes it (C = 64)
+          CK(launch_window_attn_fused_fwd(d, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "F"), rh, rw,
+                                          (C == 64 && p->c64_recompute()) ? nullptr : qkv, xc_i, 16, 0,
                                           WSP("xin"), 16, B, h, w, C, L, st));
           continue;
         }
@@ -776,8 +781,11 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       const void* gxc_i = (const char*)gxc + (size_t)i * BP * 16 * p->esz;       // chunk i of the P64 gradient: a dense plane
       if (fused_dgrad(i)) {
         M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256, st);
+        const bool rc64 = C == 64 && p->c64_recompute();
         CK(launch_window_attn_bwd_resident(qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, L, st,
-                                           packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "TF"), WSP("gd"), WSP("gdwin")));
+                                           packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "TF"), WSP("gd"), WSP("gdwin"),
+                                           rc64 ? WSP(k + "d" + std::to_string(i + 1)) : nullptr,
+                                           rc64 ? packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "F") : nullptr));
       } else if (C == 16 && p->c16_recompute()) {
         // qkv1 was not stored: recomputed inside the kernel from d1 (identical bits); then the halo overlap-add as usual
         { M2TProfScope ps(M2T_PROF_ATTN_BWD_16, st);
@@ -884,7 +892,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
     p->use_resident_attn_bwd = value >= 1; p->use_fused_qkv_dgrad = value == 2; return 0;
   }
   if (k == "conv_rows") { p->use_conv_rows = (int)value; return 0; }
-  if (k == "fused_attn_fwd") { p->use_fused_attn_fwd = (value != 0); return 0; }
+  if (k == "fused_attn_fwd") { if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_attn_fwd: 0..2"); p->use_fused_attn_fwd = (int)value; p->have_acts = false; return 0; }
   if (k == "fused_c16_fwd") { if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_c16_fwd: 0..2"); p->use_fused_c16_fwd = (int)value; p->have_acts = false; return 0; }
   if (k == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }
   return m2t_set_error(M2T_ERR_ARG, "m2t_set_option: unknown key");

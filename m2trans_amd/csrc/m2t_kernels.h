@@ -195,7 +195,10 @@ int launch_window_attn_fwd_resident(const void* qkv, const float* rel_h, const f
 // rows -> gdwin [window][36][C] (added to the border pixels by launch_halo_gather(gdwin, gd, .., C, C, 0))
 int launch_window_attn_bwd_resident(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
                                     void* gqkv, void* win, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st,
-                                    const void* wdfrag, void* gd, void* gdwin);
+                                    const void* wdfrag, void* gd, void* gdwin,
+                                    // (C, dwt_levels) = (64, 1) with the fused data gradient: xsrc [pixel][C] = the branch input and wfrag = Wqkv as
+                                    // M2T_PACK_FRAG16: qkv was not saved (may be nullptr), q | k | v are recomputed (identical bits)
+                                    const void* xsrc = nullptr, const void* wfrag = nullptr);
 int launch_halo_gather(int dt, const void* win, void* dst, int B, int h, int w, int rw, int ld, int coff, hipStream_t st);
 // k_attn_c16.hip: the whole C = 16 branch forward (InstanceNorm apply of chunk 0 + qkv projection + attention + residual), bf16.
 // x = chunk-0 plane of the block input; wqkv [48][16] (M2T_PACK_COPY); d [B*h*w][16] and qkv [B*h*w][48] are WRITTEN

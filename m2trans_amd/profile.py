@@ -74,7 +74,7 @@ def read_all():
 
 def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8, fused_attn_fwd: bool | None = None,
                      fused_tail_fwd: bool = False, fused_qkv_dgrad: bool | None = None, fused_c16_fwd: bool | None = None,
-                     c16_recompute: bool | None = None):
+                     c16_recompute: bool | None = None, c64_recompute: bool | None = None):
     """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr.
     fused_attn_fwd (default: bf16 mode): the C = 64 / 256 branches run qkv projection + attention as one kernel, so
     the forward `gemm_qkv` / `attn_fwd_*` categories are then empty (the C = 16 branch runs InstanceNorm apply +
@@ -87,6 +87,8 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         fused_qkv_dgrad = dtype == "bf16"
     if c16_recompute is None:             # plan option "fused_c16_fwd" = 2 (default in bf16 mode): qkv1 is not stored, the backward recomputes it
         c16_recompute = dtype == "bf16"
+    if c64_recompute is None:             # plan option "fused_attn_fwd" = 2 (default in bf16 mode): qkv2 is not stored
+        c64_recompute = dtype == "bf16"
     es = 2 if dtype == "bf16" else 4
     H = W = (lr + 31) // 32 * 32
     P = H * W
@@ -104,14 +106,14 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         dg = fused_qkv_dgrad and C_ >= 64
         # reads q|k|v (3C) and the output gradient (C), writes dq|dK|dV (3C); with the projection data gradient inside the
         # kernel also g_d (C) and 2 M 3C C more FLOPs
-        rc = c16_recompute and C_ == 16 and fused_c16_fwd
-        # C = 16 with recompute: reads d (C) and the output gradient (C), writes dq|dK|dV (3C), + the projection's FLOPs again
-        add(f"attn_bwd_c{C_}", nb * (win * 64000.0 * C_ + (2.0 * M * C_ * 3 * C_ if (dg or rc) else 0.0)),
-            nb * M * (5 if rc else (8 if dg else 7)) * C_ * es, nb)
+        rc = (c16_recompute and C_ == 16 and fused_c16_fwd) or (c64_recompute and C_ == 64 and fused_attn_fwd and dg)
+        # with recompute: reads d (C) instead of q|k|v (3C), + the projection's FLOPs again
+        add(f"attn_bwd_c{C_}", nb * (win * 64000.0 * C_ + (2.0 * M * C_ * 3 * C_ if dg else 0.0) + (2.0 * M * C_ * 3 * C_ if rc else 0.0)),
+            nb * M * ((8 if dg else 7) - (2 if rc else 0)) * C_ * es, nb)
         if (fused_c16_fwd if C_ == 16 else fused_attn_fwd):
             # reads x (+ the residual rows for C >= 64; for C = 16 the residual IS x), writes qkv + out (+ d1 for C = 16;
             # with recompute the C = 16 kernel writes d1 and out only)
-            add(f"attn_fused_c{C_}", nb * (win * 25600.0 * C_ + 2.0 * M * C_ * 3 * C_), nb * M * (3 if rc else 6) * C_ * es, nb)
+            add(f"attn_fused_c{C_}", nb * (win * 25600.0 * C_ + 2.0 * M * C_ * 3 * C_), nb * M * (3 if rc else 6) * C_ * es, nb)   # (C = 64 with recompute: x, residual in, out written = 3 C too)
         else:
             add(f"attn_fwd_c{C_}", nb * win * 25600.0 * C_, nb * M * (4 * C_ + (C_ if C_ == 16 else 0)) * es, nb)
             add("gemm_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
@@ -158,6 +160,7 @@ def plan_options(plan) -> dict:
     rows of `algorithmic_work` apply."""
     o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_tail_fwd", "fused_c16_fwd", "conv_rows")}
     o["c16_recompute"] = plan.query("opt:fused_c16_fwd") == 2
+    o["c64_recompute"] = plan.query("opt:fused_attn_fwd") == 2
     o["fused_qkv_dgrad"] = plan.query("opt:attn_bwd") == 2
     return o
 
@@ -172,7 +175,7 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
     opts = plan_options(plan) if plan is not None else {}
     work = algorithmic_work(B, lr, scale, dtype, fused_attn_fwd=opts.get("fused_attn_fwd"), fused_tail_fwd=bool(opts.get("fused_tail_fwd", False)),
                             fused_qkv_dgrad=opts.get("fused_qkv_dgrad"), fused_c16_fwd=opts.get("fused_c16_fwd"),
-                            c16_recompute=opts.get("c16_recompute"))
+                            c16_recompute=opts.get("c16_recompute"), c64_recompute=opts.get("c64_recompute"))
     traffic = {}
     if pmc_file and os.path.exists(pmc_file):
         try:

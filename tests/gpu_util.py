@@ -65,7 +65,7 @@ def hip_forward_trace(plan, scale, n_blocks, B, H, W):
         for i in range(4):
             h, w = H >> BR_L[i], W >> BR_L[i]
             t[f"b{b}.d{i+1}"] = ws_nchw(plan, f"b{b}.d{i+1}", B, h, w, BR_C[i])
-            if i > 0 or plan.query("stores_qkv1") == 1:        # (bf16 default: q | k | v of the C = 16 branch are recomputed by the backward)
+            if i > 1 or plan.query(f"stores_qkv{i+1}") == 1:   # (bf16 default: q | k | v of the C = 16 / 64 branches are recomputed by the backward)
                 t[f"b{b}.qkv{i+1}"] = ws_nchw(plan, f"b{b}.qkv{i+1}", B, h, w, 3 * BR_C[i])
         t[f"b{b}.xc"] = ws_nchw(plan, f"b{b}.xc", B, H, W, 64)
         t[f"X{b+1}"] = ws_nchw(plan, f"X{b+1}", B, H, W, 64)

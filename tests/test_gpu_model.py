@@ -420,8 +420,8 @@ def test_fused_qkv_attention_forward_matches_the_two_kernel_path():
     for fused in (1, 0):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
-        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_attn_fwd", fused), "m2t_set_option")
-        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_c16_fwd", 1), "m2t_set_option")       # keep qkv1 stored: compared below
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_attn_fwd", fused), "m2t_set_option")          # (1: qkv stored, compared below)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_c16_fwd", 1), "m2t_set_option")
         with torch.no_grad():
             sr = model(x)
         torch.cuda.synchronize()
@@ -470,10 +470,12 @@ def test_fused_c16_branch_forward_matches_the_three_kernel_path():
     assert rms_rel(a["sr"], b["sr"]) < 5e-2
 
 
-def test_c16_backward_recomputes_qkv_with_identical_bits():
-    """bf16, C = 16 branch: with fused_c16_fwd = 2 (default) the forward does not store q | k | v of that branch and the
-    wave-per-window backward recomputes them from the branch input d1 with the forward kernel's own MFMAs: the whole step must
-    agree BIT FOR BIT with the stored-qkv path (fused_c16_fwd = 1).  Reflect-padded input, border / edge / interior windows."""
+@pytest.mark.parametrize("key,branch", [(b"fused_c16_fwd", 1), (b"fused_attn_fwd", 2)])
+def test_backward_recomputes_qkv_with_identical_bits(key, branch):
+    """bf16, C = 16 and C = 64 branches: with fused_c16_fwd = 2 / fused_attn_fwd = 2 (defaults) the forward does not store
+    q | k | v of that branch and the backward kernel recomputes them from the branch input d with the forward kernel's own MFMAs
+    (same fragments, k order and rounding points): the whole step must agree BIT FOR BIT with the stored-qkv path (option = 1).
+    Reflect-padded input, border / edge / interior windows."""
     from m2trans_amd import _lib
     from tests.test_gpu_baseline_configs import fwd_bwd
     scale, nb, B, H0, W0 = 4, 2, 2, 60, 90
@@ -483,8 +485,8 @@ def test_c16_backward_recomputes_qkv_with_identical_bits():
     for mode in (2, 1):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
-        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_c16_fwd", mode), "m2t_set_option")
-        assert plan.query("opt:fused_c16_fwd") == mode and plan.query("stores_qkv1") == (0 if mode == 2 else 1)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, key, mode), "m2t_set_option")
+        assert plan.query("opt:" + key.decode()) == mode and plan.query(f"stores_qkv{branch}") == (0 if mode == 2 else 1)
         sr, loss, grads = fwd_bwd(model, x, hr, hr.numel())
         outs.append((sr.cpu(), grads.cpu()))
     assert torch.equal(outs[0][0], outs[1][0])

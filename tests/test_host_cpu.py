@@ -358,11 +358,17 @@ def test_roofline_work_table_matches_the_profiler_categories():
     and the dominant-kernel arithmetic of DESIGN.md holds (attention backward at C = 256 with the fused data gradient:
     10.6 GFLOP and 67 MB per launch at batch 16)."""
     from m2trans_amd import profile as P
-    w = P.algorithmic_work(16, 128, 4, "bf16")
-    assert set(w) <= set(P.CATS), set(w) - set(P.CATS)
+    wd = P.algorithmic_work(16, 128, 4, "bf16")                     # defaults: the C = 16 / 64 backward recompute q | k | v
+    w = P.algorithmic_work(16, 128, 4, "bf16", c16_recompute=False, c64_recompute=False)
+    assert set(w) <= set(P.CATS) and set(wd) <= set(P.CATS), set(w) - set(P.CATS)
+    M16, M64 = 16 * 128 * 128, 16 * 64 * 64
+    for cat, M, C in (("attn_bwd_c16", M16, 16), ("attn_bwd_c64", M64, 64)):
+        assert abs((wd[cat][0] - w[cat][0]) - 8 * 2.0 * M * C * 3 * C) < 1.0          # the projection once more per launch ...
+        assert abs((w[cat][1] - wd[cat][1]) - 8 * M * 2 * C * 2) < 1.0                # ... for 2 C fewer bf16 values read per pixel
+    assert wd["attn_bwd_c256"] == w["attn_bwd_c256"]
     fl, by, n = w["attn_bwd_c256"]
     assert n == 16 and abs(fl / n - 10.64e9) < 0.05e9 and abs(by / n - 67.1e6) < 0.2e6
-    w0 = P.algorithmic_work(16, 128, 4, "bf16", fused_attn_fwd=False, fused_qkv_dgrad=False)
+    w0 = P.algorithmic_work(16, 128, 4, "bf16", fused_attn_fwd=False, fused_qkv_dgrad=False, c16_recompute=False, c64_recompute=False)
     tot = lambda t, keys: sum(t[k][0] for k in keys if k in t)
     fwd_keys = ["attn_fwd_c16", "attn_fwd_c64", "attn_fwd_c256", "attn_fused_c16", "attn_fused_c64", "attn_fused_c256", "gemm_qkv"]
     bwd_keys = ["attn_bwd_c16", "attn_bwd_c64", "attn_bwd_c256", "gemm_qkv_dgrad"]
