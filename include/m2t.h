@@ -59,8 +59,8 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  * force (gate_branch / wgrad_big_tiles are reported + 1000).  Variants that were measured and lost live under scratch/ with
  * their numbers in profiles/README.md, not behind options.
  *   "side_stream"       [1] parameter-gradient kernels of m2t_backward on a plan-owned second stream
- *   "gate_branch"       [1] -1: side work released as soon as its inputs exist; 0..3: a block's side work waits for the
- *                           attention launch of that branch (1 = behind the two LDS-filling C = 256 launches and the C = 64 one)
+ *   "gate_branch"       [2] -1: side work released as soon as its inputs exist; 0..3: a block's side work waits for the
+ *                           attention launch of that branch (2 = behind the two LDS-filling C = 256 launches)
  *   "wgrad_big_tiles"   [-1] qkv weight gradient of the C = 256 branches with 128 x 128 output tiles: value = target number of
  *                           workgroups (64..512), 0 = off, -1 = auto (256 from 24 576 branch pixels on, i.e. batch >= 24)
  *   "fused_tail_bwd"    [1] bf16 x4: one fused kernel for the high-resolution half of the tail backward (k_tail_bwd.hip)
@@ -73,6 +73,9 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "conv_rows"         [1] bf16 conv3x3 64 -> 64 (forward and data gradient): row-streaming kernel fed by LDS-DMA with the weights in
  *                           registers (k_conv.hip); 0 = the 8 x 16 tile kernel it replaced (3 / 4: DMA-depth / epilogue variants kept for
  *                           A/B).  All bit-identical
+ *   "fused_conv_bwd"    [1] bf16 conv3x3 64 -> 64 backward: data gradient and weight / bias gradient in ONE row-streaming pass over the
+ *                           output gradient on the main stream (k_conv.hip; data gradient bit-identical, weight gradient the same
+ *                           products summed in a different order); 0 = data gradient kernel + weight-gradient kernel on the side stream
  *   "fused_attn_fwd"    [2] bf16, C = 64 / 256: 1 = qkv projection + window attention + IWT / residual in one kernel per window; 2 = the
  *                           same and q | k | v of the C = 64 branch are NOT stored: the resident backward recomputes them from the
  *                           branch input (identical bits; needs "attn_bwd" = 2; m2t_plan_query("stores_qkv2")); 0 = GEMM + attention

@@ -659,6 +659,300 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* 
   // (the dummy pairs / residual rows still in flight target LDS only; the wave ends when its counter drains)
 }
 
+// ---------------------------------------------------------------------------------------
+// Fused BACKWARD of the 64 -> 64 3x3 conv (bf16, round 3): data gradient AND weight / bias gradient in ONE pass over the
+// output gradient (the autograd of models/M2Trans_network.py:124-126,164).  Separately the two kernels read gy twice,
+// run on two streams and fight for registers and bandwidth (stand-alone 24.7 + 31.3 us, ~80 us of kernel time where they
+// meet inside the step); together they are 38.7 GFLOP on ~140 MB: on the matrix-core side of the ridge.
+//   * same row streaming as conv3x3_c64_rows_kernel: a workgroup owns a 32-pixel-wide strip segment and walks down it FOUR
+//     rows per step; gy and x rows (1-pixel halo, zero page outside the image) arrive by LDS-DMA in two rings, quads of
+//     rows D steps ahead;
+//   * eight waves, two roles, one of each per SIMD (waves w and w + 4 share a SIMD):
+//       waves 0-3  data gradient: wave (half, row pair) = conv3x3_c64_rows_kernel's wave with the flipped / transposed
+//                  weights in registers (M2T_PACK_CONV3_ROWS_T) -- the same products in the same order, identical bits;
+//       waves 4-7  weight gradient: wave v owns input-channel tile v for all nine taps and all four output-channel tiles
+//                  (36 accumulator tiles); per row of the step: four gy^T fragments and nine shifted x fragments, both by
+//                  transposing LDS reads (ds_read_b64_tr_b16) of the linear P64 row image (a pixel's 16 channels of a plane
+//                  are 32 contiguous bytes: exactly the 4 x 16 block the instruction transposes), k-slot (g, j) <-> pixel
+//                  4 g + (j & 3) + 16 (j >> 2) so that the two lane halves of a read hit disjoint banks; the bias gradient
+//                  is one more MFMA per row against a ones operand;
+//   * the weight-gradient accumulators stay in registers over ALL segments a workgroup processes and leave as one fp32
+//     slab [9][64][64] (+ [64]) per workgroup, reduced afterwards in a fixed order (no atomics).
+// ---------------------------------------------------------------------------------------
+#define C3B_ROWS 4                       // output rows per step
+#ifndef C3B_STAMP
+#define C3B_STAMP(i) do { } while (0)   // scratch/bench_conv_bwd.hip -DSTAMPS: s_memtime per phase (waves 0 and 4, lane 0)
+#define C3B_STEP_WAIT(n) c3r_wait_vm(n)
+#endif
+__device__ __forceinline__ Frag8<bf16_t> c3b_tr(const unsigned char* p) {
+  // p = this lane's address (see c3b_tr_lane): elements 0..3 = pixels +0..3, 4..7 = pixels +16..19 of the fragment's first pixel,
+  // channel (lane & 15) of the plane
+  typedef bf16x4 __attribute__((address_space(3))) * lds_ptr;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)p);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_ptr)(p + 16 * 32));
+  Frag8<bf16_t> f;
+  f.v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return f;
+}
+__device__ __forceinline__ int c3b_tr_lane(int lane) {        // lane's byte offset inside the 4-pixel x 16-channel block it helps transpose
+  const int i = lane & 15;
+  return (i >> 2) * 32 + (i & 3) * 8;
+}
+
+template <int D>
+__global__ void __launch_bounds__(512) conv3x3_c64_bwd_rows_kernel(const bf16_t* __restrict__ gy, const bf16_t* __restrict__ x,
+                                                                   const bf16_t* __restrict__ wp, bf16_t* __restrict__ gx,
+                                                                   float* __restrict__ slabs, float* __restrict__ bias_slabs,
+                                                                   const bf16_t* __restrict__ zero_page, int B, int H, int W, int RS) {
+  using T = bf16_t;
+  constexpr int NR = C3B_ROWS * (D + 2);              // ring rows per tensor: quads s, s + 1 in use, D more in flight
+  static_assert((NR & (NR - 1)) == 0, "ring row indices wrap with a mask");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* gring = smem;
+  unsigned char* xring = smem + NR * C3R_ROWB;
+  const unsigned gring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)gring;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  const int nseg = H / RS, nsx = W / C3R_SW;
+  const int nsegs = B * nsx * nseg;
+  const long long npix = (long long)B * H * W;
+  const int nsteps = RS / C3B_ROWS;
+  const int nquads = nsteps + 1;                      // quad k = input rows y0 + 4 k - 1 .. y0 + 4 k + 2
+
+  // DMA: the four data-gradient waves issue all 36 pieces of a quad pair (piece i = tensor i / 18, 1-KiB piece i % 18 of its 4-row
+  // image [row][plane][36 pixels][32 B]; wave w issues i = w + 4 j, j = 0 .. 8): an LDS-DMA instruction holds its wave's issue for
+  // 100+ cycles, which the weight-gradient wave of the same SIMD fills with products.  A piece's 64 chunks of 16 bytes cross at most
+  // one plane-row boundary (72 chunks per plane-row), so a chunk's (row, plane) is one of two wave-uniform pairs, chosen per lane by
+  // one bit: everything but two bits per piece (that choice, and "my pixel is inside the image row") stays in scalar registers.
+  constexpr int NP = 9;                               // pieces per data-gradient wave and quad pair
+  unsigned lanebits = 0;                              // bit 2 j: second (row, plane) pair; bit 2 j + 1: column valid (per segment)
+  const int lane16 = lane * 16;
+  int x0 = 0, y0 = 0;
+  long long sbase = 0;                                // element offset of (image, row y0 - 1, column x0 - 1)
+  C3B_STAMP(0);
+  auto issue_piece = [&](int k, int j) {              // k >= nquads: zero-page pieces into ring slots nobody reads (keeps the cadence)
+    const int slot = ((C3B_ROWS * k) & (NR - 1)) * C3R_ROWB;
+    const int i = wv + 4 * j;
+    const bool second = i >= 18;                      // which tensor
+    const int ii = second ? i - 18 : i;
+    const int c0 = 64 * ii, q0 = c0 / 72, rem0 = c0 - 72 * q0;
+    // wave-uniform: byte offset from the tensor base and row validity of the two candidate (row, plane) pairs
+    unsigned boff[2]; bool rok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = q0 + h, rr = q >> 2, pl = q & 3;
+      const int row = y0 + C3B_ROWS * k - 1 + rr;
+      rok[h] = k < nquads && (unsigned)row < (unsigned)H && row <= y0 + RS;      // rows beyond the bottom halo row are never read
+      boff[h] = (unsigned)((sbase + (long long)pl * npix * 16 + ((long long)C3B_ROWS * k + rr) * W * 16 + 8 * (rem0 - 72 * h)) * 2);
+    }
+    const bool hi = (lanebits >> (2 * j)) & 1, cok = (lanebits >> (2 * j + 1)) & 1;
+    const bool ok = cok && (hi ? rok[1] : rok[0]);
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(second ? x : gy) + ((hi ? boff[1] : boff[0]) + (unsigned)lane16);
+#ifdef C3B_ZERO_SPREAD
+    c3r_dma16(ok ? reinterpret_cast<const T*>(src) : zero_page + 128 * blockIdx.x, gring_lds + (second ? NR * C3R_ROWB : 0) + 1024 * ii + slot);
+#else
+    c3r_dma16(ok ? reinterpret_cast<const T*>(src) : zero_page, gring_lds + (second ? NR * C3R_ROWB : 0) + 1024 * ii + slot);
+#endif
+  };
+  auto segment_columns = [&]() {                      // per segment: which lanes' pixels lie inside the image row
+    lanebits = 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int c0 = 64 * ((wv + 4 * j) % 18);
+      const int rem0 = c0 - 72 * (c0 / 72);
+      const int hi = lane >= 72 - rem0 ? 1 : 0;       // lanes from here on belong to the next plane-row
+      const int px = (rem0 + lane - 72 * hi) >> 1;
+      lanebits |= (unsigned)(hi | ((px < C3R_SW + 2 && (unsigned)(x0 - 1 + px) < (unsigned)W) ? 2 : 0)) << (2 * j);
+    }
+  };
+  auto segment_begin = [&](int sg) {
+    const int seg = sg % nseg, sx = (sg / nseg) % nsx, b = sg / (nseg * nsx);
+    x0 = sx * C3R_SW; y0 = seg * RS;
+    sbase = (((long long)b * H + (y0 - 1)) * W + (x0 - 1)) * 16;
+    if (wv < 4) {
+      segment_columns();
+#pragma unroll
+      for (int k = 0; k <= D; ++k)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) issue_piece(k, j);
+    }
+  };
+  // step s reads quads s and s + 1.  Everything a data-gradient wave issued after its last piece of quad s + 1 may still be in
+  // flight: the D - 1 younger quads and the four stores of each of the min(s, D) steps since -- the segment's first D + 1 quads go
+  // out together, so step 0 starts when two of them are in.  The pieces of quad s + 1 + D (whose ring slot, quad s - 1's, the
+  // barrier has just freed) are issued INSIDE the step's MFMA stream, one per fragment group.
+  auto step_begin = [&](int s, bool dma_wave) {
+    if (dma_wave) C3B_STEP_WAIT((D - 1) * NP + min(s, D) * 4);
+    // (no LDS-counter wait: the only LDS reads in flight here are the next step's prefetches, which read quad s + 1)
+    __builtin_amdgcn_s_barrier();                     // every wave's pieces of quads s, s + 1 are in; all waves are done with quad s - 1
+    asm volatile("" ::: "memory");
+    C3B_STAMP(2 + 3 * s);
+  };
+
+  // The two roles run separate copies of the loop (same barrier count) so that neither carries the other's registers.
+  if (wv < 4) {
+    // ---- data gradient: wave (half, rp) -- rows 2 rp, 2 rp + 1 of the step, 32 output channels (= conv input channels) ----
+    // The four input rows i of the row pair are walked once: group (i, kx) = four B fragments (kc, mt), used by output row r with
+    // ky = i - r: per accumulator the products still arrive in (tap, kc) order, as in conv3x3_c64_rows_kernel.
+    const int half = wv & 1, rp = (wv >> 1) & 1;
+    const int laneA = (g >> 1) * (C3R_PXP * 32) + lr * 32 + (g & 1) * 16;        // B-fragment byte offset in a ring row
+    const int plane_o = 2 * half + (g >> 1);
+    Frag8<T> wreg[9][2][2];                           // (in flight under the first segment's quads; first use below)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          wreg[tap][kc][nt] = load8(wp + ((((tap * 2 + half) * 2 + kc) * 2 + nt) * 64 + lane) * 8);
+    Frag8<T> xf[2][2][2];                             // [buffer][kc][mt]
+    auto load_group = [&](int buf, int ring_row, int kx) {
+      const unsigned char* p = gring + (ring_row & (NR - 1)) * C3R_ROWB + laneA + kx * 32;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) xf[buf][kc][mt] = load8(reinterpret_cast<const T*>(p + kc * (2 * C3R_PXP * 32) + mt * (16 * 32)));
+    };
+    for (int sg = blockIdx.x; sg < nsegs; sg += gridDim.x) {
+      segment_begin(sg);
+      C3B_STAMP(1);
+      const long long obase = sbase + (long long)plane_o * npix * 16 + ((long long)W + 1) * 16 + (g & 1) * 8;   // (row y0, column x0)
+#pragma unroll 1
+      for (int s = 0; s < nsteps; ++s) {
+        step_begin(s, true);
+        if (s == 0) {                                 // (the weights went out before the first quads: in vmcnt order they are in too)
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt) asm volatile("" :: "v"(wreg[tap][kc][nt].v));
+        }
+        const int r0 = C3B_ROWS * s + 2 * rp;         // ring row of input row i = 0 of the pair
+        if (s == 0) load_group(0, r0, 0);             // (later steps: prefetched at the end of the step before)
+        f32x4 acc[2][2][2];                           // [output row of the pair][mt][nt]
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[r][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto store_row = [&](int r) {
+          const long long o = obase + ((long long)(C3B_ROWS * s + 2 * rp + r) * W + lr) * 16;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            float v[8];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[4 * nt + q] = acc[r][mt][nt][q];
+            store8f(gx + o + mt * (16 * 16), v);
+          }
+        };
+#pragma unroll
+        for (int gi = 0; gi < 12; ++gi) {
+          const int i = gi / 3, kx = gi - 3 * i;
+          if (gi < 11) load_group((gi + 1) & 1, r0 + (gi + 1) / 3, (gi + 1) % 3);
+          else load_group(0, r0 + C3B_ROWS, 0);       // the next step's first group (quad s + 1: landed)
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int ky = i - r;
+            if (ky < 0 || ky > 2) continue;
+            const int tap = 3 * ky + kx;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) mma16(acc[r][mt][nt], wreg[tap][kc][nt], xf[gi & 1][kc][mt]);
+          }
+          if (gi < NP) issue_piece(s + 1 + D, gi);
+          __builtin_amdgcn_sched_barrier(0);
+          if (gi == 8) store_row(0);                  // its last products were input row 2's
+        }
+        store_row(1);
+        C3B_STAMP(4 + 3 * s);
+      }
+      c3r_wait_vm(0);                                 // the dummy quads still in flight target the rings
+      __builtin_amdgcn_s_barrier();                   // and every wave is done reading them
+    }
+  } else {
+    // ---- weight gradient: wave v owns input-channel tile v; a step = four rows of 32 pixels = four 32-deep contraction chunks.
+    // The operand stream runs ahead: the x fragment XB taps on loads into the registers a tap's MFMAs have just released, the next
+    // row's gy^T fragments after the row's last MFMA (the data-gradient wave of the SIMD fills that gap).
+    const int vt = wv & 3;
+    const int trl = c3b_tr_lane(lane);
+    f32x4 wacc[9][4], bacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) wacc[tap][o] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Frag8<T> ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones.set(e, 1.0f);
+    constexpr int XB = 6;                             // x fragments in flight (positions 9 rl + tap of a step, XB divides 36)
+    static_assert((9 * C3B_ROWS) % XB == 0, "the x-fragment ring must close over a step");
+    Frag8<T> ga[4], gb, xb[XB];
+    // row R of the segment (R = 4 s + rl): gy lives in ring row R + 1, pixel p of the strip in ring pixel p + 1
+    auto load_g = [&](int R) {
+      const unsigned char* p = gring + ((R + 1) & (NR - 1)) * C3R_ROWB + (1 + 4 * g) * 32 + trl;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) ga[o] = c3b_tr(p + o * (C3R_PXP * 32));
+      gb = c3b_tr(p + vt * (C3R_PXP * 32));           // the bias product's operand = ga[vt] (a register select over ga[] would go through scratch)
+    };
+    auto load_x = [&](int n, int R0) {                // position n = 9 rl + tap of the step whose first row is R0 (n >= 36: the next step's)
+      const int rl = n / 9, tap = n - 9 * rl;         // x at (row + ky - 1, pixel + kx - 1): ring row R + ky, ring pixel 4 g + kx
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      xb[n % XB] = c3b_tr(xring + ((R0 + rl + ky) & (NR - 1)) * C3R_ROWB + vt * (C3R_PXP * 32) + (4 * g + kx) * 32 + trl);
+    };
+    for (int sg = blockIdx.x; sg < nsegs; sg += gridDim.x) {
+      segment_begin(sg);
+      C3B_STAMP(1);
+#pragma unroll 1
+      for (int s = 0; s < nsteps; ++s) {
+        step_begin(s, false);
+        if (s == 0) {
+          load_g(0);
+#pragma unroll
+          for (int n = 0; n < XB; ++n) load_x(n, 0);
+        }
+#pragma unroll
+        for (int rl = 0; rl < C3B_ROWS; ++rl) {
+          const int R = C3B_ROWS * s + rl;
+          mma16(bacc, gb, ones);
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap) {
+            const int n = 9 * rl + tap;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) mma16(wacc[tap][o], ga[o], xb[n % XB]);
+            load_x(n + XB, C3B_ROWS * s);             // (row 4 of the step = the next step's row 0: quad s + 1, landed)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          load_g(R + 1);
+        }
+        C3B_STAMP(4 + 3 * s);
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    // slab [tap][ic][oc]: a lane's four accumulator rows are four consecutive output channels
+    float* out = slabs + (long long)blockIdx.x * (9 * 64 * 64);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        float v[4] = {wacc[tap][o][0], wacc[tap][o][1], wacc[tap][o][2], wacc[tap][o][3]};
+        store4(out + ((long long)tap * 64 + 16 * vt + lr) * 64 + 16 * o + 4 * g, v);
+      }
+    if (lr == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias_slabs[(long long)blockIdx.x * 64 + 16 * vt + 4 * g + r] = bacc[r];
+    }
+  }
+  C3B_STAMP(63);
+}
+
 // bf16 takes the pipelined kernel: at most this many workgroups (8 per CU: with more tiles a workgroup walks several)
 constexpr int C3_PIPE_MAX_BLOCKS = 2048;
 
@@ -879,6 +1173,30 @@ int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs
     (void)hipFuncSetAttribute((const void*)conv3x3_c64_wgrad_kernel<bf16_t, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     M2T_LAUNCH_TIMED((conv3x3_c64_wgrad_kernel<bf16_t, 8>), dim3(nblk), dim3(512), sh, st, (const bf16_t*)x, (const bf16_t*)gy, slabs, bias_slabs, B, H, W, tpb);
   }
+  M2T_LAUNCH_CHECK();
+  *nslab = nblk;
+  return 0;
+}
+
+// fused backward (bf16): gx = data gradient, slabs [n][9][64][64] / bias_slabs [n][64] = weight / bias gradient partials,
+// *nslab = n <= 256 workgroups.  wrows_t: the weight in M2T_PACK_CONV3_ROWS_T order.  Returns M2T_UNSUPPORTED when the shape
+// has no strip decomposition (the caller then uses the two separate kernels).
+bool conv3x3_c64_bwd_fusable(int B, int H, int W) { return W % C3R_SW == 0 && H % 16 == 0 && (long long)B * H * W * 64 < (1LL << 31); }
+int launch_conv3x3_c64_bwd_fused(const void* gy, const void* x, const void* wrows_t, void* gx, float* slabs, float* bias_slabs, int* nslab,
+                                 const void* zero_page, int B, int H, int W, hipStream_t st) {
+  if (!conv3x3_c64_bwd_fusable(B, H, W)) return M2T_UNSUPPORTED;
+  // segments of 16 .. 64 rows, at least 256 of them when the map allows; a workgroup walks every 256th segment
+  const long long strips = (long long)B * (W / C3R_SW);
+  int rs = 64;
+  while (rs > 16 && (H % rs != 0 || strips * (H / rs) < 256)) rs >>= 1;
+  if (H % rs) return M2T_UNSUPPORTED;
+  const long long nsegs = strips * (H / rs);
+  const int nblk = (int)std::min<long long>(256, nsegs);
+  constexpr int D = 2;
+  const size_t sh = (size_t)2 * C3B_ROWS * (D + 2) * C3R_ROWB;
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)conv3x3_c64_bwd_rows_kernel<D>, (int)sh)) return rc__;
+  M2T_LAUNCH_TIMED((conv3x3_c64_bwd_rows_kernel<D>), dim3(nblk), dim3(512), sh, st, (const bf16_t*)gy, (const bf16_t*)x, (const bf16_t*)wrows_t,
+                   (bf16_t*)gx, slabs, bias_slabs, (const bf16_t*)zero_page, B, H, W, rs);
   M2T_LAUNCH_CHECK();
   *nslab = nblk;
   return 0;

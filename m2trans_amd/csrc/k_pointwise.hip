@@ -877,29 +877,8 @@ int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* par
 //   perm 0: identity
 //   perm 1: conv3x3 packed [tap][O][I] -> torch [O][I][3][3]
 //   perm 2: shuffled rows n' = sub*C + c (sub = i*r+j) -> torch row c*r*r + sub; rows of K
+//   perm 3 .. 6: see red_dest
 // =======================================================================================
-__global__ void __launch_bounds__(256) reduce_slabs_kernel(const float* __restrict__ slab, float* __restrict__ out, int ns,
-                                                           long long n, int perm, int p0, int p1, int p2) {
-  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
-    float acc = 0.f;
-#pragma unroll 8
-    for (int s = 0; s < ns; ++s) acc += slab[(long long)s * n + e];
-    long long d = e;
-    if (perm == 1) {           // p0 = O, p1 = I
-      const int i = (int)(e % p1); const int o = (int)((e / p1) % p0); const int tap = (int)(e / ((long long)p0 * p1));
-      d = ((long long)o * p1 + i) * 9 + tap;
-    } else if (perm == 2) {    // p0 = C (64), p1 = r*r, p2 = K
-      const int kk = (int)(e % p2); const int np = (int)(e / p2);
-      const int sub = np / p0, c = np % p0;
-      d = ((long long)c * p1 + sub) * p2 + kk;
-    } else if (perm == 3) {    // tail conv slab [32 (tap*3+oc, 27 used)][64 ic] -> torch [3][64][3][3]
-      const int ic = (int)(e & 63), nn = (int)(e >> 6);
-      if (nn >= 27) continue;
-      d = ((long long)(nn % 3) * 64 + ic) * 9 + nn / 3;
-    }
-    out[d] = acc;
-  }
-}
 // Batched form: ONE launch reduces many slab sets (every weight / bias / rel-pos gradient of a group of
 // blocks), driven by a descriptor table.  grid (x = element chunks, y = descriptor).
 __device__ __forceinline__ long long red_dest(long long e, int perm, int p0, int p1, int p2, bool& skip) {
@@ -919,6 +898,9 @@ __device__ __forceinline__ long long red_dest(long long e, int perm, int p0, int
     const int kk = (int)(e % p0);
     if (kk >= p1) { skip = true; return 0; }
     return (e / p0) * p1 + kk;
+  } else if (perm == 6) {    // conv3x3 [tap][I][O] (fused backward kernel) -> torch [O][I][3][3]; p0 = O, p1 = I
+    const int o = (int)(e % p0); const int i = (int)((e / p0) % p1); const int tap = (int)(e / ((long long)p0 * p1));
+    return ((long long)o * p1 + i) * 9 + tap;
   } else if (perm == 4) {    // rel-pos [10][C] -> rel_h [10][C/2] followed by rel_w [10][C/2]; p0 = C
     const int c = (int)(e % p0), i = (int)(e / p0);
     return (c < p0 / 2) ? ((long long)i * (p0 / 2) + c) : ((long long)10 * (p0 / 2) + (long long)i * (p0 / 2) + (c - p0 / 2));
@@ -977,12 +959,6 @@ int launch_multi_reduce(const float* arena, float* grads, const m2t_red_desc* de
   return 0;
 }
 
-int launch_reduce_slabs(const float* slab, float* out, int ns, long long n, int perm, int p0, int p1, int p2,
-                        hipStream_t st) {
-  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(n)), dim3(256), 0, st, slab, out, ns, n, perm, p0, p1, p2);
-  M2T_LAUNCH_CHECK();
-  return 0;
-}
 
 // =======================================================================================
 // clamp + crop + L1 (+ backward seed)                    (:74-76, train.py:199)

@@ -138,10 +138,12 @@ struct m2t_plan {
   bool use_fused_tail_fwd = true;      // x4 bf16: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored
                                        // (with bf16 mode's exp2 / rcp GELU: 5.30 vs 5.34 ms per step and 1.6 GB less HBM traffic;
                                        // with the erf form of round 2 it was 1 % slower)
-  int gate_branch = 1;                 // side-stream gate: -1 ungated, else the branch (3..0) behind whose attention launch a block's
-                                       // parameter-gradient work is released.  Same-box A/B (config 1): 1 = 5.49 ms, 2 = 5.60, 3 = 5.62,
-                                       // 0 = 5.68, ungated 5.64
+  int gate_branch = 2;                 // side-stream gate: -1 ungated, else the branch (3..0) behind whose attention launch a block's
+                                       // parameter-gradient work is released.  Same-box A/B (config 1) with the fused conv backward:
+                                       // 2 = 5.27 ms, 1 = 5.34, 3 = 5.33, ungated 5.34 (with the conv weight gradient on the side stream,
+                                       // round 2: 1 = 5.49, 2 = 5.60, 3 = 5.62, 0 = 5.68, ungated 5.64)
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)         } option "attn_bwd":
+  bool use_fused_conv_bwd = true;      // bf16 conv3x3 64 -> 64 backward: data + weight / bias gradient in one row-streaming pass (k_conv.hip)
   int use_conv_rows = 1;               // bf16 conv3x3 64 -> 64: row-streaming LDS-DMA kernel (k_conv.hip); 0 = the tile kernel; 3 / 4: A/B variants
   int wgrad_big_tiles = -1;            // C = 256 qkv weight gradient: 128 x 128 output tiles (k_gemm.hip); value = target workgroups,
                                        // 0 = off, -1 = auto: 256 from 24 576 rows on (batch 32: 9.82 vs 9.93 ms; batch 16: 5.53 vs 5.49)
@@ -381,6 +383,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "fused_tail_fwd") return p->use_fused_tail_fwd && p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
     if (o == "attn_bwd") return p->dt == M2T_F32 ? 0 : (p->use_resident_attn_bwd ? (p->use_fused_qkv_dgrad ? 2 : 1) : 0);
     if (o == "conv_rows") return p->dt != M2T_F32 ? p->use_conv_rows : 0;
+    if (o == "fused_conv_bwd") return p->dt != M2T_F32 && p->use_fused_conv_bwd && conv3x3_c64_bwd_fusable(p->B, p->H, p->W);
     if (o == "fused_attn_fwd") return p->dt != M2T_F32 ? (p->use_fused_attn_fwd == 2 && !p->c64_recompute() ? 1 : p->use_fused_attn_fwd) : 0;
     if (o == "fused_c16_fwd") return p->dt != M2T_F32 ? (p->use_fused_c16_fwd == 2 && !p->use_resident_attn_bwd ? 1 : p->use_fused_c16_fwd) : 0;
     if (o == "fused_qkv_dgrad") return p->use_fused_qkv_dgrad && p->use_resident_attn_bwd && p->dt != M2T_F32;
@@ -754,11 +757,22 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       return 0;
     };
     hipEvent_t conv_done = nullptr;
-    if (!gated) {
+    // bf16: both gradients in one pass over gy on the main stream (the partials still reduce on the side stream: every block
+    // forks at least once after this launch and before its flush)
+    const bool fuse_conv = dt != M2T_F32 && p->use_fused_conv_bwd && !skip && conv3x3_c64_bwd_fusable(B, H, W);
+    if (fuse_conv) {
+      ARENA(slabs, (size_t)256 * 9 * 64 * 64);
+      ARENA(colp, (size_t)256 * 64);
+      { M2TProfScope ps(M2T_PROF_CONV3_BWD, st);
+        CK(launch_conv3x3_c64_bwd_fused(gy, xc, packed_ptr(p, workspace, k + "wfTR"), gxc, slabs, colp, &ns, WSP("zero_page"), B, H, W, st)); }
+      defer(slabs, p->poff.at(pre + "feed_forward.0.weight"), ns, 9 * 64 * 64, 6, 64, 64, 0);    // slabs come as [tap][ic][oc]
+      defer(colp, p->poff.at(pre + "feed_forward.0.bias"), ns, 64, 0, 0, 0, 0);
+    } else if (!gated) {
       fork();
       CK(side_conv());
       conv_done = side_marker();
     }
+    if (!fuse_conv)
     { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st,
                                                                         packed_ptr(p, workspace, k + "wfTR"), WSP("zero_page"), p->use_conv_rows >= 2 ? p->use_conv_rows : (p->use_conv_rows ? 0 : 1))); }
     for (int i = 3; i >= 0; --i) {
@@ -806,8 +820,10 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
           CK(side_branch(j));
           branch_done[j] = side_marker();
         }
-        CK(side_conv());
-        conv_done = side_marker();
+        if (!fuse_conv) {
+          CK(side_conv());
+          conv_done = side_marker();
+        }
       } else if (i < gate) {
         fork();
         CK(side_branch(i));
@@ -892,6 +908,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
     p->use_resident_attn_bwd = value >= 1; p->use_fused_qkv_dgrad = value == 2; return 0;
   }
   if (k == "conv_rows") { p->use_conv_rows = (int)value; return 0; }
+  if (k == "fused_conv_bwd") { p->use_fused_conv_bwd = (value != 0); return 0; }
   if (k == "fused_attn_fwd") { if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_attn_fwd: 0..2"); p->use_fused_attn_fwd = (int)value; p->have_acts = false; return 0; }
   if (k == "fused_c16_fwd") { if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_c16_fwd: 0..2"); p->use_fused_c16_fwd = (int)value; p->have_acts = false; return 0; }
   if (k == "debug_skip_side") { p->debug_skip_side = (value != 0); return 0; }

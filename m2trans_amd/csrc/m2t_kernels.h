@@ -7,6 +7,7 @@
 #define M2T_NORM_SPLIT 32     // pixel splits per image in the InstanceNorm reductions
 #define M2T_LOSS_BLOCKS 1024  // partial sums of the L1 loss
 #define M2T_MAX_SLABS 1024    // split-M slabs of a weight-gradient GEMM
+#define M2T_UNSUPPORTED (-1000)
 #define M2T_PACK_CHUNK 2048   // output elements one workgroup of the weight-packing kernel converts
 
 enum m2t_pack_kind {
@@ -37,6 +38,7 @@ enum m2t_prof_cat {
   M2T_PROF_ATTN_FUSED_64, M2T_PROF_ATTN_FUSED_256,      // fused qkv projection + window attention forward (k_attn_fused.hip)
   M2T_PROF_TAIL_FWD_FUSED,                              // tail.3 expansion + PixelShuffle + GELU + tail conv (k_tail_fwd.hip)
   M2T_PROF_ATTN_FUSED_16,                               // InstanceNorm apply + qkv projection + window attention, C = 16 (k_attn_c16.hip)
+  M2T_PROF_CONV3_BWD,                                   // conv 64 -> 64 data + weight gradient in one pass (k_conv.hip)
   M2T_PROF_NCAT
 };
 void m2t_prof_begin(int cat, hipStream_t st);
@@ -45,7 +47,8 @@ void m2t_prof_end(int cat, hipStream_t st);
 // (hipExtLaunchKernelGGL start / stop events = the dispatch's own begin / end timestamps, the quantity rocprofv3
 // reports) instead of bracketing it with marker packets, which add the ~5 us launch gap to every sample.
 #define M2T_PROF_DISPATCH_CATS ((1ull << M2T_PROF_GEMM_QKV) - 1ull | (1ull << M2T_PROF_FINAL_FWD) | (1ull << M2T_PROF_FINAL_DGRAD) | (1ull << M2T_PROF_FINAL_WGRAD) | \
-                                (1ull << M2T_PROF_ATTN_FUSED_64) | (1ull << M2T_PROF_ATTN_FUSED_256) | (1ull << M2T_PROF_TAIL_FWD_FUSED) | (1ull << M2T_PROF_ATTN_FUSED_16))
+                                (1ull << M2T_PROF_ATTN_FUSED_64) | (1ull << M2T_PROF_ATTN_FUSED_256) | (1ull << M2T_PROF_TAIL_FWD_FUSED) | (1ull << M2T_PROF_ATTN_FUSED_16) | \
+                                (1ull << M2T_PROF_CONV3_BWD))
 bool m2t_prof_take(hipEvent_t* a, hipEvent_t* b);
 #define M2T_LAUNCH_TIMED(kernel, grid, block, sh, st, ...)                                                       \
   do {                                                                                                           \
@@ -78,7 +81,6 @@ int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* par
                   int accumulate, hipStream_t st, int unshuf = 0, int gH = 0, int gW = 0, int gr = 1, int gC = 64,
                   int* nblk_out = nullptr);   // nblk_out != null: write the partials only and report their count
 int launch_multi_reduce(const float* arena, float* grads, const m2t_red_desc* descs, int ndesc, hipStream_t st);
-int launch_reduce_slabs(const float* slab, float* out, int ns, long long n, int perm, int p0, int p1, int p2, hipStream_t st);
 int launch_clamp_l1(const float* pre, const float* hr, float* sr, float* gpre, float* part, float* loss, int B, int Hp,
                     int Wp, int Hs, int Ws, float R, float loss_scale, float gscale, hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
@@ -138,6 +140,11 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
                                                           // (conv3x3_c64_pipe_kernel); 3: depth 3; 4: depth 2 + pipelined epilogue
 int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, float* bias_slabs, int* nslab, int B, int H,
                              int W, hipStream_t st);   // bias_slabs [nslab][64]: column sums of gy
+// bf16: data gradient + weight / bias gradient partials in one pass over gy (conv3x3_c64_bwd_rows_kernel); M2T_UNSUPPORTED for
+// shapes without a strip decomposition.  wrows_t: M2T_PACK_CONV3_ROWS_T; slabs [<= 256][9][64][64], bias_slabs [<= 256][64]
+bool conv3x3_c64_bwd_fusable(int B, int H, int W);
+int launch_conv3x3_c64_bwd_fused(const void* gy, const void* x, const void* wrows_t, void* gx, float* slabs, float* bias_slabs, int* nslab,
+                                 const void* zero_page, int B, int H, int W, hipStream_t st);
 // tail conv 64->3, reflect padding, input = the stored activation gelu(t); output NCHW fp32 [B][3][H][W]
 int launch_final_conv_fwd(int dt, const void* tpre, const float* w, float* out, int B, int H, int W, hipStream_t st);
 int launch_final_conv_dgrad(int dt, const float* gout, const float* w, const void* tpre, void* gtpre, int B, int H, int W,
@@ -146,8 +153,6 @@ int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* 
                             hipStream_t st);
 
 // ---- k_branch.hip -----------------------------------------------------------------------
-// one CFTM branch of the forward pass (prep + qkv projection + window attention + IWT/residual) per window;
-#define M2T_UNSUPPORTED (-1000)
 
 // ---- k_tail_fwd.hip ----------------------------------------------------------------------
 // x4 tail, bf16: tail.3 expansion + PixelShuffle + GELU + tail conv in one pass; gelu(t2) never reaches HBM.

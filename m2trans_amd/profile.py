@@ -25,7 +25,7 @@ from . import _lib
 CATS = ["attn_fwd_c16", "attn_fwd_c64", "attn_fwd_c256", "attn_bwd_c16", "attn_bwd_c64", "attn_bwd_c256",
         "conv3x3_fwd", "conv3x3_dgrad", "conv3x3_wgrad", "gemm_qkv", "gemm_qkv_dgrad", "wgrad_qkv",
         "tail_gemm", "tail_wgrad", "final_conv_fwd", "final_conv_dgrad", "final_conv_wgrad",
-        "attn_fused_c64", "attn_fused_c256", "tail_fwd_fused", "attn_fused_c16"]
+        "attn_fused_c64", "attn_fused_c256", "tail_fwd_fused", "attn_fused_c16", "conv3x3_bwd"]
 KERNEL_OF = {
     "attn_fwd_c16": "window_attn_fwd_kernel<C=16>", "attn_fwd_c64": "window_attn_fwd_kernel<C=64>",
     "attn_fwd_c256": "window_attn_fwd_kernel<C=256>", "attn_bwd_c16": "window_attn_bwd_kernel<C=16>",
@@ -40,6 +40,7 @@ KERNEL_OF = {
     "attn_fused_c256": "window_attn_fused_fwd_kernel<C=256,L=2> (qkv projection + window attention + IWT^2/residual)",
     "attn_fused_c16": "window_attn_fused_c16_fwd_kernel (InstanceNorm apply + qkv projection + window attention + residual, wave per window)",
     "tail_fwd_fused": "tail_fwd_fused_kernel (tail.3 1x1 expansion + PixelShuffle + GELU + tail conv)",
+    "conv3x3_bwd": "conv3x3_c64_bwd_rows_kernel (64->64 3x3 conv: data gradient + weight / bias gradient in one row-streaming pass)",
 }
 KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these categories
     "attn_fwd_c16": "window_attn_fwd_c16_kernel (wave per window)",
@@ -74,7 +75,7 @@ def read_all():
 
 def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8, fused_attn_fwd: bool | None = None,
                      fused_tail_fwd: bool = False, fused_qkv_dgrad: bool | None = None, fused_c16_fwd: bool | None = None,
-                     c16_recompute: bool | None = None, c64_recompute: bool | None = None):
+                     c16_recompute: bool | None = None, c64_recompute: bool | None = None, fused_conv_bwd: bool | None = None):
     """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr.
     fused_attn_fwd (default: bf16 mode): the C = 64 / 256 branches run qkv projection + attention as one kernel, so
     the forward `gemm_qkv` / `attn_fwd_*` categories are then empty (the C = 16 branch runs InstanceNorm apply +
@@ -89,6 +90,8 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         c16_recompute = dtype == "bf16"
     if c64_recompute is None:             # plan option "fused_attn_fwd" = 2 (default in bf16 mode): qkv2 is not stored
         c64_recompute = dtype == "bf16"
+    if fused_conv_bwd is None:            # plan option "fused_conv_bwd" (default on in bf16 mode)
+        fused_conv_bwd = dtype == "bf16"
     es = 2 if dtype == "bf16" else 4
     H = W = (lr + 31) // 32 * 32
     P = H * W
@@ -122,8 +125,13 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         add("wgrad_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
     conv_fl = 2.0 * B * P * 64 * 576
     add("conv3x3_fwd", nb * conv_fl, nb * B * P * 64 * es * 3, nb)
-    add("conv3x3_dgrad", nb * conv_fl, nb * B * P * 64 * es * 2, nb)
-    add("conv3x3_wgrad", nb * conv_fl, nb * B * P * 64 * es * 2, nb)
+    if fused_conv_bwd:
+        # one pass: reads the output gradient and the conv input, writes the input gradient (the fp32 partial slabs of the weight
+        # gradient, 37.7 MB per launch at 256 workgroups, are bookkeeping of the split, not algorithmic bytes)
+        add("conv3x3_bwd", nb * 2 * conv_fl, nb * B * P * 64 * es * 3, nb)
+    else:
+        add("conv3x3_dgrad", nb * conv_fl, nb * B * P * 64 * es * 2, nb)
+        add("conv3x3_wgrad", nb * conv_fl, nb * B * P * 64 * es * 2, nb)
     if scale == 4:
         # tail.0: M=BP, K=64, N=256 ; tail.3: M=4BP ; each: fwd + dgrad GEMM and a wgrad
         for M in (B * P, 4 * B * P):
@@ -158,7 +166,7 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
 def plan_options(plan) -> dict:
     """The kernel-selection options in force on a plan (m2t_plan_query("opt:<key>")): which kernels ran decides which
     rows of `algorithmic_work` apply."""
-    o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_tail_fwd", "fused_c16_fwd", "conv_rows")}
+    o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_tail_fwd", "fused_c16_fwd", "conv_rows", "fused_conv_bwd")}
     o["c16_recompute"] = plan.query("opt:fused_c16_fwd") == 2
     o["c64_recompute"] = plan.query("opt:fused_attn_fwd") == 2
     o["fused_qkv_dgrad"] = plan.query("opt:attn_bwd") == 2
@@ -175,7 +183,8 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
     opts = plan_options(plan) if plan is not None else {}
     work = algorithmic_work(B, lr, scale, dtype, fused_attn_fwd=opts.get("fused_attn_fwd"), fused_tail_fwd=bool(opts.get("fused_tail_fwd", False)),
                             fused_qkv_dgrad=opts.get("fused_qkv_dgrad"), fused_c16_fwd=opts.get("fused_c16_fwd"),
-                            c16_recompute=opts.get("c16_recompute"), c64_recompute=opts.get("c64_recompute"))
+                            c16_recompute=opts.get("c16_recompute"), c64_recompute=opts.get("c64_recompute"),
+                            fused_conv_bwd=opts.get("fused_conv_bwd"))
     traffic = {}
     if pmc_file and os.path.exists(pmc_file):
         try:

@@ -175,7 +175,7 @@ def test_bf16_fast_kernels_match_plain_kernels():
     for fast in (1, 0):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
-        for key, val in ((b"attn_bwd", 2 if fast else 0), (b"gate_branch", 1 if fast else -1), (b"side_stream", fast), (b"fused_tail_bwd", fast)):
+        for key, val in ((b"attn_bwd", 2 if fast else 0), (b"gate_branch", 2 if fast else -1), (b"fused_conv_bwd", fast), (b"side_stream", fast), (b"fused_tail_bwd", fast)):
             _lib.check(_lib.load().m2t_set_option(plan.handle, key, val), "m2t_set_option")
         sr = model(x)
         torch.nn.L1Loss()(sr, hr).backward()
@@ -540,13 +540,44 @@ def test_row_streaming_conv3x3_is_bit_identical_to_the_tile_kernel():
             model, _ = build_model(scale, nb, "bf16")
             plan = model._plan_for(x)
             _lib.check(_lib.load().m2t_set_option(plan.handle, b"conv_rows", rows), "m2t_set_option")
-            assert plan.query("opt:conv_rows") == rows
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_conv_bwd", 0), "m2t_set_option")     # the data gradient is this kernel too
+            assert plan.query("opt:conv_rows") == rows and plan.query("opt:fused_conv_bwd") == 0
             sr = model(x)
             torch.nn.L1Loss()(sr, hr).backward()
             outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone()))
         for o in outs[1:]:
             assert torch.equal(outs[0][0], o[0]), (B, H, W)
             assert torch.equal(outs[0][1], o[1]), (B, H, W)
+
+
+def test_fused_conv_backward_matches_the_two_kernel_path():
+    """bf16 3x3 conv 64 -> 64 backward in one pass (conv3x3_c64_bwd_rows_kernel, option fused_conv_bwd, default): its data-gradient
+    waves run the row-streaming kernel's products in the same order, so every gradient that flows THROUGH the conv -- all
+    parameters but the conv's own -- is bit-identical to the two-kernel path; the conv weight / bias gradients are the same bf16
+    products accumulated in fp32 in another order (one 32-pixel row per MFMA, <= 256 partial slabs): within 1e-5 of the gradient's
+    norm.  Sizes as in the row-streaming test: segments of 32 and 16 rows, strips at the image border, reflect padding."""
+    from m2trans_amd import _lib
+    for (B, H, W) in ((8, 128, 128), (3, 96, 160), (2, 60, 90)):
+        scale, nb = 4, 2
+        x = O.closed_form_image(B, 3, H, W).cuda()
+        hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+        outs = []
+        for fused in (1, 0):
+            model, _ = build_model(scale, nb, "bf16")
+            plan = model._plan_for(x)
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_conv_bwd", fused), "m2t_set_option")
+            assert plan.query("opt:fused_conv_bwd") == fused
+            sr = model(x)
+            torch.nn.L1Loss()(sr, hr).backward()
+            outs.append((sr.detach().clone(), {n: q.grad.clone() for n, q in model.named_parameters() if q.requires_grad}))
+        (sa, ga), (sb, gb) = outs
+        assert torch.equal(sa, sb)
+        for n in ga:
+            if ".feed_forward.0." in n:
+                d = float((ga[n].double() - gb[n].double()).norm()) / float(gb[n].double().norm())
+                assert d < 1e-5, (B, H, W, n, d)
+            else:
+                assert torch.equal(ga[n], gb[n]), (B, H, W, n)
 
 
 def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():

@@ -374,6 +374,11 @@ def test_roofline_work_table_matches_the_profiler_categories():
     bwd_keys = ["attn_bwd_c16", "attn_bwd_c64", "attn_bwd_c256", "gemm_qkv_dgrad"]
     assert abs(tot(w, fwd_keys) - tot(w0, fwd_keys)) < 1e-3 * tot(w0, fwd_keys)
     assert abs(tot(w, bwd_keys) - tot(w0, bwd_keys)) < 1e-3 * tot(w0, bwd_keys)
+    # the fused conv backward does the FLOPs of the two kernels it replaces on three tensor passes instead of four
+    ws = P.algorithmic_work(16, 128, 4, "bf16", fused_conv_bwd=False)
+    assert "conv3x3_bwd" in wd and "conv3x3_dgrad" not in wd and "conv3x3_bwd" not in ws
+    assert wd["conv3x3_bwd"][0] == ws["conv3x3_dgrad"][0] + ws["conv3x3_wgrad"][0]
+    assert wd["conv3x3_bwd"][1] * 4 == (ws["conv3x3_dgrad"][1] + ws["conv3x3_wgrad"][1]) * 3 and wd["conv3x3_bwd"][2] == 8
 
 
 def test_bench_plain_multi_gpu_launch_builds_the_torchrun_child():
