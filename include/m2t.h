@@ -67,9 +67,10 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "fused_tail_fwd"    [1] bf16 x4: tail.3 expansion + PixelShuffle + GELU + tail conv in one kernel (k_tail_fwd.hip); gelu(t2) and
  *                           gelu'(t2) are then never stored and the fused tail backward recomputes them per tile (needs
  *                           "fused_tail_bwd"); m2t_plan_query("stores_t2") tells whether ws:t2act / ws:t2der are written
- *   "attn_bwd"          [2] bf16 attention backward: 0 = chunked kernels + halo gather + data-gradient GEMM, 1 = whole-window-
+ *   "attn_bwd"          [3] bf16 attention backward: 0 = chunked kernels + halo gather + data-gradient GEMM, 1 = whole-window-
  *                           resident / wave-per-window kernels, 2 = 1 + the data gradient of the qkv projection inside the
- *                           C = 64 / 256 kernels (k_attn_res.hip)
+ *                           C = 64 / 256 kernels (k_attn_res.hip), 3 = 2 + one kernel for the C = 16 branch's overlap-add,
+ *                           projection data gradient and branch_prep_bwd (k_attn_c16.hip; bit-identical to 2)
  *   "conv_rows"         [1] bf16 conv3x3 64 -> 64 (forward and data gradient): row-streaming kernel fed by LDS-DMA with the weights in
  *                           registers (k_conv.hip); 0 = the 8 x 16 tile kernel it replaced (3 / 4: DMA-depth / epilogue variants kept for
  *                           A/B).  All bit-identical

@@ -548,6 +548,75 @@ __global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// C = 16 branch, what follows the attention backward on the main chain, in one pass per pixel row (bf16):
+//   halo_gather     dK|dV of a window-border pixel += the ring rows of the (<= 3) neighbouring windows      (k_attn.hip)
+//   gemm_nt         g_d = [dq | dK | dV] Wqkv      (M = pixels, N = 16, K = 48)                               (k_gemm.hip)
+//   branch_prep_bwd g_n[chunk 0] = g_d + g_xc[chunk 0]                                                        (k_pointwise.hip)
+// Three launches that move 25 + 25 + 17 MB per block at batch 16 become one that reads each gqkv row once.  A wave owns 16
+// consecutive pixels of an image row: lane (pixel = l & 15, g = l >> 4) loads the 8 columns 8 g .. of the first 32 (dq | dK) and,
+// for g < 2, of the last 16 (dV) of its pixel's row, adds the neighbours' ring rows in halo_gather's order (fp32, one rounding),
+// writes the completed dK|dV back (the weight-gradient GEMM on the side stream reads them) and feeds the rounded values to the
+// same two 32-deep MFMAs the GEMM issues (k-slot = column; the second one zero beyond column 47); the tile comes back as
+// (pixel, 4 channels) per lane, is rounded like the GEMM's store, and leaves as g_n.  Bit-identical to the three kernels.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) c16_dgrad_prep_kernel(bf16_t* __restrict__ gqkv, const bf16_t* __restrict__ win,
+                                                             const bf16_t* __restrict__ wT, const bf16_t* __restrict__ gxc,
+                                                             bf16_t* __restrict__ gn, int B, int h, int w) {
+  using T = bf16_t;
+  const int lane = threadIdx.x & 63, lr = lane & 15, g = lane >> 4;
+  const int tpr = w / 16;                             // tiles per image row
+  const int ntile = B * h * tpr;
+  const int nh = h / 8, nw = w / 8;
+  // A operand: Wqkv^T rows n = lr ([16][48]): columns 8 g .. of the first 32, and 32 + 8 g .. (g < 2) of the rest
+  const Frag8<T> wa0 = load8(wT + lr * 48 + 8 * g);
+  const Frag8<T> wa1 = g < 2 ? load8(wT + lr * 48 + 32 + 8 * g) : frag_zero<T>();
+  // this lane's two 8-column pieces of a gqkv row: piece 0 = columns 8 g (dq for g < 2, dK for g >= 2), piece 1 = 32 + 8 (g & 1)
+  // (dV; lanes g >= 2 load it too -- no divergent loads -- and drop it)
+  const int col0 = 8 * g, col1 = 32 + 8 * (g & 1);
+  const int ring0 = g >= 2 ? 8 * (g - 2) : 0, ring1 = 16 + 8 * (g & 1);        // the pieces' columns inside a ring row [dK | dV]
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
+  for (int t = wave; t < ntile; t += nwave) {
+    const int tx = t % tpr, y = (t / tpr) % h, b = t / (tpr * h);
+    const int x = 16 * tx + lr;
+    const long long pix = ((long long)b * h + y) * w + x;
+    T* row = gqkv + pix * 48;
+    long long hoff[3];
+    const int nsrc = halo_sources(b, y, x, nh, nw, 32, hoff);
+    float a0[8], a1[8], r0[3][8], r1[3][8], px4[4];
+    load8f(row + col0, a0);
+    load8f(row + col1, a1);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {                     // unconditional loads from a clamped source, selected below
+      const long long o = a < nsrc ? hoff[a] : 0;
+      load8f(win + o + ring0, r0[a]);
+      load8f(win + o + ring1, r1[a]);
+    }
+    load4(gxc + pix * 16 + 4 * g, px4);
+    const bool gather0 = g >= 2 && nsrc > 0, gather1 = g < 2 && nsrc > 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (a < nsrc) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a0[e] = g >= 2 ? a0[e] + r0[a][e] : a0[e]; a1[e] += r1[a][e]; }
+      }
+    }
+    Frag8<T> f0, f1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { f0.set(e, a0[e]); f1.set(e, g < 2 ? a1[e] : 0.f); }
+    if (gather0) store8(row + col0, f0);
+    if (gather1) store8(row + col1, f1);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mma16(acc, wa0, f0);                              // D[n = 4 g + r][pixel lr]
+    mma16(acc, wa1, f1);
+    float o4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o4[r] = to_f(from_f<T>(acc[r])) + px4[r];     // g_d is a stored bf16 tensor in the unfused chain
+    store4(gn + pix * 16 + 4 * g, o4);
+  }
+}
+
 }  // namespace
 
 int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
@@ -558,6 +627,19 @@ int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float*
   if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_bwd_c16_kernel, (int)sh)) return rc__;
   M2T_LAUNCH_TIMED(window_attn_bwd_c16_kernel, dim3((nwin + 3) / 4), dim3(256), sh, st, (const bf16_t*)qkv, rel_h, rel_w,
                      (const bf16_t*)gout, ldg, gc0, (bf16_t*)gqkv, (bf16_t*)win, relw, h, w, nwin, (const bf16_t*)d, (const bf16_t*)wqkv);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// gqkv [B*h*w][48] (dK|dV of border pixels completed in place), win [window][36][32], wT = Wqkv^T [16][48] (M2T_PACK_TRANSPOSE),
+// gxc / gn: chunk 0 planes [B*h*w][16] of the P64 gradients.  w % 16 == 0.
+int launch_c16_dgrad_prep(void* gqkv, const void* win, const void* wT, const void* gxc, void* gn, int B, int h, int w, hipStream_t st) {
+  if (h % 8 || w % 16) return m2t_set_error(-2, "c16_dgrad_prep: h % 8, w % 16");
+  const long long ntile = (long long)B * h * (w / 16);
+  if (ntile * 16 * 48 >= (1LL << 31)) return m2t_set_error(-2, "c16_dgrad_prep: too many pixels for 32-bit tile indexing");
+  const int grid = (int)std::min<long long>((ntile + 3) / 4, 4096);
+  hipLaunchKernelGGL(c16_dgrad_prep_kernel, dim3(grid), dim3(256), 0, st, (bf16_t*)gqkv, (const bf16_t*)win, (const bf16_t*)wT,
+                     (const bf16_t*)gxc, (bf16_t*)gn, B, h, w);
   M2T_LAUNCH_CHECK();
   return 0;
 }

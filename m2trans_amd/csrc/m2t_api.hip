@@ -147,7 +147,8 @@ struct m2t_plan {
   int use_conv_rows = 1;               // bf16 conv3x3 64 -> 64: row-streaming LDS-DMA kernel (k_conv.hip); 0 = the tile kernel; 3 / 4: A/B variants
   int wgrad_big_tiles = -1;            // C = 256 qkv weight gradient: 128 x 128 output tiles (k_gemm.hip); value = target workgroups,
                                        // 0 = off, -1 = auto: 256 from 24 576 rows on (batch 32: 9.82 vs 9.93 ms; batch 16: 5.53 vs 5.49)
-  bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside that kernel                } 0 / 1 / 2
+  bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside that kernel                } 0 .. 3
+  bool use_c16_prep = true;            // bf16, C = 16: overlap-add + projection data gradient + branch_prep_bwd in one kernel }
   int use_fused_c16_fwd = 2;           // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip);
                                        // 2: ... and qkv1 is not stored: the wave-per-window backward recomputes it from d1 (needs attn_bwd >= 1)
   bool c16_recompute() const { return dt != M2T_F32 && use_fused_c16_fwd == 2 && use_resident_attn_bwd; }
@@ -381,7 +382,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "wgrad_big_tiles") return p->wgrad_big_tiles + 1000;
     if (o == "fused_tail_bwd") return p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
     if (o == "fused_tail_fwd") return p->use_fused_tail_fwd && p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
-    if (o == "attn_bwd") return p->dt == M2T_F32 ? 0 : (p->use_resident_attn_bwd ? (p->use_fused_qkv_dgrad ? 2 : 1) : 0);
+    if (o == "attn_bwd") return p->dt == M2T_F32 ? 0 : (p->use_resident_attn_bwd ? (p->use_fused_qkv_dgrad ? (p->use_c16_prep ? 3 : 2) : 1) : 0);
     if (o == "conv_rows") return p->dt != M2T_F32 ? p->use_conv_rows : 0;
     if (o == "fused_conv_bwd") return p->dt != M2T_F32 && p->use_fused_conv_bwd && conv3x3_c64_bwd_fusable(p->B, p->H, p->W);
     if (o == "fused_attn_fwd") return p->dt != M2T_F32 ? (p->use_fused_attn_fwd == 2 && !p->c64_recompute() ? 1 : p->use_fused_attn_fwd) : 0;
@@ -793,6 +794,9 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       // (gathering inside the TILED GEMM / wgrad loaders, M2T_A_HALO, was measured slower: the gather is then
       //  repeated once per column-block.)
       const void* gxc_i = (const char*)gxc + (size_t)i * BP * 16 * p->esz;       // chunk i of the P64 gradient: a dense plane
+      // bf16 C = 16 with "attn_bwd" = 3: the overlap-add, the projection data gradient and branch_prep_bwd are one kernel behind
+      // the attention backward; it completes dK|dV in gqkv, so the branch's side work is released after it
+      const bool c16_prep = dt != M2T_F32 && C == 16 && p->use_c16_prep && p->use_fused_qkv_dgrad && p->use_resident_attn_bwd;
       if (fused_dgrad(i)) {
         M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256, st);
         const bool rc64 = C == 64 && p->c64_recompute();
@@ -804,34 +808,41 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         // qkv1 was not stored: recomputed inside the kernel from d1 (identical bits); then the halo overlap-add as usual
         { M2TProfScope ps(M2T_PROF_ATTN_BWD_16, st);
           CK(launch_window_attn_bwd_c16(nullptr, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, st, WSP(k + "d1"), packed_ptr(p, workspace, k + "w1"))); }
-        CK(launch_halo_gather(dt, win, gqkv, B, h, w, 2 * C, 3 * C, C, st));
+        if (!c16_prep) CK(launch_halo_gather(dt, win, gqkv, B, h, w, 2 * C, 3 * C, C, st));
       } else {
-        CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, st, L, true, p->use_resident_attn_bwd));
+        CK(launch_window_attn_bwd(dt, qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, st, L, !c16_prep, p->use_resident_attn_bwd));
       }
-      if (!gated) {
-        fork();
-        CK(side_branch(i));
-        branch_done[i] = side_marker();
-      } else if (i == gate) {
-        fork();                              // the gate: the LDS-hungry attention kernels of this block are on their way
-        // gated branches first, then the block's conv weight gradient (512 threads, 80 KB of LDS: +1.9 % over putting it
-        // first, where it met the C = 64 attention)
-        for (int j = 3; j >= gate; --j) {
-          CK(side_branch(j));
-          branch_done[j] = side_marker();
+      auto release_side = [&]() -> int {
+        if (!gated) {
+          fork();
+          CK(side_branch(i));
+          branch_done[i] = side_marker();
+        } else if (i == gate) {
+          fork();                              // the gate: the LDS-hungry attention kernels of this block are on their way
+          // gated branches first, then the block's conv weight gradient (512 threads, 80 KB of LDS: +1.9 % over putting it
+          // first, where it met the C = 64 attention)
+          for (int j = 3; j >= gate; --j) {
+            CK(side_branch(j));
+            branch_done[j] = side_marker();
+          }
+          if (!fuse_conv) {
+            CK(side_conv());
+            conv_done = side_marker();
+          }
+        } else if (i < gate) {
+          fork();
+          CK(side_branch(i));
+          branch_done[i] = side_marker();
         }
-        if (!fuse_conv) {
-          CK(side_conv());
-          conv_done = side_marker();
-        }
-      } else if (i < gate) {
-        fork();
-        CK(side_branch(i));
-        branch_done[i] = side_marker();
-      }
+        return 0;
+      };
+      if (!c16_prep) CK(release_side());
       if (fused_dgrad(i)) {
         // own-window products are in gd; add the ring rows of the (<= 3) neighbouring windows to the border pixels
         CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st, WSP("gdwin")));
+      } else if (c16_prep) {
+        CK(launch_c16_dgrad_prep(gqkv, win, packed_ptr(p, workspace, k + "w1T"), gxc, gn, B, H, W, st));
+        CK(release_side());
       } else {
         m2t_gemm_args ga{};
         ga.A = gqkv; ga.lda = 3 * C; ga.W = packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "T");
@@ -904,8 +915,8 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (k == "fused_tail_bwd") { p->use_fused_tail_bwd = (value != 0); return 0; }
   if (k == "fused_tail_fwd") { p->use_fused_tail_fwd = (value != 0); p->have_acts = false; return 0; }
   if (k == "attn_bwd") {
-    if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "attn_bwd: 0..2");
-    p->use_resident_attn_bwd = value >= 1; p->use_fused_qkv_dgrad = value == 2; return 0;
+    if (value < 0 || value > 3) return m2t_set_error(M2T_ERR_ARG, "attn_bwd: 0..3");
+    p->use_resident_attn_bwd = value >= 1; p->use_fused_qkv_dgrad = value >= 2; p->use_c16_prep = value == 3; return 0;
   }
   if (k == "conv_rows") { p->use_conv_rows = (int)value; return 0; }
   if (k == "fused_conv_bwd") { p->use_fused_conv_bwd = (value != 0); return 0; }

@@ -192,6 +192,8 @@ int launch_window_attn_fwd_c16(const void* qkv, const float* rel_h, const float*
 int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
                                void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st, const void* d = nullptr,
                                const void* wqkv = nullptr);
+// bf16 C = 16 branch: halo gather + projection data gradient + branch_prep_bwd (k = 0) in one kernel (k_attn_c16.hip)
+int launch_c16_dgrad_prep(void* gqkv, const void* win, const void* wT, const void* gxc, void* gn, int B, int h, int w, hipStream_t st);
 int launch_window_attn_fwd_resident(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0,
                                     const void* res, int ldr, int B, int h, int w, int C, int post_levels, hipStream_t st);
 // the resident kernel alone (bf16); M2T_UNSUPPORTED when (C, dwt_levels) has no instantiation

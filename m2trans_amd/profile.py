@@ -75,7 +75,8 @@ def read_all():
 
 def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8, fused_attn_fwd: bool | None = None,
                      fused_tail_fwd: bool = False, fused_qkv_dgrad: bool | None = None, fused_c16_fwd: bool | None = None,
-                     c16_recompute: bool | None = None, c64_recompute: bool | None = None, fused_conv_bwd: bool | None = None):
+                     c16_recompute: bool | None = None, c64_recompute: bool | None = None, fused_conv_bwd: bool | None = None,
+                     c16_prep: bool | None = None):
     """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr.
     fused_attn_fwd (default: bf16 mode): the C = 64 / 256 branches run qkv projection + attention as one kernel, so
     the forward `gemm_qkv` / `attn_fwd_*` categories are then empty (the C = 16 branch runs InstanceNorm apply +
@@ -90,6 +91,8 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         c16_recompute = dtype == "bf16"
     if c64_recompute is None:             # plan option "fused_attn_fwd" = 2 (default in bf16 mode): qkv2 is not stored
         c64_recompute = dtype == "bf16"
+    if c16_prep is None:                  # plan option "attn_bwd" = 3 (default in bf16 mode): no data-gradient GEMM for the C = 16 branch either
+        c16_prep = dtype == "bf16" and bool(fused_qkv_dgrad)
     if fused_conv_bwd is None:            # plan option "fused_conv_bwd" (default on in bf16 mode)
         fused_conv_bwd = dtype == "bf16"
     es = 2 if dtype == "bf16" else 4
@@ -120,7 +123,7 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         else:
             add(f"attn_fwd_c{C_}", nb * win * 25600.0 * C_, nb * M * (4 * C_ + (C_ if C_ == 16 else 0)) * es, nb)
             add("gemm_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
-        if not dg:
+        if not dg and not (c16_prep and C_ == 16):
             add("gemm_qkv_dgrad", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
         add("wgrad_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
     conv_fl = 2.0 * B * P * 64 * 576
@@ -169,7 +172,8 @@ def plan_options(plan) -> dict:
     o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_tail_fwd", "fused_c16_fwd", "conv_rows", "fused_conv_bwd")}
     o["c16_recompute"] = plan.query("opt:fused_c16_fwd") == 2
     o["c64_recompute"] = plan.query("opt:fused_attn_fwd") == 2
-    o["fused_qkv_dgrad"] = plan.query("opt:attn_bwd") == 2
+    o["fused_qkv_dgrad"] = plan.query("opt:attn_bwd") >= 2
+    o["c16_prep"] = plan.query("opt:attn_bwd") == 3
     return o
 
 
@@ -184,7 +188,7 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
     work = algorithmic_work(B, lr, scale, dtype, fused_attn_fwd=opts.get("fused_attn_fwd"), fused_tail_fwd=bool(opts.get("fused_tail_fwd", False)),
                             fused_qkv_dgrad=opts.get("fused_qkv_dgrad"), fused_c16_fwd=opts.get("fused_c16_fwd"),
                             c16_recompute=opts.get("c16_recompute"), c64_recompute=opts.get("c64_recompute"),
-                            fused_conv_bwd=opts.get("fused_conv_bwd"))
+                            fused_conv_bwd=opts.get("fused_conv_bwd"), c16_prep=opts.get("c16_prep"))
     traffic = {}
     if pmc_file and os.path.exists(pmc_file):
         try:

@@ -175,7 +175,7 @@ def test_bf16_fast_kernels_match_plain_kernels():
     for fast in (1, 0):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
-        for key, val in ((b"attn_bwd", 2 if fast else 0), (b"gate_branch", 2 if fast else -1), (b"fused_conv_bwd", fast), (b"side_stream", fast), (b"fused_tail_bwd", fast)):
+        for key, val in ((b"attn_bwd", 3 if fast else 0), (b"gate_branch", 2 if fast else -1), (b"fused_conv_bwd", fast), (b"side_stream", fast), (b"fused_tail_bwd", fast)):
             _lib.check(_lib.load().m2t_set_option(plan.handle, key, val), "m2t_set_option")
         sr = model(x)
         torch.nn.L1Loss()(sr, hr).backward()
@@ -522,6 +522,29 @@ def test_fused_projection_data_gradient_matches_the_gemm_path():
         a, b = ga[o:o + k].double(), gb[o:o + k].double()
         d = float((a - b).norm())
         assert d <= 2e-2 * float(b.norm()) or d <= 1e-5 * total, (n, d / max(float(b.norm()), 1e-30), d / total)
+
+
+def test_c16_gather_projection_prep_kernel_is_bit_identical_to_the_three_kernels():
+    """bf16, C = 16 branch: halo overlap-add + projection data gradient + branch_prep_bwd in one kernel (c16_dgrad_prep_kernel,
+    "attn_bwd" = 3, default) against halo_gather + gemm_nt + branch_prep_bwd ("attn_bwd" = 2): same fp32 adds in the same order,
+    the same two 32-deep MFMAs per 16 pixels, the same rounding points -- every gradient of the step identical, at sizes with
+    image-border, edge and interior windows (60 x 90 reflect-padded to 64 x 96) and at 128 x 128."""
+    from m2trans_amd import _lib
+    for (B, H, W) in ((2, 60, 90), (4, 128, 128)):
+        scale, nb = 4, 2
+        x = O.closed_form_image(B, 3, H, W).cuda()
+        hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+        outs = []
+        for level in (3, 2):
+            model, _ = build_model(scale, nb, "bf16")
+            plan = model._plan_for(x)
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"attn_bwd", level), "m2t_set_option")
+            assert plan.query("opt:attn_bwd") == level
+            sr = model(x)
+            torch.nn.L1Loss()(sr, hr).backward()
+            outs.append({n: q.grad.clone() for n, q in model.named_parameters() if q.requires_grad})
+        for n in outs[0]:
+            assert torch.equal(outs[0][n], outs[1][n]), (B, H, W, n)
 
 
 def test_row_streaming_conv3x3_is_bit_identical_to_the_tile_kernel():
