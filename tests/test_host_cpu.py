@@ -359,7 +359,8 @@ def test_roofline_work_table_matches_the_profiler_categories():
     10.6 GFLOP and 67 MB per launch at batch 16)."""
     from m2trans_amd import profile as P
     wd = P.algorithmic_work(16, 128, 4, "bf16")                     # defaults: the C = 16 / 64 backward recompute q | k | v
-    w = P.algorithmic_work(16, 128, 4, "bf16", c16_recompute=False, c64_recompute=False)
+    w = P.algorithmic_work(16, 128, 4, "bf16", c16_recompute=False, c64_recompute=False, c16_prep=False)
+    assert "gemm_qkv_dgrad" in w and "gemm_qkv_dgrad" not in wd      # "attn_bwd" = 3: the C = 16 projection gradient left the GEMM too
     assert set(w) <= set(P.CATS) and set(wd) <= set(P.CATS), set(w) - set(P.CATS)
     M16, M64 = 16 * 128 * 128, 16 * 64 * 64
     for cat, M, C in (("attn_bwd_c16", M16, 16), ("attn_bwd_c64", M64, 64)):
