@@ -259,6 +259,7 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         ts.step(*batches[s % 2], captions)
+    host_enqueue_s = time.perf_counter() - t0     # the host's share: how long the launches took to queue (no sync inside)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -310,7 +311,8 @@ def main():
                        "world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                        "grad_exchange": ("none" if ts.bucket is None else
                                          ("bucketed all-reduce overlapped with backward" if ts.overlap_comm else "one all-reduce after backward")),
-                       "final_loss": round(loss, 6)},
+                       "final_loss": round(loss, 6),
+                       "host_enqueue_ms_per_step": round(1000.0 * host_enqueue_s / args.steps, 3)},
             "roofline": roofline,
         }
         if experiment:

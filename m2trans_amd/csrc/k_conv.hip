@@ -416,12 +416,14 @@ __device__ __forceinline__ void c3r_dma16(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int NRES, int D, int DR, bool PIPE>   // residual tensors (0: data gradient, 1: forward, 2: last block); DMA depth of the input rows /
-                                                 // residual rows, in steps; PIPE: epilogue of step s - 1 under the products of step s
+template <int NRES, int D, int DR, bool PIPE, bool ST>   // residual tensors (0: data gradient, 1: forward, 2: last block); DMA depth of the input
+                                                 // rows / residual rows, in steps; PIPE: epilogue of step s - 1 under the products of step s;
+                                                 // ST: InstanceNorm statistics of the output (the next block's input) as per-segment partials
 __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp,
                                                                   const float* __restrict__ bias, const bf16_t* __restrict__ res1,
                                                                   const bf16_t* __restrict__ res2, bf16_t* __restrict__ y,
-                                                                  const bf16_t* __restrict__ zero_page, int B, int H, int W, int RS) {
+                                                                  const bf16_t* __restrict__ zero_page, int B, int H, int W, int RS,
+                                                                  float* __restrict__ stat_part) {
   using T = bf16_t;
   static_assert(DR >= 1 && DR <= D, "the residual rows are issued no earlier than the input rows they go with");
   constexpr int NR = 2 * D + 4;                       // ring rows: a pair in flight never overwrites a row a slower wave still reads
@@ -574,6 +576,12 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* 
       }
     }
   };
+  // ST: this lane's 8 channels over its 2 x nsteps pixels, as sums of (v - K) and (v - K)^2 of the STORED (rounded) values around the
+  // lane's first value K -- what instnorm_stats1_kernel would read back from HBM, without the cancellation of plain sums of squares
+  float stk[8], st1[8], st2[8];
+  bool st_first = true;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { stk[e] = 0.f; st1[e] = 0.f; st2[e] = 0.f; }
   // epilogue of one 16-pixel tile: + bias + res1 + res2 (this order), one rounding, one 16-byte store
   auto epi_mt = [&](int mt, const f32x4 (&acc)[2][2], const Frag8<T> (&rv)[NRR][2], int orow) {
     float v[8];
@@ -595,7 +603,21 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* 
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += rv[1][mt].get(e);
     }
-    store8f(y + obase + ((long long)orow * W + x0 + 16 * mt + lr) * 16, v);
+    if constexpr (ST) {
+      Frag8<T> f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f.set(e, v[e]);
+      store8(y + obase + ((long long)orow * W + x0 + 16 * mt + lr) * 16, f);
+      if (st_first) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) stk[e] = f.get(e);
+        st_first = false;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float dv = f.get(e) - stk[e]; st1[e] += dv; st2[e] = fmaf(dv, dv, st2[e]); }
+    } else {
+      store8f(y + obase + ((long long)orow * W + x0 + 16 * mt + lr) * 16, v);
+    }
   };
 
   if constexpr (!PIPE) {
@@ -657,6 +679,52 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* 
     epi_mt(1, pacc, prv, y0 + 2 * (nsteps - 1) + rrw);
   }
   // (the dummy pairs / residual rows still in flight target LDS only; the wave ends when its counter drains)
+  if constexpr (ST) {
+    // lane -> (n, mean, M2) of its 2 nsteps values; the 16 pixel lanes of a channel group (same g) merge by xor butterflies, the two
+    // waves that share a channel half (the two rows of a step) through LDS: equal counts everywhere, so mean = the average of the
+    // means and M2 = sum (M2_i + n_i (mean_i - mean)^2), every sum in a fixed order.  part [image][segment][64][3] = (n, mean, M2).
+    float* st_lds = bias_s + 64;                      // [2 halves][4 g][8 ch][2]
+    const float nl = (float)(2 * nsteps), inl = 1.0f / nl;
+    float mean_l[8], m2_l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float dm = st1[e] * inl;
+      mean_l[e] = stk[e] + dm;
+      m2_l[e] = fmaxf(st2[e] - st1[e] * dm, 0.f);
+    }
+    float mean_w[8], m2_w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float sm = mean_l[e];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
+      mean_w[e] = sm * (1.0f / 16.0f);
+      const float dd = mean_l[e] - mean_w[e];
+      float q = fmaf(nl * dd, dd, m2_l[e]);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
+      m2_w[e] = q;
+    }
+    const int half_w = wv & 1;
+    if (rrw == 1 && lr == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { st_lds[((half_w * 4 + g) * 8 + e) * 2] = mean_w[e]; st_lds[((half_w * 4 + g) * 8 + e) * 2 + 1] = m2_w[e]; }
+    }
+    lds_barrier();
+    if (rrw == 0 && lr == 0) {
+      const float nw = 16.0f * nl;
+      float* o = stat_part + (((long long)b * (nseg * nsx) + sx * nseg + seg) * 64 + 32 * half_w + 8 * g) * 3;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float mo = st_lds[((half_w * 4 + g) * 8 + e) * 2], qo = st_lds[((half_w * 4 + g) * 8 + e) * 2 + 1];
+        const float mean = 0.5f * (mean_w[e] + mo);
+        const float da = mean_w[e] - mean, db = mo - mean;
+        o[3 * e] = 2.0f * nw;
+        o[3 * e + 1] = mean;
+        o[3 * e + 2] = (m2_w[e] + nw * da * da) + (qo + nw * db * db);
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -967,19 +1035,37 @@ static int c3r_rows_per_segment(int B, int H, int W) {
 }
 template <int NRES, int D, int DR, bool PIPE = false>
 static int go_c3r(const void* x, const void* wp /* M2T_PACK_CONV3_ROWS(_T) */, const float* bias, const void* res1, const void* res2, void* y, const void* zero_page,
-                  int B, int H, int W, int rs, hipStream_t st) {
+                  int B, int H, int W, int rs, hipStream_t st, float* stat_part = nullptr) {
   constexpr int NR = 2 * D + 4;
-  const size_t sh = (size_t)NR * C3R_ROWB + (size_t)NRES * (DR + 1) * C3R_RESB + 64 * sizeof(float);
-  if (int rc__ = m2t_ensure_dynamic_lds((const void*)conv3x3_c64_rows_kernel<NRES, D, DR, PIPE>, (int)sh)) return rc__;
+  const size_t sh = (size_t)NR * C3R_ROWB + (size_t)NRES * (DR + 1) * C3R_RESB + (64 + 128) * sizeof(float);
   const int nblk = B * (W / C3R_SW) * (H / rs);
-  M2T_LAUNCH_TIMED((conv3x3_c64_rows_kernel<NRES, D, DR, PIPE>), dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
-                   (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, (const bf16_t*)zero_page, B, H, W, rs);
+  if constexpr (NRES == 1) {
+    if (stat_part) {
+      if (int rc__ = m2t_ensure_dynamic_lds((const void*)conv3x3_c64_rows_kernel<NRES, D, DR, PIPE, true>, (int)sh)) return rc__;
+      M2T_LAUNCH_TIMED((conv3x3_c64_rows_kernel<NRES, D, DR, PIPE, true>), dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
+                       (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, (const bf16_t*)zero_page, B, H, W, rs, stat_part);
+      return 0;
+    }
+  }
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)conv3x3_c64_rows_kernel<NRES, D, DR, PIPE, false>, (int)sh)) return rc__;
+  M2T_LAUNCH_TIMED((conv3x3_c64_rows_kernel<NRES, D, DR, PIPE, false>), dim3(nblk), dim3(256), sh, st, (const bf16_t*)x, (const bf16_t*)wp, bias,
+                   (const bf16_t*)res1, (const bf16_t*)res2, (bf16_t*)y, (const bf16_t*)zero_page, B, H, W, rs, (float*)nullptr);
   return 0;
 }
 
+// the rows kernel can leave the InstanceNorm statistics of y as <= M2T_NORM_SPLIT per-image partials: number of partials, 0 = not available
+int conv3x3_c64_stat_partials(int dt, int B, int H, int W, int variant) {
+  if (dt == M2T_F32 || variant == 1 || W % C3R_SW || (long long)B * H * W * 64 >= (1LL << 31)) return 0;
+  const int rs = c3r_rows_per_segment(B, H, W);
+  if (rs <= 0) return 0;
+  const int n = (W / C3R_SW) * (H / rs);
+  return n <= M2T_NORM_SPLIT ? n : 0;
+}
 int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias, const void* res1, const void* res2,
-                       void* y, int B, int H, int W, hipStream_t st, const void* wrows, const void* zero_page, int variant) {
+                       void* y, int B, int H, int W, hipStream_t st, const void* wrows, const void* zero_page, int variant, float* stat_part) {
   if (H % C3_TH || W % C3_TW) return m2t_set_error(-2, "conv3x3_c64: H%8 or W%16");
+  if (stat_part && !(res1 && !res2 && conv3x3_c64_stat_partials(dt, B, H, W, variant) > 0))
+    return m2t_set_error(-2, "conv3x3_c64: statistics partials need the one-residual row-streaming kernel (conv3x3_c64_stat_partials)");
   const long long ntiles = (long long)B * (H / C3_TH) * (W / C3_TW);
   if (res2 && !res1) return m2t_set_error(-2, "conv3x3_c64: res2 without res1");
   if (dt != M2T_F32 && wrows && zero_page && variant != 1 && W % C3R_SW == 0 && (long long)B * H * W * 64 < (1LL << 31)) {
@@ -992,15 +1078,15 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
       // step s (variants 3 / 4, kept for A/B); inside the two-stream step all of them tie
       if (variant == 3) {
         if (res2) rc = go_c3r<2, 3, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
-        else if (res1) rc = go_c3r<1, 3, 3>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+        else if (res1) rc = go_c3r<1, 3, 3>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st, stat_part);
         else rc = go_c3r<0, 3, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
       } else if (variant == 4) {
         if (res2) rc = go_c3r<2, 2, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
-        else if (res1) rc = go_c3r<1, 2, 2, true>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+        else if (res1) rc = go_c3r<1, 2, 2, true>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st, stat_part);
         else rc = go_c3r<0, 2, 1, true>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
       } else {
         if (res2) rc = go_c3r<2, 2, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
-        else if (res1) rc = go_c3r<1, 2, 2>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+        else if (res1) rc = go_c3r<1, 2, 2>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st, stat_part);
         else rc = go_c3r<0, 2, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
       }
       if (rc) return rc;

@@ -290,6 +290,15 @@ int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float
   return 0;
 }
 
+// the second stage alone: `part` [B][nsplit][64][3] = (n, mean, M2) partials written by another kernel (the row-streaming conv
+// leaves the statistics of its output this way, k_conv.hip)
+int launch_instnorm_finalize(const float* part, float* mean, float* rstd, int B, int nsplit, hipStream_t st) {
+  if (nsplit < 1 || nsplit > M2T_NORM_SPLIT) return m2t_set_error(-2, "instnorm_finalize: 1 .. 32 partials per image");
+  hipLaunchKernelGGL(instnorm_stats2_kernel, dim3(B), dim3(64), 0, st, part, mean, rstd, nsplit, 1e-5f);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
 // =======================================================================================
 // branch_prep<L>: the input side of CFTM branch k (k = chunk index 0..3, L = DWT levels)
 //   xin = norm(x)[chunk k]                      (k = 0)         (:135-139)

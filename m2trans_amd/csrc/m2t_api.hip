@@ -430,6 +430,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
   CK(launch_pack(dt, params, WSP("packed"), (const m2t_pack_desc*)WSP("pack_descs"), WSP("pack_blocks"), (int)(p->pack_blocks.size() / 2), st));
   CK(launch_head_conv_fwd(dt, x, params + p->poff.at("head.weight"), params + p->poff.at("head.bias"), WSP("X0"), B,
                           p->H0, p->W0, H, W, st));
+  int stat_partials = 0;
   for (int b = 0; b < p->nb; ++b) {
     const std::string k = "b" + std::to_string(b) + ".";
     const std::string pre = "body." + std::to_string(b) + ".";
@@ -437,7 +438,9 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     float* mean = (float*)WSP(k + "mean");
     float* rstd = (float*)WSP(k + "rstd");
     void* xc = WSP(k + "xc");
-    CK(launch_instnorm_stats(dt, X, mean, rstd, (float*)WSP("norm_part"), B, (int)p->P, st));
+    // statistics of the block input: left as per-segment partials by the previous block's conv (bf16, row-streaming), else two stages
+    if (stat_partials > 0) CK(launch_instnorm_finalize((const float*)WSP("norm_part"), mean, rstd, B, stat_partials, st));
+    else CK(launch_instnorm_stats(dt, X, mean, rstd, (float*)WSP("norm_part"), B, (int)p->P, st));
     for (int i = 0; i < 4; ++i) {
       const int C = BR_C[i], L = BR_L[i];
       const int h = H >> L, w = W >> L;
@@ -478,9 +481,11 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     }
     // x = feed_forward(xc) + x (:164); the last block also folds in `res + x` (:70)
     { M2TProfScope ps(M2T_PROF_CONV3_FWD, st);
+      const int variant = p->use_conv_rows >= 2 ? p->use_conv_rows : (p->use_conv_rows ? 0 : 1);
+      stat_partials = (b < p->nb - 1) ? conv3x3_c64_stat_partials(dt, B, H, W, variant) : 0;
       CK(launch_conv3x3_c64(dt, xc, packed_ptr(p, workspace, k + "wf"), params + p->poff.at(pre + "feed_forward.0.bias"), X,
                             (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st,
-                            packed_ptr(p, workspace, k + "wfR"), WSP("zero_page"), p->use_conv_rows >= 2 ? p->use_conv_rows : (p->use_conv_rows ? 0 : 1))); }
+                            packed_ptr(p, workspace, k + "wfR"), WSP("zero_page"), variant, stat_partials > 0 ? (float*)WSP("norm_part") : nullptr)); }
   }
   void* Y = WSP("X" + std::to_string(p->nb));
   const int r0 = (s == 4) ? 2 : s;

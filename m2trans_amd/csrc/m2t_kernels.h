@@ -66,6 +66,7 @@ struct M2TProfScope {
 int launch_dwt(int dt, int L, const void* src, int lds_, int c0, void* dst, int ldd, int d0, int B, int H, int W,
                int C, bool inverse, hipStream_t st);
 int launch_pixel_shuffle_nchw(const float* in, float* out, int B, int C, int H, int W, int r, int inverse, hipStream_t st);
+int launch_instnorm_finalize(const float* part, float* mean, float* rstd, int B, int nsplit, hipStream_t st);
 int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float* part, int B, int P, hipStream_t st);
 int launch_branch_prep(int dt, int L, const void* x, const float* mean, const float* rstd, const void* xc, int k,
                        void* xin, void* d, int B, int H, int W, hipStream_t st);
@@ -136,8 +137,11 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
                        void* y, int B, int H, int W, hipStream_t st,
                        const void* wrows = nullptr,       // bf16: the same weight in M2T_PACK_CONV3_ROWS(_T) order and ...
                        const void* zero_page = nullptr,   // ... >= 64 zero bytes in device memory -> the row-streaming kernel
-                       int variant = 0);                  // 0: row-streaming, DMA depth 2 (default); 1: the tile kernel
+                       int variant = 0,                   // 0: row-streaming, DMA depth 2 (default); 1: the tile kernel
                                                           // (conv3x3_c64_pipe_kernel); 3: depth 3; 4: depth 2 + pipelined epilogue
+                       float* stat_part = nullptr);       // one residual, row-streaming: InstanceNorm partials of y, [B][n][64][3] with
+                                                          // n = conv3x3_c64_stat_partials(...) (0: this shape / variant cannot)
+int conv3x3_c64_stat_partials(int dt, int B, int H, int W, int variant);
 int launch_conv3x3_c64_wgrad(int dt, const void* x, const void* gy, float* slabs, float* bias_slabs, int* nslab, int B, int H,
                              int W, hipStream_t st);   // bias_slabs [nslab][64]: column sums of gy
 // bf16: data gradient + weight / bias gradient partials in one pass over gy (conv3x3_c64_bwd_rows_kernel); M2T_UNSUPPORTED for

@@ -549,17 +549,21 @@ def test_c16_gather_projection_prep_kernel_is_bit_identical_to_the_three_kernels
 
 def test_row_streaming_conv3x3_is_bit_identical_to_the_tile_kernel():
     """bf16 3x3 conv 64 -> 64: the row-streaming kernel (LDS-DMA rings for the input and residual rows, weights in registers,
-    option conv_rows, default) keeps the products and their order of the tile kernel, so the whole step -- eight forward
-    convs, eight data gradients -- must agree bit for bit.  Sizes: 128x128 batch 8 (256 segments of 32 rows), 96x160 batch 3
-    (segments of 32 rows, 5 strips, first / last strip at the image border) and 60x90 reflect-padded to 64x96 batch 2
-    (segments of 16 rows)."""
+    option conv_rows, default) keeps the products and their order of the tile kernel: with the same InstanceNorm statistics the
+    whole step -- eight forward convs, eight data gradients -- agrees bit for bit between its three variants (DMA depth 2, depth 3,
+    depth 2 + pipelined epilogue), which also leave the statistics of their output as per-segment partials in the same order.
+    The tile kernel's path takes the statistics with the two-stage kernel instead (another summation order: mean / rstd differ in the
+    last bits), so against it the FIRST conv output, whose input statistics are common, must be identical and the step agree to
+    bf16 noise.  Sizes: 128x128 batch 8 (256 segments of 32 rows), 96x160 batch 3 (5 strips, first / last at the image border) and
+    60x90 reflect-padded to 64x96 batch 2 (segments of 16 rows)."""
     from m2trans_amd import _lib
+    from tests.gpu_util import ws_nchw
     for (B, H, W) in ((8, 128, 128), (3, 96, 160), (2, 60, 90)):
         scale, nb = 4, 2
         x = O.closed_form_image(B, 3, H, W).cuda()
         hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
         outs = []
-        for rows in (1, 0, 3, 4):          # default (DMA depth 2), tile kernel, depth 3, depth 2 + pipelined epilogue
+        for rows in (1, 3, 4, 0):          # default (DMA depth 2), depth 3, depth 2 + pipelined epilogue, tile kernel
             model, _ = build_model(scale, nb, "bf16")
             plan = model._plan_for(x)
             _lib.check(_lib.load().m2t_set_option(plan.handle, b"conv_rows", rows), "m2t_set_option")
@@ -567,10 +571,42 @@ def test_row_streaming_conv3x3_is_bit_identical_to_the_tile_kernel():
             assert plan.query("opt:conv_rows") == rows and plan.query("opt:fused_conv_bwd") == 0
             sr = model(x)
             torch.nn.L1Loss()(sr, hr).backward()
-            outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone()))
-        for o in outs[1:]:
+            torch.cuda.synchronize()
+            Hp, Wp = plan.query("padded_h"), plan.query("padded_w")
+            outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone(),
+                         ws_nchw(plan, "X1", B, Hp, Wp, 64)))
+        for o in outs[1:3]:
             assert torch.equal(outs[0][0], o[0]), (B, H, W)
             assert torch.equal(outs[0][1], o[1]), (B, H, W)
+        tile = outs[3]
+        assert torch.equal(outs[0][2], tile[2]), (B, H, W)                      # first block: same statistics, same bits
+        assert rms_rel(outs[0][0], tile[0]) < 5e-2, (B, H, W, rms_rel(outs[0][0], tile[0]))     # (as the other fused-vs-plain A/Bs: closed-form weights amplify last-bit flips)
+        gd = float((outs[0][1].double() - tile[1].double()).norm()) / float(tile[1].double().norm())
+        assert gd < 5e-2, (B, H, W, gd)
+
+
+def test_conv_epilogue_statistics_match_the_two_stage_kernel():
+    """The InstanceNorm statistics a block takes from the previous block's conv epilogue (per-segment (n, mean, M2) partials of the
+    stored bf16 values, merged by the same second stage) against mean / rstd recomputed in fp64 from the stored block input: the
+    same quantity the two-stage kernel measures, within fp32 rounding (1e-5 relative on rstd, 1e-6 of the value scale on mean)."""
+    from tests.gpu_util import ws_nchw
+    for (B, H, W) in ((4, 128, 128), (2, 60, 90)):
+        scale, nb = 4, 3
+        x = O.closed_form_image(B, 3, H, W).cuda()
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(x)
+        with torch.no_grad():
+            model(x)
+        torch.cuda.synchronize()
+        Hp, Wp = plan.query("padded_h"), plan.query("padded_w")
+        for b in (1, 2):
+            X = ws_nchw(plan, f"X{b}", B, Hp, Wp, 64).double()
+            mean = X.mean(dim=(2, 3))
+            rstd = 1.0 / torch.sqrt(X.var(dim=(2, 3), unbiased=False) + 1e-5)
+            got_m = plan.ws_tensor(f"b{b}.mean", dtype=torch.float32).reshape(B, 64).double().cpu()
+            got_r = plan.ws_tensor(f"b{b}.rstd", dtype=torch.float32).reshape(B, 64).double().cpu()
+            assert float((got_m - mean).abs().max()) <= 1e-6 * float(X.abs().max()) + 1e-7, (B, H, W, b)
+            assert float(((got_r - rstd) / rstd).abs().max()) <= 1e-5, (B, H, W, b, float(((got_r - rstd) / rstd).abs().max()))
 
 
 def test_fused_conv_backward_matches_the_two_kernel_path():
