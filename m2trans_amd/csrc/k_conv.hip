@@ -578,10 +578,52 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* 
   };
   // ST: this lane's 8 channels over its 2 x nsteps pixels, as sums of (v - K) and (v - K)^2 of the STORED (rounded) values around the
   // lane's first value K -- what instnorm_stats1_kernel would read back from HBM, without the cancellation of plain sums of squares
+  // Every 16 output rows (8 steps) a wave leaves one partial (n, mean, M2) per channel for its 8 rows x 32 pixels: the partials and
+  // their order do not depend on the segment length, hence not on the batch size (bitwise batch invariance of the step).
   float stk[8], st1[8], st2[8];
   bool st_first = true;
 #pragma unroll
   for (int e = 0; e < 8; ++e) { stk[e] = 0.f; st1[e] = 0.f; st2[e] = 0.f; }
+  auto stat_flush = [&](int sub) {                    // sub: index of the 16-row group inside the segment
+    if constexpr (ST) {
+      // lane -> (n, mean, M2) of its 16 values; the 16 pixel lanes of a channel group (same g) merge by xor butterflies: equal
+      // counts, so mean = the average of the means and M2 = sum (M2_i + n_i (mean_i - mean)^2), every sum in a fixed order
+      const float nl = 16.0f, inl = 1.0f / 16.0f;
+      float mean_w[8], m2_w[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dm = st1[e] * inl;
+        const float mean_l = stk[e] + dm;
+        const float m2_l = fmaxf(st2[e] - st1[e] * dm, 0.f);
+        float sm = mean_l;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
+        mean_w[e] = sm * (1.0f / 16.0f);
+        const float dd = mean_l - mean_w[e];
+        float q = fmaf(nl * dd, dd, m2_l);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
+        m2_w[e] = q;
+      }
+      if (lr == 0) {
+        // part [image][strip][16-row group][row parity][64][3]: this lane's 8 channels = 24 consecutive floats, six 16-byte stores
+        const int idx = ((sx * (H / 16) + y0 / 16 + sub) * 2 + rrw);
+        float* o = stat_part + (((long long)b * (nsx * (H / 16) * 2) + idx) * 64 + 32 * (wv & 1) + 8 * g) * 3;
+        float t[24];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { t[3 * e] = 256.0f; t[3 * e + 1] = mean_w[e]; t[3 * e + 2] = m2_w[e]; }
+#pragma unroll
+        for (int v4 = 0; v4 < 6; ++v4) {
+          const float q4[4] = {t[4 * v4], t[4 * v4 + 1], t[4 * v4 + 2], t[4 * v4 + 3]};
+          store4(o + 4 * v4, q4);
+        }
+      }
+      issued += 6;                                    // (exec-masked stores still count)
+      st_first = true;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { st1[e] = 0.f; st2[e] = 0.f; }
+    }
+  };
   // epilogue of one 16-pixel tile: + bias + res1 + res2 (this order), one rounding, one 16-byte store
   auto epi_mt = [&](int mt, const f32x4 (&acc)[2][2], const Frag8<T> (&rv)[NRR][2], int orow) {
     float v[8];
@@ -640,6 +682,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* 
       epi_mt(0, acc, rv, y0 + 2 * s + rrw);
       epi_mt(1, acc, rv, y0 + 2 * s + rrw);
       issued += 2;
+      if ((s & 7) == 7) stat_flush(s >> 3);
       C3R_STAMP(4 + 3 * s);
     }
   } else {
@@ -667,6 +710,7 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* 
         if (s > 0 && tap == 4) epi_mt(1, pacc, prv, porow);
       }
       if (s > 0) issued += 2;
+      if (s > 0 && ((s - 1) & 7) == 7) stat_flush((s - 1) >> 3);
       C3R_STAMP(3 + 3 * s);
       read_res(s, prv);
 #pragma unroll
@@ -677,54 +721,9 @@ __global__ void __launch_bounds__(256, 2) conv3x3_c64_rows_kernel(const bf16_t* 
     }
     epi_mt(0, pacc, prv, y0 + 2 * (nsteps - 1) + rrw);
     epi_mt(1, pacc, prv, y0 + 2 * (nsteps - 1) + rrw);
+    stat_flush((nsteps - 1) >> 3);
   }
   // (the dummy pairs / residual rows still in flight target LDS only; the wave ends when its counter drains)
-  if constexpr (ST) {
-    // lane -> (n, mean, M2) of its 2 nsteps values; the 16 pixel lanes of a channel group (same g) merge by xor butterflies, the two
-    // waves that share a channel half (the two rows of a step) through LDS: equal counts everywhere, so mean = the average of the
-    // means and M2 = sum (M2_i + n_i (mean_i - mean)^2), every sum in a fixed order.  part [image][segment][64][3] = (n, mean, M2).
-    float* st_lds = bias_s + 64;                      // [2 halves][4 g][8 ch][2]
-    const float nl = (float)(2 * nsteps), inl = 1.0f / nl;
-    float mean_l[8], m2_l[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float dm = st1[e] * inl;
-      mean_l[e] = stk[e] + dm;
-      m2_l[e] = fmaxf(st2[e] - st1[e] * dm, 0.f);
-    }
-    float mean_w[8], m2_w[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float sm = mean_l[e];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
-      mean_w[e] = sm * (1.0f / 16.0f);
-      const float dd = mean_l[e] - mean_w[e];
-      float q = fmaf(nl * dd, dd, m2_l[e]);
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o);
-      m2_w[e] = q;
-    }
-    const int half_w = wv & 1;
-    if (rrw == 1 && lr == 0) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { st_lds[((half_w * 4 + g) * 8 + e) * 2] = mean_w[e]; st_lds[((half_w * 4 + g) * 8 + e) * 2 + 1] = m2_w[e]; }
-    }
-    lds_barrier();
-    if (rrw == 0 && lr == 0) {
-      const float nw = 16.0f * nl;
-      float* o = stat_part + (((long long)b * (nseg * nsx) + sx * nseg + seg) * 64 + 32 * half_w + 8 * g) * 3;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float mo = st_lds[((half_w * 4 + g) * 8 + e) * 2], qo = st_lds[((half_w * 4 + g) * 8 + e) * 2 + 1];
-        const float mean = 0.5f * (mean_w[e] + mo);
-        const float da = mean_w[e] - mean, db = mo - mean;
-        o[3 * e] = 2.0f * nw;
-        o[3 * e + 1] = mean;
-        o[3 * e + 2] = (m2_w[e] + nw * da * da) + (qo + nw * db * db);
-      }
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1037,7 +1036,7 @@ template <int NRES, int D, int DR, bool PIPE = false>
 static int go_c3r(const void* x, const void* wp /* M2T_PACK_CONV3_ROWS(_T) */, const float* bias, const void* res1, const void* res2, void* y, const void* zero_page,
                   int B, int H, int W, int rs, hipStream_t st, float* stat_part = nullptr) {
   constexpr int NR = 2 * D + 4;
-  const size_t sh = (size_t)NR * C3R_ROWB + (size_t)NRES * (DR + 1) * C3R_RESB + (64 + 128) * sizeof(float);
+  const size_t sh = (size_t)NR * C3R_ROWB + (size_t)NRES * (DR + 1) * C3R_RESB + 64 * sizeof(float);
   const int nblk = B * (W / C3R_SW) * (H / rs);
   if constexpr (NRES == 1) {
     if (stat_part) {
@@ -1053,13 +1052,12 @@ static int go_c3r(const void* x, const void* wp /* M2T_PACK_CONV3_ROWS(_T) */, c
   return 0;
 }
 
-// the rows kernel can leave the InstanceNorm statistics of y as <= M2T_NORM_SPLIT per-image partials: number of partials, 0 = not available
+// the rows kernel can leave the InstanceNorm statistics of y as <= 2 M2T_NORM_SPLIT per-image partials: number of partials, 0 = not available
 int conv3x3_c64_stat_partials(int dt, int B, int H, int W, int variant) {
   if (dt == M2T_F32 || variant == 1 || W % C3R_SW || (long long)B * H * W * 64 >= (1LL << 31)) return 0;
-  const int rs = c3r_rows_per_segment(B, H, W);
-  if (rs <= 0) return 0;
-  const int n = (W / C3R_SW) * (H / rs);
-  return n <= M2T_NORM_SPLIT ? n : 0;
+  if (c3r_rows_per_segment(B, H, W) <= 0) return 0;
+  const int n = (W / C3R_SW) * (H / 16) * 2;          // one per wave and 16 output rows: independent of the segment length
+  return n <= 2 * M2T_NORM_SPLIT ? n : 0;
 }
 int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias, const void* res1, const void* res2,
                        void* y, int B, int H, int W, hipStream_t st, const void* wrows, const void* zero_page, int variant, float* stat_part) {

@@ -253,6 +253,7 @@ __global__ void __launch_bounds__(256) instnorm_stats1_kernel(const T* __restric
     }
   }
 }
+template <bool PAIRS>     // PAIRS: up to 64 partials, neighbours merged first (the conv epilogue's per-wave partials)
 __global__ void __launch_bounds__(64) instnorm_stats2_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
                                        int nsplit, float eps) {
   // every partial is fetched before the first merge (independent loads in flight), then a fixed pairwise tree:
@@ -262,7 +263,18 @@ __global__ void __launch_bounds__(64) instnorm_stats2_kernel(const float* __rest
 #pragma unroll
   for (int s = 0; s < M2T_NORM_SPLIT; ++s) {
     w[s].n = 0.f; w[s].mean = 0.f; w[s].m2 = 0.f;
-    if (s < nsplit) {
+    if constexpr (PAIRS) {
+      Wf u; u.n = 0.f; u.mean = 0.f; u.m2 = 0.f;
+      if (2 * s < nsplit) {
+        const float* o = part + (((long long)b * nsplit + 2 * s) * 64 + ch) * 3;
+        w[s].n = o[0]; w[s].mean = o[1]; w[s].m2 = o[2];
+      }
+      if (2 * s + 1 < nsplit) {
+        const float* o = part + (((long long)b * nsplit + 2 * s + 1) * 64 + ch) * 3;
+        u.n = o[0]; u.mean = o[1]; u.m2 = o[2];
+      }
+      w[s] = wf_merge(w[s], u);
+    } else if (s < nsplit) {
       const float* o = part + (((long long)b * nsplit + s) * 64 + ch) * 3;
       w[s].n = o[0]; w[s].mean = o[1]; w[s].m2 = o[2];
     }
@@ -285,7 +297,7 @@ int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float
   if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_stats1_kernel<float>, dim3(nsplit, B), dim3(256), 0, st, (const float*)x, part, P, nsplit);
   else hipLaunchKernelGGL(instnorm_stats1_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, st, (const bf16_t*)x, part, P, nsplit);
   M2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL(instnorm_stats2_kernel, dim3(B), dim3(64), 0, st, part, mean, rstd, nsplit, 1e-5f);
+  hipLaunchKernelGGL(instnorm_stats2_kernel<false>, dim3(B), dim3(64), 0, st, part, mean, rstd, nsplit, 1e-5f);
   M2T_LAUNCH_CHECK();
   return 0;
 }
@@ -293,8 +305,8 @@ int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float
 // the second stage alone: `part` [B][nsplit][64][3] = (n, mean, M2) partials written by another kernel (the row-streaming conv
 // leaves the statistics of its output this way, k_conv.hip)
 int launch_instnorm_finalize(const float* part, float* mean, float* rstd, int B, int nsplit, hipStream_t st) {
-  if (nsplit < 1 || nsplit > M2T_NORM_SPLIT) return m2t_set_error(-2, "instnorm_finalize: 1 .. 32 partials per image");
-  hipLaunchKernelGGL(instnorm_stats2_kernel, dim3(B), dim3(64), 0, st, part, mean, rstd, nsplit, 1e-5f);
+  if (nsplit < 1 || nsplit > 2 * M2T_NORM_SPLIT) return m2t_set_error(-2, "instnorm_finalize: 1 .. 64 partials per image");
+  hipLaunchKernelGGL(instnorm_stats2_kernel<true>, dim3(B), dim3(64), 0, st, part, mean, rstd, nsplit, 1e-5f);
   M2T_LAUNCH_CHECK();
   return 0;
 }

@@ -134,8 +134,8 @@ struct m2t_plan {
   // ---- options (m2t_set_option; include/m2t.h documents each) ----
   bool use_side = true;
   bool debug_skip_side = false;        // timing experiments only: skip every parameter-gradient kernel (results are WRONG)
-  bool use_fused_tail_bwd = true;      // x4 bf16: k_tail_bwd.hip instead of four HR kernels
-  bool use_fused_tail_fwd = true;      // x4 bf16: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored
+  bool use_fused_tail_bwd = true;      // x4 bf16: k_tail_bwd.hip instead of four HR kernels                              } option "fused_tail":
+  bool use_fused_tail_fwd = true;      // x4 bf16: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored } 0 / 1 / 2
                                        // (with bf16 mode's exp2 / rcp GELU: 5.30 vs 5.34 ms per step and 1.6 GB less HBM traffic;
                                        // with the erf form of round 2 it was 1 % slower)
   int gate_branch = 2;                 // side-stream gate: -1 ungated, else the branch (3..0) behind whose attention launch a block's
@@ -292,7 +292,7 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   }
   p->add_ws("xin", BP * 16, es);
   p->add_ws("a", BP * 16, es);
-  p->add_ws("norm_part", (size_t)B * M2T_NORM_SPLIT * 64 * 3, 4);
+  p->add_ws("norm_part", (size_t)B * 2 * M2T_NORM_SPLIT * 64 * 3, 4);      // (the conv epilogue leaves up to 64 partials per image)
   p->add_ws("norm_s", (size_t)B * 64 * 2, 4);
   const int r0 = (s == 4) ? 2 : s;
   // tail activations: gelu(t) and gelu'(t) of each expansion (the pre-activation t itself is never needed again)
@@ -380,8 +380,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "side_stream") return p->use_side;
     if (o == "gate_branch") return p->gate_branch + 1000;      // (offset: -1 is the "unknown key" value of this function)
     if (o == "wgrad_big_tiles") return p->wgrad_big_tiles + 1000;
-    if (o == "fused_tail_bwd") return p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
-    if (o == "fused_tail_fwd") return p->use_fused_tail_fwd && p->use_fused_tail_bwd && p->scale == 4 && p->dt != M2T_F32;
+    if (o == "fused_tail") return (p->scale == 4 && p->dt != M2T_F32) ? (p->use_fused_tail_bwd ? (p->use_fused_tail_fwd ? 2 : 1) : 0) : 0;
     if (o == "attn_bwd") return p->dt == M2T_F32 ? 0 : (p->use_resident_attn_bwd ? (p->use_fused_qkv_dgrad ? (p->use_c16_prep ? 3 : 2) : 1) : 0);
     if (o == "conv_rows") return p->dt != M2T_F32 ? p->use_conv_rows : 0;
     if (o == "fused_conv_bwd") return p->dt != M2T_F32 && p->use_fused_conv_bwd && conv3x3_c64_bwd_fusable(p->B, p->H, p->W);
@@ -917,8 +916,10 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (k == "side_stream") { p->use_side = (value != 0); return 0; }
   if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }
   if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
-  if (k == "fused_tail_bwd") { p->use_fused_tail_bwd = (value != 0); return 0; }
-  if (k == "fused_tail_fwd") { p->use_fused_tail_fwd = (value != 0); p->have_acts = false; return 0; }
+  if (k == "fused_tail") {
+    if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_tail: 0..2");
+    p->use_fused_tail_bwd = value >= 1; p->use_fused_tail_fwd = value == 2; p->have_acts = false; return 0;
+  }
   if (k == "attn_bwd") {
     if (value < 0 || value > 3) return m2t_set_error(M2T_ERR_ARG, "attn_bwd: 0..3");
     p->use_resident_attn_bwd = value >= 1; p->use_fused_qkv_dgrad = value >= 2; p->use_c16_prep = value == 3; return 0;

@@ -80,7 +80,7 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
     """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr.
     fused_attn_fwd (default: bf16 mode): the C = 64 / 256 branches run qkv projection + attention as one kernel, so
     the forward `gemm_qkv` / `attn_fwd_*` categories are then empty (the C = 16 branch runs InstanceNorm apply +
-    projection + attention as `attn_fused_c16`).  fused_tail_fwd: option "fused_tail_fwd" of the plan (default off)."""
+    projection + attention as `attn_fused_c16`).  fused_tail_fwd: option "fused_tail" = 2 of the plan (the bf16 default)."""
     if fused_attn_fwd is None:
         fused_attn_fwd = dtype == "bf16"
     if fused_c16_fwd is None:             # plan option "fused_c16_fwd": the C = 16 branch has its own fused kernel
@@ -169,7 +169,8 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
 def plan_options(plan) -> dict:
     """The kernel-selection options in force on a plan (m2t_plan_query("opt:<key>")): which kernels ran decides which
     rows of `algorithmic_work` apply."""
-    o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_tail_fwd", "fused_c16_fwd", "conv_rows", "fused_conv_bwd")}
+    o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_c16_fwd", "conv_rows", "fused_conv_bwd")}
+    o["fused_tail_fwd"] = plan.query("opt:fused_tail") == 2
     o["c16_recompute"] = plan.query("opt:fused_c16_fwd") == 2
     o["c64_recompute"] = plan.query("opt:fused_attn_fwd") == 2
     o["fused_qkv_dgrad"] = plan.query("opt:attn_bwd") >= 2

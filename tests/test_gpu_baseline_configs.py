@@ -100,10 +100,20 @@ def check_vs_oracle(scale, lr, B, dtype, nb=8, verbose=True):
               f"{worst[1]:.2e} vs {own[worst[0]]:.2e})")
         stage_txt = ""
     else:
+        from m2trans_amd import _lib
         from tests.gpu_util import hip_forward_trace
         plan = model._plan_for(x.cuda())
         H, W = plan.query("padded_h"), plan.query("padded_w")
+        if scale == 4 and plan.query("stores_t2") == 0:
+            # default x4 path: gelu(t2) / gelu'(t2) live only in LDS (fused forward tail), which would leave the last stage two
+            # kernels deep.  The same step with them stored must give the same bits; its workspace then feeds the stage gates.
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_tail", 1), "m2t_set_option")
+            sr1, loss1, grads1 = fwd_bwd(model, x.cuda(), hr.cuda(), hr.numel())
+            assert plan.query("stores_t2") == 1
+            assert torch.equal(sr1, sr) and loss1 == loss and torch.equal(grads1, grads), "fused forward tail is not bit-identical"
         trace = hip_forward_trace(plan, scale, nb, B, H, W)
+        if scale == 4:
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_tail", 2), "m2t_set_option")
         rep = {}
         loss_o, sr_o, g_o = O.l1_loss_and_grads(x, hr, p, scale, nb, emulate_bf16=True, force=trace, stage_report=rep)
         rows = grad_table(model, grads, g_o)

@@ -86,7 +86,7 @@ def test_forward_backward_vs_reference_golden(golden_dir, name):
     loss = (sr - hr).abs().mean()
     loss.backward()
     assert rel(sr, torch.from_numpy(g["sr"])) < 1e-4
-    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5
     grads = {n: q.grad for n, q in model.named_parameters() if q.requires_grad}
     norms = dict(zip([str(s) for s in g["grad_names"]], g["grad_norms"]))
     rows = [(k, abs(float(v.double().norm()) - norms[k]) / (norms[k] + 1e-30)) for k, v in grads.items()]
@@ -175,7 +175,7 @@ def test_bf16_fast_kernels_match_plain_kernels():
     for fast in (1, 0):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
-        for key, val in ((b"attn_bwd", 3 if fast else 0), (b"gate_branch", 2 if fast else -1), (b"fused_conv_bwd", fast), (b"side_stream", fast), (b"fused_tail_bwd", fast)):
+        for key, val in ((b"attn_bwd", 3 if fast else 0), (b"gate_branch", 2 if fast else -1), (b"fused_conv_bwd", fast), (b"side_stream", fast), (b"fused_tail", 2 if fast else 0)):
             _lib.check(_lib.load().m2t_set_option(plan.handle, key, val), "m2t_set_option")
         sr = model(x)
         torch.nn.L1Loss()(sr, hr).backward()
@@ -653,7 +653,7 @@ def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():
         for fused in (1, 0):
             model, _ = build_model(scale, nb, "bf16")
             plan = model._plan_for(x)
-            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_tail_fwd", fused), "m2t_set_option")
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_tail", 2 if fused else 1), "m2t_set_option")
             assert plan.query("stores_t2") == 1 - fused
             sr = model(x)
             torch.nn.L1Loss()(sr, hr).backward()

@@ -29,6 +29,8 @@ CATEGORY_OF = [   # (substring of the kernel name, extra substring, category)
     ("window_attn_fwd_kernel", "Li16E", "attn_fwd_c16"), ("window_attn_fwd_kernel", "Li64E", "attn_fwd_c64"),
     ("window_attn_fwd_kernel", "Li256E", "attn_fwd_c256"), ("window_attn_bwd_kernel", "Li16E", "attn_bwd_c16"),
     ("window_attn_bwd_kernel", "Li64E", "attn_bwd_c64"), ("window_attn_bwd_kernel", "Li256E", "attn_bwd_c256"),
+    ("conv3x3_c64_bwd_rows_kernel", "", "conv3x3_bwd"), ("conv3x3_c64_rows_kernel", "", "conv3x3_fwd"),
+    ("wgrad_tn_fast_kernel", "", "wgrad_tn_fast"), ("wgrad_tn_big_kernel", "", "wgrad_tn_big"), ("c16_dgrad_prep_kernel", "", "c16_dgrad_prep"),
     ("conv3x3_c64_wgrad_kernel", "", "conv3x3_wgrad"), ("conv3x3_c64_kernel", "", "conv3x3_fwd+dgrad"), ("conv3x3_c64_pipe_kernel", "", "conv3x3_fwd+dgrad"),
     ("final_conv_fwd_kernel", "", "final_conv_fwd"), ("final_conv_dgrad_kernel", "", "final_conv_dgrad"),
     ("final_conv_wgrad_kernel", "", "final_conv_wgrad"), ("wgrad_tn_kernel", "", "wgrad_tn(all)"),
