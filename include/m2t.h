@@ -121,6 +121,11 @@ int m2t_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
  * category ids are listed in m2trans_amd/profile.py; mask bit i enables category i; 0 = off. */
 int m2t_profile_enable(unsigned long long category_mask);
 int m2t_profile_read(int category, double* total_ms, long long* launches);
+/* single-kernel categories (attention, 3x3 conv, tail kernels) are timed by events that ride on the dispatch itself; such a
+ * dispatch costs ~10 us of launch path, so a step with 16 timed launches runs 2 % slower than an untimed one.  n > 1 times a
+ * uniform sample -- every n-th launch of each category -- instead (process-wide, default 1 = every launch); m2t_profile_read
+ * then returns the total and the count of the SAMPLED launches. */
+int m2t_profile_sample_every(int n);
 
 /* ---- operators (NHWC tensors in `dtype` unless stated) ---------------------------------- */
 /* DWT.forward / IWT.forward (models/M2Trans_network.py:198-237), `levels` in {1,2} applied

@@ -32,6 +32,7 @@ SIGNATURES = {
     "m2t_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f, _vp]),
     "m2t_profile_enable": (_i, [C.c_ulonglong]),
     "m2t_profile_read": (_i, [_i, C.POINTER(_d), C.POINTER(_ll)]),
+    "m2t_profile_sample_every": (_i, [_i]),
     "m2t_swin_create": (_i, [C.POINTER(_vp), _i, _i]),
     "m2t_swin_destroy": (None, [_vp]),
     "m2t_swin_query": (_ll, [_vp, C.c_char_p]),

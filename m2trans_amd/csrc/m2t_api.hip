@@ -43,16 +43,24 @@ namespace {
 struct ProfRec { hipEvent_t a, b; int cat; };
 struct ProfState {
   std::atomic<unsigned long long> mask{0};
+  std::atomic<int> every{1};              // dispatch-timed categories: events ride on one launch in `every` (m2t_profile_sample_every)
   std::mutex mu;
   std::vector<ProfRec> pool;
   size_t used = 0;
+  long long seen[64] = {0};               // launches of each category since m2t_profile_enable (under mu)
 };
 ProfState g_prof;
 struct ProfOpen { long long slot = -1; bool taken = false; };
 thread_local ProfOpen g_open;             // the record of the scope this thread has open
-long long prof_claim(int cat) {           // next free record, or -1 (mask off / pool exhausted)
+long long prof_claim(int cat) {           // next free record, or -1 (mask off / not a sampled launch / pool exhausted)
   if (!((g_prof.mask.load(std::memory_order_relaxed) >> cat) & 1ull)) return -1;
   std::lock_guard<std::mutex> lk(g_prof.mu);
+  if ((M2T_PROF_DISPATCH_CATS >> cat) & 1ull) {
+    // an event-carrying dispatch costs ~10 us of launch path (measured: 16 timed launches per step = +2.3 % on the step);
+    // timing a uniform 1-in-N sample of a category's launches keeps the average and most of the step
+    const int n = g_prof.every.load(std::memory_order_relaxed);
+    if (n > 1 && (g_prof.seen[cat]++ % n) != 0) return -1;
+  }
   if (g_prof.used >= g_prof.pool.size()) return -1;
   g_prof.pool[g_prof.used].cat = -1;      // becomes `cat` once both events are on a stream
   return (long long)g_prof.used++;
@@ -95,6 +103,12 @@ extern "C" int m2t_profile_enable(unsigned long long category_mask) {
   }
   g_prof.mask.store(category_mask, std::memory_order_relaxed);
   g_prof.used = 0;
+  for (auto& v : g_prof.seen) v = 0;
+  return 0;
+}
+extern "C" int m2t_profile_sample_every(int n) {
+  if (n < 1) return m2t_set_error(M2T_ERR_ARG, "m2t_profile_sample_every: n >= 1");
+  g_prof.every.store(n, std::memory_order_relaxed);
   return 0;
 }
 // total milliseconds and launch count of one category since m2t_profile_enable, over every thread that launched; the

@@ -59,7 +59,9 @@ MFMA_PEAK_TF = {"bf16": 2500.0, "fp32": 157.3}
 ALL_MASK = (1 << len(CATS)) - 1
 
 
-def enable(mask: int = ALL_MASK):
+def enable(mask: int = ALL_MASK, sample_every: int = 1):
+    """sample_every = n > 1: the dispatch-timed (single-kernel) categories take their events on every n-th launch only."""
+    _lib.check(_lib.load().m2t_profile_sample_every(int(sample_every)), "m2t_profile_sample_every")
     _lib.check(_lib.load().m2t_profile_enable(C.c_ulonglong(mask)), "m2t_profile_enable")
 
 
