@@ -6,6 +6,7 @@
 #include <string>
 #include <vector>
 #include "m2t_kernels.h"
+#include <cstring>
 #include "../../include/m2t.h"
 
 namespace {
@@ -27,6 +28,14 @@ struct m2t_swin {
   std::map<std::string, Ws> ws;
   size_t ws_bytes = 0;
   const float* weights = nullptr;          // caller's flat fp32 weights (device), set by load_weights
+  // crop tables travel through a small ring of PINNED host slots, so the upload is a true asynchronous copy and the call returns
+  // without waiting for the stream (round 3: the hipStreamSynchronize that protected a pageable temporary made every
+  // SemanticLoss step wait for the model's forward pass -- 8 of the 11 ms of configs[2] were host stall)
+  static constexpr int NPIN = 8;
+  int* pinned = nullptr;                   // [NPIN][3 * max_images]
+  hipEvent_t pin_ev[NPIN] = {};            // slot k's copy has been consumed
+  bool pin_used[NPIN] = {};
+  int pin_next = 0;
   bool fused_mlp = true;                   // bf16, stages 1 / 2: LayerNorm + fc1 + GELU + fc2 + residual in one kernel (k_swin.hip)
   void add_param(const std::string& n, long long c) { pnames.push_back(n); poff[n] = nparams; pnum[n] = c; nparams += c; }
   void add_pack(const std::string& n, long long c) { npacked = (npacked + 7) & ~7LL; pk[n] = npacked; npacked += c; }
@@ -100,7 +109,14 @@ extern "C" int m2t_swin_create(m2t_swin** out, int max_images, int dtype) {
   *out = p;
   return 0;
 }
-extern "C" void m2t_swin_destroy(m2t_swin* p) { delete p; }
+extern "C" void m2t_swin_destroy(m2t_swin* p) {
+  if (!p) return;
+  if (p->pinned) {
+    (void)hipHostFree(p->pinned);
+    for (auto& e : p->pin_ev) if (e) (void)hipEventDestroy(e);
+  }
+  delete p;
+}
 extern "C" long long m2t_swin_query(const m2t_swin* p, const char* key) {
   if (!p || !key) return -1;
   const std::string k(key);
@@ -194,10 +210,28 @@ extern "C" int m2t_swin_encode_pair(m2t_swin* p, const float* src, int n_a, cons
   hipStream_t st = (hipStream_t)stream;
   const int dt = p->dt;
   const float* wt = p->weights;
-  hipError_t e = hipMemcpyAsync(SWP("crops"), crops_host, sizeof(int) * 3 * n, hipMemcpyHostToDevice, st);
+  hipError_t e = hipSuccess;
+  if (!p->pinned) {
+    e = hipHostMalloc((void**)&p->pinned, sizeof(int) * 3 * (size_t)p->max_images * m2t_swin::NPIN, hipHostMallocDefault);
+    if (e != hipSuccess) { p->pinned = nullptr; return m2t_set_hip_error(e, __FILE__, __LINE__); }
+    for (auto& ev : p->pin_ev) {
+      e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+    }
+  }
+  const int slot = p->pin_next;
+  p->pin_next = (slot + 1) % m2t_swin::NPIN;
+  if (p->pin_used[slot]) {             // eight encodes ago: long done unless the caller never synchronises
+    e = hipEventSynchronize(p->pin_ev[slot]);
+    if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+  }
+  int* stage = p->pinned + (size_t)slot * 3 * p->max_images;
+  memcpy(stage, crops_host, sizeof(int) * 3 * n);      // crops_host may be a temporary of the caller
+  e = hipMemcpyAsync(SWP("crops"), stage, sizeof(int) * 3 * n, hipMemcpyHostToDevice, st);
   if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
-  e = hipStreamSynchronize(st);        // crops_host may be a temporary
+  e = hipEventRecord(p->pin_ev[slot], st);
   if (e != hipSuccess) return m2t_set_hip_error(e, __FILE__, __LINE__);
+  p->pin_used[slot] = true;
   void *X = SWP("X"), *Hn = SWP("Hn"), *QKV = SWP("QKV"), *AO = SWP("AO"), *MH = SWP("MH");
   const float* fbias = (const float*)SWP("fbias");
   CKS(launch_swin_patchify(dt, src, src_b, n_a, Hs, Ws, (const int*)SWP("crops"), n, SWP("A0"), st));
