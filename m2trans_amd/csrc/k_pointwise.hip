@@ -253,7 +253,6 @@ __global__ void __launch_bounds__(256) instnorm_stats1_kernel(const T* __restric
     }
   }
 }
-template <bool PAIRS>     // PAIRS: up to 64 partials, neighbours merged first (the conv epilogue's per-wave partials)
 __global__ void __launch_bounds__(64) instnorm_stats2_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd,
                                        int nsplit, float eps) {
   // every partial is fetched before the first merge (independent loads in flight), then a fixed pairwise tree:
@@ -263,18 +262,7 @@ __global__ void __launch_bounds__(64) instnorm_stats2_kernel(const float* __rest
 #pragma unroll
   for (int s = 0; s < M2T_NORM_SPLIT; ++s) {
     w[s].n = 0.f; w[s].mean = 0.f; w[s].m2 = 0.f;
-    if constexpr (PAIRS) {
-      Wf u; u.n = 0.f; u.mean = 0.f; u.m2 = 0.f;
-      if (2 * s < nsplit) {
-        const float* o = part + (((long long)b * nsplit + 2 * s) * 64 + ch) * 3;
-        w[s].n = o[0]; w[s].mean = o[1]; w[s].m2 = o[2];
-      }
-      if (2 * s + 1 < nsplit) {
-        const float* o = part + (((long long)b * nsplit + 2 * s + 1) * 64 + ch) * 3;
-        u.n = o[0]; u.mean = o[1]; u.m2 = o[2];
-      }
-      w[s] = wf_merge(w[s], u);
-    } else if (s < nsplit) {
+    if (s < nsplit) {
       const float* o = part + (((long long)b * nsplit + s) * 64 + ch) * 3;
       w[s].n = o[0]; w[s].mean = o[1]; w[s].m2 = o[2];
     }
@@ -297,16 +285,51 @@ int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float
   if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_stats1_kernel<float>, dim3(nsplit, B), dim3(256), 0, st, (const float*)x, part, P, nsplit);
   else hipLaunchKernelGGL(instnorm_stats1_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, st, (const bf16_t*)x, part, P, nsplit);
   M2T_LAUNCH_CHECK();
-  hipLaunchKernelGGL(instnorm_stats2_kernel<false>, dim3(B), dim3(64), 0, st, part, mean, rstd, nsplit, 1e-5f);
+  hipLaunchKernelGGL(instnorm_stats2_kernel, dim3(B), dim3(64), 0, st, part, mean, rstd, nsplit, 1e-5f);
   M2T_LAUNCH_CHECK();
   return 0;
 }
 
-// the second stage alone: `part` [B][nsplit][64][3] = (n, mean, M2) partials written by another kernel (the row-streaming conv
-// leaves the statistics of its output this way, k_conv.hip)
+// The second stage alone, for partials written by another kernel (the row-streaming conv leaves the statistics of its output as
+// `part` [B][nsplit <= 64][64][3] = (n, mean, M2), k_conv.hip).  One 256-thread block per image: thread (channel, quarter) takes
+// every 4th partial; N = sum n_i, mean = sum n_i mean_i / N, M2 = sum (M2_i + n_i (mean_i - mean)^2) -- no division per merge, all
+// loads in flight at once, two LDS exchanges, every sum in a fixed order.  (The 64-thread pair tree this replaces took 15 us per
+// launch, more than the 12.5 us pass over the map that the epilogue partials had saved.)
+__global__ void __launch_bounds__(256) instnorm_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean,
+                                                                float* __restrict__ rstd, int nsplit, float eps) {
+  const int b = blockIdx.x, ch = threadIdx.x & 63, q = threadIdx.x >> 6;
+  __shared__ float sh[3][4][64];
+  float n[16], m[16], v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int s = q + 4 * i;
+    n[i] = 0.f; m[i] = 0.f; v[i] = 0.f;
+    if (s < nsplit) {
+      const float* o = part + (((long long)b * nsplit + s) * 64 + ch) * 3;
+      n[i] = o[0]; m[i] = o[1]; v[i] = o[2];
+    }
+  }
+  float sn = 0.f, sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { sn += n[i]; sm = fmaf(n[i], m[i], sm); }
+  sh[0][q][ch] = sn; sh[1][q][ch] = sm;
+  __syncthreads();
+  const float N = (sh[0][0][ch] + sh[0][1][ch]) + (sh[0][2][ch] + sh[0][3][ch]);
+  const float mu = ((sh[1][0][ch] + sh[1][1][ch]) + (sh[1][2][ch] + sh[1][3][ch])) / fmaxf(N, 1.f);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const float d = m[i] - mu; sq += fmaf(n[i] * d, d, v[i]); }
+  sh[2][q][ch] = sq;
+  __syncthreads();
+  if (q == 0) {
+    const float M2 = (sh[2][0][ch] + sh[2][1][ch]) + (sh[2][2][ch] + sh[2][3][ch]);
+    mean[b * 64 + ch] = mu;
+    rstd[b * 64 + ch] = 1.0f / sqrtf(M2 / N + eps);   // biased variance
+  }
+}
 int launch_instnorm_finalize(const float* part, float* mean, float* rstd, int B, int nsplit, hipStream_t st) {
   if (nsplit < 1 || nsplit > 2 * M2T_NORM_SPLIT) return m2t_set_error(-2, "instnorm_finalize: 1 .. 64 partials per image");
-  hipLaunchKernelGGL(instnorm_stats2_kernel<true>, dim3(B), dim3(64), 0, st, part, mean, rstd, nsplit, 1e-5f);
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(B), dim3(256), 0, st, part, mean, rstd, nsplit, 1e-5f);
   M2T_LAUNCH_CHECK();
   return 0;
 }
