@@ -109,7 +109,7 @@ def test_backward_fp32_every_parameter(scale, nb, B, H0, W0):
     sr = model(x.cuda())
     loss = torch.nn.L1Loss()(sr, hr.cuda())
     loss.backward()
-    assert abs(float(loss) - float(loss_o)) < 1e-5
+    assert abs(float(loss.detach()) - float(loss_o)) < 1e-5
     rows = [(n, rel(q.grad, g_o[n])) for n, q in model.named_parameters() if q.requires_grad]
     bad = [(n, e) for n, e in rows if not (e < 1e-4)]
     assert not bad, "\n".join(f"{n:40s} {e:.3e}" for n, e in rows)
