@@ -23,28 +23,34 @@ constexpr int TF_NM = TF_MB * TF_MB;             // 100 mid pixels (7 MFMA colum
 constexpr int TF_BE = 2 * TF_MB;                 // 20: edge of the a2 block
 constexpr int TF_HP = (TF_T + 2) * (TF_T + 2);   // 324 halo pixels of the conv (21 tiles of 16, last one partly padding)
 constexpr int TF_LD = 72;
-constexpr size_t TF_SZ_W3 = sizeof(bf16_t) * 256 * TF_LD, TF_SZ_WF = sizeof(bf16_t) * 32 * TF_LD;
+constexpr size_t TF_SZ_WF = sizeof(bf16_t) * 32 * TF_LD;
 constexpr size_t TF_SZ_A1 = sizeof(bf16_t) * 112 * TF_LD, TF_SZ_A2 = sizeof(bf16_t) * TF_BE * TF_BE * TF_LD;
-constexpr size_t TF_SMEM = TF_SZ_W3 + TF_SZ_WF + TF_SZ_A1 + TF_SZ_A2;
+constexpr size_t TF_SMEM = TF_SZ_WF + TF_SZ_A1 + TF_SZ_A2;      // 78 336 B: TWO workgroups per CU (the tail.3 weight fragments live in registers)
+static_assert(2 * TF_SMEM <= 160 * 1024, "two workgroups per CU");
 static_assert(sizeof(float) * 336 * 33 <= TF_SZ_A2, "the fp32 product tile overlays the a2 block");
 
-__global__ void __launch_bounds__(512) tail_fwd_fused_kernel(const bf16_t* __restrict__ a1, const bf16_t* __restrict__ w3p,
+__global__ void __launch_bounds__(512, 4) tail_fwd_fused_kernel(const bf16_t* __restrict__ a1, const bf16_t* __restrict__ w3p,
                                                              const float* __restrict__ b3, const float* __restrict__ wf,
                                                              float* __restrict__ out, int B, int H, int W) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T(*W3s)[TF_LD] = reinterpret_cast<T(*)[TF_LD]>(smem);                                          // [256 n'][k], n' = sub * 64 + c
-  T(*Wfs)[TF_LD] = reinterpret_cast<T(*)[TF_LD]>(smem + TF_SZ_W3);                               // [(tap, oc) -> 32][ic]
-  T(*A1b)[TF_LD] = reinterpret_cast<T(*)[TF_LD]>(smem + TF_SZ_W3 + TF_SZ_WF);                    // [100 mid pixels -> 112][k]
-  T(*A2b)[TF_LD] = reinterpret_cast<T(*)[TF_LD]>(smem + TF_SZ_W3 + TF_SZ_WF + TF_SZ_A1);         // [20 x 20 block pixels][c]
-  float(*Ys)[33] = reinterpret_cast<float(*)[33]>(smem + TF_SZ_W3 + TF_SZ_WF + TF_SZ_A1);        // [336][33], overlays A2b
+  T(*Wfs)[TF_LD] = reinterpret_cast<T(*)[TF_LD]>(smem);                                          // [(tap, oc) -> 32][ic]
+  T(*A1b)[TF_LD] = reinterpret_cast<T(*)[TF_LD]>(smem + TF_SZ_WF);                               // [100 mid pixels -> 112][k]
+  T(*A2b)[TF_LD] = reinterpret_cast<T(*)[TF_LD]>(smem + TF_SZ_WF + TF_SZ_A1);                    // [20 x 20 block pixels][c]
+  float(*Ys)[33] = reinterpret_cast<float(*)[33]>(smem + TF_SZ_WF + TF_SZ_A1);                   // [336][33], overlays A2b
   const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6;
   const int lr = lane & 15, g = lane >> 4;
   const int Hm = H / 2, Wm = W / 2;
   const int tw = W / TF_T, th = H / TF_T;
   const long long ntiles = (long long)B * th * tw;
   const long long hw = (long long)H * W;
-  for (int i = tid; i < 256 * 8; i += 512) store8(&W3s[i >> 3][(i & 7) * 8], load8(w3p + (long long)(i >> 3) * 64 + (i & 7) * 8));
+  // this wave's tail.3 weight fragments (n' tiles 2 w8, 2 w8 + 1; [256 n'][64 k] packed rows): 16 registers for the whole kernel --
+  // in LDS they were 36.8 KB, the difference between one and two workgroups per CU
+  Frag8<T> w3f[2][2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) w3f[o][kc] = load8(w3p + (long long)(16 * (2 * w8 + o) + lr) * 64 + 32 * kc + 8 * g);
   for (int i = tid; i < 32 * 64; i += 512) {
     const int n = i >> 6, ic = i & 63;              // n = tap * 3 + oc
     float v = 0.f;
@@ -54,26 +60,24 @@ __global__ void __launch_bounds__(512) tail_fwd_fused_kernel(const bf16_t* __res
   for (int i = tid; i < 12 * 8; i += 512) store8(&A1b[100 + (i >> 3)][(i & 7) * 8], frag_zero<T>());    // MFMA padding rows
   // tiles are dealt round-robin over LOGICAL workgroup indices (XCD-aware: in every round an XCD owns a contiguous run)
   const long long lb = xcd_block_index();
-  Frag8<T> ra[2];
-  auto fetch = [&](long long t) {                   // the 10 x 10 mid pixels: clamped coordinates (a clamped pixel is never used)
-    const int x0 = (int)(t % tw) * TF_T;
-    const long long q = t / tw;
-    const int y0 = (int)(q % th) * TF_T;
-    const T* ab = a1 + (q / th) * (long long)Hm * Wm * 64;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int idx = min(tid + it * 512, TF_NM * 8 - 1);
-      const int m = idx >> 3, cv = idx & 7;
-      const int my = min(max(y0 / 2 - 1 + m / TF_MB, 0), Hm - 1), mx = min(max(x0 / 2 - 1 + m % TF_MB, 0), Wm - 1);
-      ra[it] = load8(ab + ((long long)my * Wm + mx) * 64 + cv * 8);
-    }
-  };
-  if (lb < ntiles) fetch(lb);
   for (long long t = lb; t < ntiles; t += gridDim.x) {
     const int x0 = (int)(t % tw) * TF_T;
     const long long q = t / tw;
     const int y0 = (int)(q % th) * TF_T;
     const long long b = q / th;
+    // the 10 x 10 mid pixels: clamped coordinates (a clamped pixel is never used).  No cross-tile prefetch in registers: the second
+    // workgroup of the CU is what runs while this one waits (and the eight registers are what keeps the kernel at 128)
+    Frag8<T> ra[2];
+    {
+      const T* ab = a1 + b * (long long)Hm * Wm * 64;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = min(tid + it * 512, TF_NM * 8 - 1);
+        const int m = idx >> 3, cv = idx & 7;
+        const int my = min(max(y0 / 2 - 1 + m / TF_MB, 0), Hm - 1), mx = min(max(x0 / 2 - 1 + m % TF_MB, 0), Wm - 1);
+        ra[it] = load8(ab + ((long long)my * Wm + mx) * 64 + cv * 8);
+      }
+    }
     lds_barrier();          // the previous tile's readers of A1b / Ys are done (first trip: weights staged)
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -81,7 +85,6 @@ __global__ void __launch_bounds__(512) tail_fwd_fused_kernel(const bf16_t* __res
       if (idx < TF_NM * 8) store8(&A1b[idx >> 3][(idx & 7) * 8], ra[it]);
     }
     lds_barrier();
-    if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
     // ---- t2^T [n'][m] = W3 a1^T + b3, a2 = gelu(t2) -> the 20 x 20 block.  wave w8: n' tiles 2 w8, 2 w8 + 1 ----
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
@@ -91,9 +94,8 @@ __global__ void __launch_bounds__(512) tail_fwd_fused_kernel(const bf16_t* __res
       for (int mt = 0; mt < 7; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
-        const Frag8<T> wfr = load8(&W3s[16 * nt + lr][32 * kc + 8 * g]);
 #pragma unroll
-        for (int mt = 0; mt < 7; ++mt) mma16(acc[mt], wfr, load8(&A1b[16 * mt + lr][32 * kc + 8 * g]));
+        for (int mt = 0; mt < 7; ++mt) mma16(acc[mt], w3f[o][kc], load8(&A1b[16 * mt + lr][32 * kc + 8 * g]));
       }
       float bv[4];
 #pragma unroll
@@ -168,7 +170,7 @@ int launch_tail_fwd_fused(const void* a1, const void* w3p, const float* b3, cons
                           hipStream_t st) {
   if (H % 32 || W % 32) return m2t_set_error(-2, "tail_fwd_fused: H, W must be multiples of 32");
   const long long ntiles = (long long)B * (H / TF_T) * (W / TF_T);
-  const int nblk = (int)std::min<long long>(256, ntiles);
+  const int nblk = (int)std::min<long long>(512, ntiles);         // two workgroups per CU
   if (int rc__ = m2t_ensure_dynamic_lds((const void*)tail_fwd_fused_kernel, (int)TF_SMEM)) return rc__;
   M2T_LAUNCH_TIMED(tail_fwd_fused_kernel, dim3(nblk), dim3(512), TF_SMEM, st, (const bf16_t*)a1, (const bf16_t*)w3p, b3, wf, out, B,
                    H, W);
