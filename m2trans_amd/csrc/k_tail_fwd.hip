@@ -9,8 +9,11 @@
 // the step's HBM traffic -- for 134 MB of input and 50 MB of output.  Here a2 exists only in LDS: per 16x16 output
 // tile a workgroup stages the 10x10 mid-resolution pixels of a1 = gelu(t1) that cover the tile and its 1-pixel halo
 // (reflected at the image border, so every source lies inside the image), expands them (224 MFMAs), applies GELU
-// (the erf is what the kernel is bound by: 25 600 evaluations per tile on the VALU; the halo costs 1.56x), and feeds
-// the 18x18 halo pixels to the tail conv exactly as final_conv_fwd_kernel does.  The backward pass recomputes a2 and
+// (the activation is what the kernel is bound by: 25 600 evaluations per tile on the VALU, the halo costs 1.56x; in bf16 mode
+// it is the exp2 / rcp form of m2t_common.h, 11 issue slots instead of erf's 14 + a division), and feeds
+// the 18x18 halo pixels to the tail conv exactly as final_conv_fwd_kernel does.  Two 512-thread workgroups share a CU (78 KB of LDS
+// and 124 VGPRs each: the tail.3 weight fragments are 16 registers per wave, not 36.8 KB of LDS), so one workgroup's GELU phase
+// runs under the other's MFMA / LDS phases: 341 -> 279 us per launch at batch 16.  The backward pass recomputes a2 and
 // gelu'(t2) the same way (k_tail_bwd.hip, RC variant).  Operand fragments, k order, bias add, gelu and the tap
 // summation are those of the two kernels it replaces: identical bits.
 #include "m2t_kernels.h"
