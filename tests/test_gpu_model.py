@@ -191,6 +191,30 @@ def test_bf16_fast_kernels_match_plain_kernels():
     assert not bad, bad
 
 
+def test_profile_sampling_times_every_nth_dispatch():
+    """m2t_profile_sample_every(n): the dispatch-timed categories put their HIP events on every n-th launch only (bench.py uses
+    n = 3 on the dominant kernel: an event-carrying dispatch costs ~10 us of launch path).  Two blocks launch the C = 256 attention
+    backward four times per step: n = 1 records 4, n = 3 records launches 0 and 3, and the sampled average is a plausible duration."""
+    from m2trans_amd import profile as P
+    scale, nb, B = 4, 2, 2
+    x = O.closed_form_image(B, 3, 64, 64).cuda()
+    hr = O.closed_form_image(B, 3, 256, 256, phase=0.7).cuda()
+    model, _ = build_model(scale, nb, "bf16")
+    cat = P.CATS.index("attn_bwd_c256")
+    counts = {}
+    try:
+        for n in (1, 3):
+            P.enable(1 << cat, sample_every=n)
+            torch.nn.L1Loss()(model(x), hr).backward()
+            torch.cuda.synchronize()
+            ms, cnt = P.read_all()["attn_bwd_c256"]
+            counts[n] = cnt
+            assert cnt > 0 and 1e-3 < ms / cnt < 5.0, (n, ms, cnt)
+    finally:
+        P.enable(0, sample_every=1)
+    assert counts == {1: 4, 3: 2}, counts
+
+
 def test_overlapped_gradient_exchange_path_single_rank():
     """The bucketed exchange (communication stream waiting on the per-bucket events of m2t_backward, then the compute
     stream waiting on the communication stream before Adam) with ONE rank: the collectives are identities, so two
