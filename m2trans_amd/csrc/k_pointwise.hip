@@ -415,24 +415,25 @@ __global__ void __launch_bounds__(256) branch_prep_kernel(const T* __restrict__ 
 // butterflies per (block, channel) out of LDS, phase C writes the d rows as one contiguous run.  Same fp32 operations
 // and rounding points as the register kernel -> identical bits.
 // ---------------------------------------------------------------------------------------
-template <int TX>
-__global__ void __launch_bounds__(256) branch_prep_l2_tiled_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
-                                                                   const float* __restrict__ rstd, const bf16_t* __restrict__ xc, int k,
-                                                                   bf16_t* __restrict__ xin, bf16_t* __restrict__ d, int B, int H, int W) {
-  constexpr int NB = TX / 4;                       // 4x4 blocks per tile
-  constexpr int NV = 4 * TX * 2;                   // 16-byte vectors of the full-resolution tile (4 rows x TX px x 2 halves)
-  __shared__ __attribute__((aligned(16))) bf16_t Q[4][TX][16];
-  __shared__ __attribute__((aligned(16))) bf16_t D[NB][256];
+template <int L, int TX>     // L = 1 (C = 64 branch: 2 rows x TX pixels per workgroup) or 2 (C = 256 branches: 4 rows x TX pixels)
+__global__ void __launch_bounds__(256) branch_prep_tiled_kernel(const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                                const float* __restrict__ rstd, const bf16_t* __restrict__ xc, int k,
+                                                                bf16_t* __restrict__ xin, bf16_t* __restrict__ d, int B, int H, int W) {
+  constexpr int S = Haar<L>::S, N = Haar<L>::N, BW = 16 * N;
+  constexpr int NB = TX / S;                       // S x S blocks per tile
+  constexpr int NV = S * TX * 2;                   // 16-byte vectors of the full-resolution tile (S rows x TX px x 2 halves)
+  __shared__ __attribute__((aligned(16))) bf16_t Q[S][TX][16];
+  __shared__ __attribute__((aligned(16))) bf16_t D[NB][BW];
   const int tid = threadIdx.x;
   const int tpr = W / TX;                          // tiles per image row
-  const int t = blockIdx.x;                        // tile = (b, LR2 row i, tile column)
-  const int tc = t % tpr, i = (t / tpr) % (H / 4), b = t / (tpr * (H / 4));
+  const int t = blockIdx.x;                        // tile = (b, block row i, tile column)
+  const int tc = t % tpr, i = (t / tpr) % (H / S), b = t / (tpr * (H / S));
   const long long npix = (long long)B * H * W;
   const int x0 = tc * TX;
   // ---- phase A ----
   for (int v = tid; v < NV; v += 256) {
     const int row = v / (2 * TX), cv = v % (2 * TX), px = cv >> 1, half = cv & 1;
-    const long long pix = ((long long)b * H + 4 * i + row) * W + x0 + px;
+    const long long pix = ((long long)b * H + S * i + row) * W + x0 + px;
     float q[8];
     load8f(x + ((long long)k * npix + pix) * 16 + half * 8, q);
 #pragma unroll
@@ -441,7 +442,7 @@ __global__ void __launch_bounds__(256) branch_prep_l2_tiled_kernel(const bf16_t*
       q[c] = (q[c] - mean[ch]) * rstd[ch];
     }
     float p[8];
-    load8f(xc + ((long long)(k - 1) * npix + pix) * 16 + half * 8, p);        // k >= 2 for the L = 2 branches
+    load8f(xc + ((long long)(k - 1) * npix + pix) * 16 + half * 8, p);        // k >= 1 for the L >= 1 branches
 #pragma unroll
     for (int c = 0; c < 8; ++c) q[c] = (q[c] + p[c]) * 0.5f;
     store8f(xin + pix * 16 + half * 8, q);
@@ -451,20 +452,20 @@ __global__ void __launch_bounds__(256) branch_prep_l2_tiled_kernel(const bf16_t*
   // ---- phase B: (block, channel) items ----
   for (int it = tid; it < NB * 16; it += 256) {
     const int blk = it >> 4, ch = it & 15;
-    float vv[4][4];
+    float vv[S][S];
 #pragma unroll
-    for (int y = 0; y < 4; ++y)
+    for (int y = 0; y < S; ++y)
 #pragma unroll
-      for (int xx = 0; xx < 4; ++xx) vv[y][xx] = to_f(Q[y][4 * blk + xx][ch]);
-    float o[16];
-    Haar<2>::fwd(vv, o);
+      for (int xx = 0; xx < S; ++xx) vv[y][xx] = to_f(Q[y][S * blk + xx][ch]);
+    float o[N];
+    Haar<L>::fwd(vv, o);
 #pragma unroll
-    for (int n = 0; n < 16; ++n) D[blk][n * 16 + ch] = from_f<bf16_t>(o[n]);
+    for (int n = 0; n < N; ++n) D[blk][n * 16 + ch] = from_f<bf16_t>(o[n]);
   }
   __syncthreads();
-  // ---- phase C: NB consecutive d rows = one contiguous run of NB * 512 bytes ----
-  bf16_t* dp = d + (((long long)b * (H / 4) + i) * (W / 4) + x0 / 4) * 256;
-  for (int v = tid; v < NB * 32; v += 256) store8(dp + v * 8, load8(&D[0][0] + v * 8));
+  // ---- phase C: NB consecutive d rows = one contiguous run of NB * 2 BW bytes ----
+  bf16_t* dp = d + (((long long)b * (H / S) + i) * (W / S) + x0 / S) * BW;
+  for (int v = tid; v < NB * (BW / 8); v += 256) store8(dp + v * 8, load8(&D[0][0] + v * 8));
 }
 
 template <typename T>
@@ -484,9 +485,17 @@ int launch_branch_prep(int dt, int L, const void* x, const float* mean, const fl
                        void* xin, void* d, int B, int H, int W, hipStream_t st) {
   if (dt == M2T_F32) return launch_branch_prep_t<float>(L, (const float*)x, mean, rstd, (const float*)xc, k, (float*)xin, (float*)d, B, H, W, st);
   if (L == 2 && k >= 1 && W % 32 == 0 && H % 4 == 0) {
-    if (W % 64 == 0) hipLaunchKernelGGL(branch_prep_l2_tiled_kernel<64>, dim3(B * (H / 4) * (W / 64)), dim3(256), 0, st, (const bf16_t*)x, mean, rstd,
+    if (W % 64 == 0) hipLaunchKernelGGL((branch_prep_tiled_kernel<2, 64>), dim3(B * (H / 4) * (W / 64)), dim3(256), 0, st, (const bf16_t*)x, mean, rstd,
                                         (const bf16_t*)xc, k, (bf16_t*)xin, (bf16_t*)d, B, H, W);
-    else hipLaunchKernelGGL(branch_prep_l2_tiled_kernel<32>, dim3(B * (H / 4) * (W / 32)), dim3(256), 0, st, (const bf16_t*)x, mean, rstd,
+    else hipLaunchKernelGGL((branch_prep_tiled_kernel<2, 32>), dim3(B * (H / 4) * (W / 32)), dim3(256), 0, st, (const bf16_t*)x, mean, rstd,
+                            (const bf16_t*)xc, k, (bf16_t*)xin, (bf16_t*)d, B, H, W);
+    M2T_LAUNCH_CHECK();
+    return 0;
+  }
+  if (L == 1 && k >= 1 && W % 32 == 0 && H % 2 == 0) {
+    if (W % 64 == 0) hipLaunchKernelGGL((branch_prep_tiled_kernel<1, 64>), dim3(B * (H / 2) * (W / 64)), dim3(256), 0, st, (const bf16_t*)x, mean, rstd,
+                                        (const bf16_t*)xc, k, (bf16_t*)xin, (bf16_t*)d, B, H, W);
+    else hipLaunchKernelGGL((branch_prep_tiled_kernel<1, 32>), dim3(B * (H / 2) * (W / 32)), dim3(256), 0, st, (const bf16_t*)x, mean, rstd,
                             (const bf16_t*)xc, k, (bf16_t*)xin, (bf16_t*)d, B, H, W);
     M2T_LAUNCH_CHECK();
     return 0;
@@ -627,32 +636,33 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_kernel(const T* __restric
       }
   }
 }
-// bf16, L = 2 backward, tiled through LDS like branch_prep_l2_tiled_kernel (the register kernel: 14 us for 42 MB):
+// bf16, L = 1 / 2 backward, tiled through LDS like branch_prep_tiled_kernel (the register kernel: 14 us for 42 MB at L = 2):
 // phase A stages the g_d rows, phase B the inverse butterflies per (block, channel), phase C the full-resolution
 // read-modify-writes with consecutive lanes on consecutive 16 bytes.
-template <int TX>
-__global__ void __launch_bounds__(256) branch_prep_bwd_l2_tiled_kernel(const bf16_t* __restrict__ gd, bf16_t* __restrict__ gxc,
-                                                                       bf16_t* __restrict__ gn, int k, int B, int H, int W,
-                                                                       const bf16_t* __restrict__ gdwin) {
-  constexpr int NB = TX / 4, NV = 4 * TX * 2;
-  __shared__ __attribute__((aligned(16))) bf16_t D[NB][256];
-  __shared__ __attribute__((aligned(16))) float V[4][TX][16];
+template <int L, int TX>     // L = 1 (C = 64 branch: 2 rows x TX pixels per workgroup) or 2 (C = 256 branches: 4 rows x TX pixels)
+__global__ void __launch_bounds__(256) branch_prep_bwd_tiled_kernel(const bf16_t* __restrict__ gd, bf16_t* __restrict__ gxc,
+                                                                    bf16_t* __restrict__ gn, int k, int B, int H, int W,
+                                                                    const bf16_t* __restrict__ gdwin) {
+  constexpr int S = Haar<L>::S, N = Haar<L>::N, BW = 16 * N;       // block edge, sub-bands, values per block of g_d
+  constexpr int NB = TX / S, VB = BW / 8, NV = S * TX * 2;         // blocks per tile, 16-byte vectors per block, full-resolution vectors
+  __shared__ __attribute__((aligned(16))) bf16_t D[NB][BW];
+  __shared__ __attribute__((aligned(16))) float V[S][TX][16];
   const int tid = threadIdx.x;
   const int tpr = W / TX;
   const int t = blockIdx.x;
-  const int tc = t % tpr, i = (t / tpr) % (H / 4), b = t / (tpr * (H / 4));
+  const int tc = t % tpr, i = (t / tpr) % (H / S), b = t / (tpr * (H / S));
   const long long npix = (long long)B * H * W;
   const int x0 = tc * TX;
-  const bf16_t* sp = gd + (((long long)b * (H / 4) + i) * (W / 4) + x0 / 4) * 256;
+  const bf16_t* sp = gd + (((long long)b * (H / S) + i) * (W / S) + x0 / S) * BW;
   if (!gdwin) {
-    for (int v = tid; v < NB * 32; v += 256) store8(&D[0][0] + v * 8, load8(sp + v * 8));
+    for (int v = tid; v < NB * VB; v += 256) store8(&D[0][0] + v * 8, load8(sp + v * 8));
   } else {
-    for (int v = tid; v < NB * 32; v += 256) {
-      const int blk = v >> 5, cv = v & 31;
+    for (int v = tid; v < NB * VB; v += 256) {
+      const int blk = v / VB, cv = v % VB;
       float q[8];
       load8f(sp + v * 8, q);
       long long hoff[3];
-      const int nsrc = halo_sources(b, i, x0 / 4 + blk, H / 32, W / 32, 256, hoff);
+      const int nsrc = halo_sources(b, i, x0 / S + blk, H / (8 * S), W / (8 * S), BW, hoff);
       for (int a = 0; a < nsrc; ++a) {
         float rr[8];
         load8f(gdwin + hoff[a] + cv * 8, rr);
@@ -665,20 +675,20 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_l2_tiled_kernel(const bf1
   __syncthreads();
   for (int it = tid; it < NB * 16; it += 256) {
     const int blk = it >> 4, ch = it & 15;
-    float o[16];
+    float o[N];
 #pragma unroll
-    for (int n = 0; n < 16; ++n) o[n] = to_f(D[blk][n * 16 + ch]);
-    float vv[4][4];
-    Haar<2>::inv(o, vv);
+    for (int n = 0; n < N; ++n) o[n] = to_f(D[blk][n * 16 + ch]);
+    float vv[S][S];
+    Haar<L>::inv(o, vv);
 #pragma unroll
-    for (int y = 0; y < 4; ++y)
+    for (int y = 0; y < S; ++y)
 #pragma unroll
-      for (int xx = 0; xx < 4; ++xx) V[y][4 * blk + xx][ch] = vv[y][xx];
+      for (int xx = 0; xx < S; ++xx) V[y][S * blk + xx][ch] = vv[y][xx];
   }
   __syncthreads();
   for (int v = tid; v < NV; v += 256) {
     const int row = v / (2 * TX), cv = v % (2 * TX), px = cv >> 1, half = cv & 1;
-    const long long pix = ((long long)b * H + 4 * i + row) * W + x0 + px;
+    const long long pix = ((long long)b * H + S * i + row) * W + x0 + px;
     float p[8], pp[8], q[8];
     load8f(gxc + ((long long)k * npix + pix) * 16 + half * 8, p);
     load8f(gxc + ((long long)(k - 1) * npix + pix) * 16 + half * 8, pp);
@@ -696,9 +706,17 @@ int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, i
                            hipStream_t st, const void* gdwin) {
   if ((long long)B * H * W * 4 >= (1LL << 31)) return m2t_set_error(-2, "branch_prep_bwd: B*H*W too large for 32-bit indexing");
   if (dt != M2T_F32 && L == 2 && k >= 1 && W % 32 == 0 && H % 4 == 0) {
-    if (W % 64 == 0) hipLaunchKernelGGL(branch_prep_bwd_l2_tiled_kernel<64>, dim3(B * (H / 4) * (W / 64)), dim3(256), 0, st, (const bf16_t*)gd,
+    if (W % 64 == 0) hipLaunchKernelGGL((branch_prep_bwd_tiled_kernel<2, 64>), dim3(B * (H / 4) * (W / 64)), dim3(256), 0, st, (const bf16_t*)gd,
                                         (bf16_t*)gxc, (bf16_t*)gn, k, B, H, W, (const bf16_t*)gdwin);
-    else hipLaunchKernelGGL(branch_prep_bwd_l2_tiled_kernel<32>, dim3(B * (H / 4) * (W / 32)), dim3(256), 0, st, (const bf16_t*)gd, (bf16_t*)gxc,
+    else hipLaunchKernelGGL((branch_prep_bwd_tiled_kernel<2, 32>), dim3(B * (H / 4) * (W / 32)), dim3(256), 0, st, (const bf16_t*)gd, (bf16_t*)gxc,
+                            (bf16_t*)gn, k, B, H, W, (const bf16_t*)gdwin);
+    M2T_LAUNCH_CHECK();
+    return 0;
+  }
+  if (dt != M2T_F32 && L == 1 && k >= 1 && W % 32 == 0 && H % 2 == 0) {      // C = 64 branch: the same staging, two rows per workgroup
+    if (W % 64 == 0) hipLaunchKernelGGL((branch_prep_bwd_tiled_kernel<1, 64>), dim3(B * (H / 2) * (W / 64)), dim3(256), 0, st, (const bf16_t*)gd,
+                                        (bf16_t*)gxc, (bf16_t*)gn, k, B, H, W, (const bf16_t*)gdwin);
+    else hipLaunchKernelGGL((branch_prep_bwd_tiled_kernel<1, 32>), dim3(B * (H / 2) * (W / 32)), dim3(256), 0, st, (const bf16_t*)gd, (bf16_t*)gxc,
                             (bf16_t*)gn, k, B, H, W, (const bf16_t*)gdwin);
     M2T_LAUNCH_CHECK();
     return 0;
