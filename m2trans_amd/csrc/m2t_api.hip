@@ -624,16 +624,18 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     descs.push_back(d);
   };
   size_t bucket_i = 0;
-  auto mark_bucket = [&]() {         // the gradient range of bucket_i is final on the reduction stream from here on
-    if (bucket_i < p->bucket_events.size() && p->red_uploaded) (void)hipEventRecord(p->bucket_events[bucket_i], sd);
+  auto mark_bucket_on = [&](hipStream_t rs) {   // the gradient range of bucket_i is final on stream rs from here on
+    if (bucket_i < p->bucket_events.size() && p->red_uploaded) (void)hipEventRecord(p->bucket_events[bucket_i], rs);
     ++bucket_i;
   };
+  auto mark_bucket = [&]() { mark_bucket_on(sd); };
+  hipStream_t flush_stream = sd;
   auto flush = [&]() -> int {        // one launch reduces everything deferred since the last flush
     if (overflow) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: slab arena too small");
     if (descs.size() > 512) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: too many deferred reductions");
     if (!p->red_uploaded) return 0;  // first call: table not on the device yet, reduced at the end
     const int cnt = (int)(descs.size() - flushed);
-    int rc = launch_multi_reduce(arena, grads, descs_dev + flushed, cnt, sd);
+    int rc = launch_multi_reduce(arena, grads, descs_dev + flushed, cnt, flush_stream);
     flushed = descs.size();
     return rc;
   };
@@ -876,10 +878,17 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     conv_done_prev = conv_done;
     gy = gx;
     if ((b & 1) == 0) { CK(flush()); mark_bucket(); }
+    else if (b == 1) CK(flush());      // (the step's last pair: its first half is reduced under block 0, so that what is left after the
+                                       //  last data-gradient kernel is short -- the main stream idles until it is done)
   }
   // head: g(res) = g(X0) from the chain + g(Y) from `res + x`
   CK(launch_add(dt, gy, WSP("gT"), WSP("gxc"), BP * 64, st));
-  fork();
+  // The end of the step is a serial chain: head weight gradient -> its reduction -> (the caller's) Adam.  In steady state it runs on the
+  // MAIN stream behind the last data-gradient kernel: handing it to the side stream and back cost two cross-stream waits and a
+  // queue position behind the last block pair's reduction (96 us between the last backward kernel and Adam, measured).
+  const bool tail_on_main = p->red_uploaded && sd != st;
+  hipStream_t hs = tail_on_main ? st : sd;
+  if (!tail_on_main) fork();
   if (!skip) {
     // head conv: im2col'd input (made at the start of this backward, off the critical path) x output gradient
     const int nsl = wgrad_slab_count(BP, 64, 32);
@@ -888,7 +897,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     m2t_wgrad_args wa{};
     wa.G = WSP("gxc"); wa.ldg = M2T_LD_P64; wa.gmode = M2T_A_PLAIN; wa.X = WSP("head_cols"); wa.ldx = 32; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = 64; wa.K = 32; wa.H = H; wa.Wd = W; wa.r = 1; wa.C = 64;
-    CK(launch_wgrad_tn(dt, wa, &ns, sd));
+    CK(launch_wgrad_tn(dt, wa, &ns, hs));
     defer(slabs, p->poff.at("head.weight"), ns, 64 * 32, 5, 32, 27, 0);
     defer(colp, p->poff.at("head.bias"), ns, 64, 0, 0, 0, 0);
   }
@@ -905,12 +914,19 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   } else if (p->red_descs.size() != descs.size()) {
     return m2t_set_error(M2T_ERR_STATE, "m2t_backward: reduction table changed between steps");
   }
-  CK(flush());
-  mark_bucket();
+  if (tail_on_main && !first_backward) {
+    main_wait(side_marker());        // join first: everything the side stream still reduces; then the head's reduction on this stream
+    flush_stream = st;
+    CK(flush());
+    mark_bucket_on(st);
+  } else {
+    CK(flush());
+    mark_bucket();
+  }
   if (first_backward)                // nothing was reduced before this point: every bucket completes here
     for (auto e : p->bucket_events) (void)hipEventRecord(e, sd);
   if (bucket_i != p->buckets.size()) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: gradient bucket table out of step");
-  main_wait(side_marker());          // join: every gradient is complete in main-stream order
+  if (!(tail_on_main && !first_backward)) main_wait(side_marker());          // join: every gradient is complete in main-stream order
   p->have_seed = false;
   return 0;
 }
