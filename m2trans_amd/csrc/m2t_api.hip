@@ -152,10 +152,11 @@ struct m2t_plan {
   bool use_fused_tail_fwd = true;      // x4 bf16: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored } 0 / 1 / 2
                                        // (with bf16 mode's exp2 / rcp GELU: 5.30 vs 5.34 ms per step and 1.6 GB less HBM traffic;
                                        // with the erf form of round 2 it was 1 % slower)
-  int gate_branch = 2;                 // side-stream gate: -1 ungated, else the branch (3..0) behind whose attention launch a block's
-                                       // parameter-gradient work is released.  Same-box A/B (config 1) with the fused conv backward:
-                                       // 2 = 5.27 ms, 1 = 5.34, 3 = 5.33, ungated 5.34 (with the conv weight gradient on the side stream,
-                                       // round 2: 1 = 5.49, 2 = 5.60, 3 = 5.62, 0 = 5.68, ungated 5.64)
+  int gate_branch = -1;                // side-stream gate: -1 ungated (a branch's side work follows its attention launch), else the branch (3..0)
+                                       // behind whose attention launch a block's parameter-gradient work is released.  Same-box A/B (config 1),
+                                       // end of round 3 (one buffer-set wait per block instead of one per branch): ungated 4.84 ms, 2 = 4.95,
+                                       // 0 = 5.10, 3 = 5.10, 1 = 5.14, one stream 5.35; batch 32: ungated 8.78, 2 = 8.76.  (While the main chain
+                                       // still waited for the side stream once per BRANCH the gate paid: round 2: 1 = 5.49, 2 = 5.60, ungated 5.64)
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)         } option "attn_bwd":
   bool use_fused_conv_bwd = true;      // bf16 conv3x3 64 -> 64 backward: data + weight / bias gradient in one row-streaming pass (k_conv.hip)
   int use_conv_rows = 1;               // bf16 conv3x3 64 -> 64: row-streaming LDS-DMA kernel (k_conv.hip); 0 = the tile kernel; 3 / 4: A/B variants
@@ -328,10 +329,12 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("gd", BP * 16, es);
   p->add_ws("gdwin", BP * 9, es);      // ring rows of the fused projection data gradient: [windows][36][C], windows * C = BP / 4
   p->add_ws("head_cols", BP * 32, es);
-  for (int i = 0; i < 4; ++i) {     // one set per branch: the side stream may lag the main chain by a whole block
-    p->add_ws("gqkv" + std::to_string(i), BP * 48, es);
-    p->add_ws("win" + std::to_string(i), BP * 50, es);
-    p->add_ws("relw" + std::to_string(i), (size_t)(BP / 64) * 10 * 16, 4);
+  for (int i = 0; i < 4; ++i) {     // TWO sets per branch (even / odd blocks): the side stream may lag the main chain by two blocks, and
+    for (const char* set : {"", "b"}) {   // the main chain waits for it once per block instead of once per branch
+      p->add_ws("gqkv" + std::to_string(i) + set, BP * 48, es);
+      p->add_ws("win" + std::to_string(i) + set, BP * 50, es);
+      p->add_ws("relw" + std::to_string(i) + set, (size_t)(BP / 64) * 10 * 16, 4);
+    }
   }
   p->add_ws("rel_part", 32 * 10 * 256, 4);
   {
@@ -719,10 +722,17 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   // ---- body, last block first.  gy = gradient of X[b+1] ----
   void* gy = WSP("gT");
   void* gnext[2] = {WSP("gA"), WSP("gB")};
-  void* gqkv_buf[4] = {WSP("gqkv0"), WSP("gqkv1"), WSP("gqkv2"), WSP("gqkv3")};
-  float* relw_buf[4] = {(float*)WSP("relw0"), (float*)WSP("relw1"), (float*)WSP("relw2"), (float*)WSP("relw3")};
-  void* win_buf[4] = {WSP("win0"), WSP("win1"), WSP("win2"), WSP("win3")};
-  hipEvent_t branch_done[4] = {nullptr, nullptr, nullptr, nullptr};
+  void* gqkv_sets[2][4]; float* relw_sets[2][4]; void* win_sets[2][4];
+  for (int i = 0; i < 4; ++i) {
+    gqkv_sets[0][i] = WSP("gqkv" + std::to_string(i)); gqkv_sets[1][i] = WSP("gqkv" + std::to_string(i) + "b");
+    relw_sets[0][i] = (float*)WSP("relw" + std::to_string(i)); relw_sets[1][i] = (float*)WSP("relw" + std::to_string(i) + "b");
+    win_sets[0][i] = WSP("win" + std::to_string(i)); win_sets[1][i] = WSP("win" + std::to_string(i) + "b");
+  }
+  // Every event recorded on / waited for by the main stream costs a few microseconds of idle between two dependent kernels (the
+  // backward's launches sit 4-7 us apart where such an operation lies between them, 0-1 us where none does): the block's side work
+  // is therefore released with TWO forks (at the gate, and after the last branch), and its buffers are protected by ONE wait per
+  // block -- for the side work of the block two back, which used the same buffer set.
+  hipEvent_t block_done[2] = {nullptr, nullptr};
   hipEvent_t conv_done_prev = nullptr;      // side finished reading gy of the previously processed block
   // Side-stream schedule.  The two C = 256 attention kernels that open a block need a whole CU's LDS per workgroup
   // (k_attn_res.hip): any concurrent parameter-gradient kernel starves them until it has drained (measured:
@@ -743,6 +753,9 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     void* gxc = WSP("gxc");
     void* gn = WSP("gn");
     void* gy_blk = gy;
+    void** gqkv_buf = gqkv_sets[b & 1]; float** relw_buf = relw_sets[b & 1]; void** win_buf = win_sets[b & 1];
+    main_wait(block_done[b & 1]);              // the side consumers of this buffer set (block b + 2) are done
+    std::vector<int> pending;                  // branches whose side work waits for the block's second fork
     // feed_forward conv: weight / bias gradients on the side stream, data gradient on the main one
     auto side_conv = [&]() -> int {
       if (skip) return 0;
@@ -807,7 +820,6 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       void* gqkv = gqkv_buf[i];
       void* win = win_buf[i];
       float* relw = relw_buf[i];
-      main_wait(branch_done[i]);             // the side consumers of this branch's buffers (previous block) are done
       // gradient of IWT^L is DWT^L: applied while the kernel loads g_xc[chunk i]
       // dK|dV stay window-major in `win`; the fused tail kernel gathers them once per row, writes them back
       // into gqkv for the weight-gradient GEMM, multiplies by Wqkv and applies IWT / branch mixing.
@@ -836,23 +848,24 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         if (!gated) {
           fork();
           CK(side_branch(i));
-          branch_done[i] = side_marker();
+          if (i == 0) block_done[b & 1] = side_marker();
         } else if (i == gate) {
           fork();                              // the gate: the LDS-hungry attention kernels of this block are on their way
           // gated branches first, then the block's conv weight gradient (512 threads, 80 KB of LDS: +1.9 % over putting it
           // first, where it met the C = 64 attention)
-          for (int j = 3; j >= gate; --j) {
-            CK(side_branch(j));
-            branch_done[j] = side_marker();
-          }
+          for (int j = 3; j >= gate; --j) CK(side_branch(j));
           if (!fuse_conv) {
             CK(side_conv());
             conv_done = side_marker();
           }
+          if (i == 0) block_done[b & 1] = side_marker();
         } else if (i < gate) {
-          fork();
-          CK(side_branch(i));
-          branch_done[i] = side_marker();
+          pending.push_back(i);                // released together behind the last branch: one fork instead of one per branch
+          if (i == 0) {
+            fork();
+            for (int j : pending) CK(side_branch(j));
+            block_done[b & 1] = side_marker();
+          }
         }
         return 0;
       };

@@ -175,7 +175,7 @@ def test_bf16_fast_kernels_match_plain_kernels():
     for fast in (1, 0):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
-        for key, val in ((b"attn_bwd", 3 if fast else 0), (b"gate_branch", 2 if fast else -1), (b"fused_conv_bwd", fast), (b"side_stream", fast), (b"fused_tail", 2 if fast else 0)):
+        for key, val in ((b"attn_bwd", 3 if fast else 0), (b"gate_branch", -1), (b"fused_conv_bwd", fast), (b"side_stream", fast), (b"fused_tail", 2 if fast else 0)):
             _lib.check(_lib.load().m2t_set_option(plan.handle, key, val), "m2t_set_option")
         sr = model(x)
         torch.nn.L1Loss()(sr, hr).backward()

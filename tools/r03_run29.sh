@@ -1,0 +1,14 @@
+cd $GRAFT_REPO_ROOT
+ab() { python bench.py --no-cpu-baseline --no-kernel-events --steps 20 $2 2>&1 | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'])"; }
+for i in 1 2 3 4; do
+ab gate2 ""
+ab ungated "--option gate_branch=-1"
+done
+for i in 1 2; do
+ab c3_gate2 "--config 3"
+ab c3_ungated "--config 3 --option gate_branch=-1"
+ab c4_gate2 "--config 4"
+ab c4_ungated "--config 4 --option gate_branch=-1"
+done
