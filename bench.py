@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--semantic-loss", action="store_true",
                     help="BASELINE configs[2]: add the MedCLIP(Swin-T) image-text regulariser (random-init tower, hash text features)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=None)
+    ap.add_argument("--stub-step", action="store_true",
+                    help="HARNESS SELF-TEST on CPU: run this script's N-rank control flow with gloo and a sleeping stand-in for the step; "
+                         "prints an `invalid` line with no throughput")
     args = ap.parse_args()
     # presets = BASELINE.json configs[i]; configs[0] (x2 64x64 CPU forward) is a parity case, not a bench line
     if args.config is None:
@@ -157,20 +160,79 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
+def visible_gpu_count(sysfs_root: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
+    """GPUs this process could open, counted WITHOUT the HIP runtime (torch.cuda.device_count() falls back to
+    hipGetDeviceCount when amdsmi is absent, which initialises HIP in the parent): KFD topology nodes with SIMDs are
+    GPUs (CPU nodes have simd_count 0), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES."""
+    n = 0
+    try:
+        for node in sorted(os.listdir(sysfs_root)):
+            try:
+                props = dict(l.split(None, 1) for l in open(os.path.join(sysfs_root, node, "properties")).read().splitlines() if " " in l)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def launch_ranks(args) -> int:
-    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (never an exec: this process
-    has not touched the GPU yet and stays a plain parent), relay rank 0's JSON line, return the child's status."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (never an exec), relay rank 0's
+    JSON line, return the child's status.  The parent stays strictly GPU-free: devices are counted from sysfs."""
     import subprocess
-    visible = torch.cuda.device_count()           # counting devices does not initialise the HIP runtime
-    if visible < args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but only {visible} device(s) are visible", file=sys.stderr)
-        return 2
+    if not args.stub_step:
+        visible = visible_gpu_count()
+        if visible < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {visible} device(s) are visible", file=sys.stderr)
+            return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(1, args.gpus))))
     cmd = child_command(sys.argv[1:], args.gpus, free_port())
     print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
     return subprocess.run(cmd, env=env).returncode
+
+
+def stub_main(args, world: int, rank: int) -> None:
+    """--stub-step: the N-rank CONTROL FLOW of this script (launcher relay, WORLD_SIZE guard, barrier-bracketed timed region,
+    MAX-over-ranks time, rank-0-only JSON line) on CPU with gloo and a sleeping stand-in for the step.  A self-test of the
+    harness for boxes without GPUs (tests/test_host_cpu.py); its line says `invalid` and carries no throughput."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+    per_step = 0.01 * (1 + rank)                 # rank r is (r + 1) x slower: the MAX reduction must report the slowest rank
+    for _ in range(args.warmup):
+        time.sleep(per_step)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(per_step)
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    own = dt
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    if rank == 0:
+        print(json.dumps({"metric": "bench.py control-flow self-test (no GPU work)", "value": None, "invalid": True, "stub": True,
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
+                          "rank0_ms_per_step": round(1000.0 * own / args.steps, 3), "scaling": "weak",
+                          "config": {"per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                                     "backend": "gloo", "world_size": dist.get_world_size() if dist.is_initialized() else 1}}), flush=True)
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def main():
@@ -182,6 +244,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU")
+    if args.stub_step:
+        return stub_main(args, world, rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None

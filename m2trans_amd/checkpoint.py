@@ -85,7 +85,7 @@ def import_checkpoint(ckpt: dict, model, train_step=None) -> int:
         if sch is not None:
             train_step.scheduler_last_epoch = int(sch.get("last_epoch", 0))
         else:
-            # a checkpoint without scheduler state (e.g. --pretrain files): the reference saves BEFORE the epoch's
-            # scheduler.step() (train.py:341-358), so the scheduler stood at epoch - 1
-            train_step.scheduler_last_epoch = max(0, int(ckpt.get("epoch", 0)) - 1)
+            # no scheduler state: only --resume restores the schedule (train.py:97-103) and resume checkpoints always carry it;
+            # a --pretrain load (train.py:85-88) takes the model weights alone and starts CosineAnnealingLR fresh
+            train_step.scheduler_last_epoch = 0
     return int(ckpt.get("epoch", 0)) + 1

@@ -654,7 +654,8 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   const bool skip = p->debug_skip_side;
   hipStream_t tws = sd;      // tail weight gradients: side stream (same-box A/B: +0.5 % over the main stream)
   fork();
-  if (!skip) CK(launch_head_im2col(dt, x, WSP("head_cols"), B, p->H0, p->W0, H, W, sd));
+  hipEvent_t im2col_done = nullptr;           // head_cols is produced on the side stream; the head weight gradient may run on the main one
+  if (!skip) { CK(launch_head_im2col(dt, x, WSP("head_cols"), B, p->H0, p->W0, H, W, sd)); im2col_done = side_marker(); }
   const bool fused_tail = p->use_fused_tail_bwd && s == 4 && dt != M2T_F32;
   if (fused_tail) {
     // one pass over the high-resolution tensors (k_tail_bwd.hip): tail conv dgrad + wgrad, GELU', tail.3 dgrad + wgrad
@@ -910,6 +911,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     m2t_wgrad_args wa{};
     wa.G = WSP("gxc"); wa.ldg = M2T_LD_P64; wa.gmode = M2T_A_PLAIN; wa.X = WSP("head_cols"); wa.ldx = 32; wa.xmode = M2T_A_PLAIN;
     wa.slabs = slabs; wa.bias_slabs = colp; wa.M = BP; wa.N = 64; wa.K = 32; wa.H = H; wa.Wd = W; wa.r = 1; wa.C = 64;
+    if (hs == st) main_wait(im2col_done);      // (long since complete; the wait closes the hazard for every n_blocks)
     CK(launch_wgrad_tn(dt, wa, &ns, hs));
     defer(slabs, p->poff.at("head.weight"), ns, 64 * 32, 5, 32, 27, 0);
     defer(colp, p->poff.at("head.bias"), ns, 64, 0, 0, 0, 0);
@@ -965,7 +967,8 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   }
   if (k == "attn_bwd") {
     if (value < 0 || value > 3) return m2t_set_error(M2T_ERR_ARG, "attn_bwd: 0..3");
-    p->use_resident_attn_bwd = value >= 1; p->use_fused_qkv_dgrad = value >= 2; p->use_c16_prep = value == 3; return 0;
+    // (which of qkv1 / qkv2 the forward stores depends on this option: activations of a forward run under another value are unusable)
+    p->use_resident_attn_bwd = value >= 1; p->use_fused_qkv_dgrad = value >= 2; p->use_c16_prep = value == 3; p->have_acts = false; return 0;
   }
   if (k == "conv_rows") { p->use_conv_rows = (int)value; return 0; }
   if (k == "fused_conv_bwd") { p->use_fused_conv_bwd = (value != 0); return 0; }

@@ -159,9 +159,14 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         add("final_conv_fwd", fin, HR * (64 * es + 12), 1)
     if scale == 4 and dtype == "bf16":
         # fused tail backward (k_tail_bwd.hip): tail conv dgrad + wgrad, GELU', tail.3 dgrad + wgrad in one pass:
-        # reads gelu(t2), gelu'(t2) (HR), gelu(t1), gelu'(t1) (HR/4), g(sr); writes g(t1) (HR/4)
+        # reads g(sr) (HR x 12 B), gelu(t1), gelu'(t1) (HR/4); writes g(t1) (HR/4).  The stored variant (option "fused_tail" = 1)
+        # also reads gelu(t2), gelu'(t2) (HR x 2 x 64 es); the default recomputing variant (= 2) does not -- it pays the tail.3
+        # expansion's FLOPs a second time instead
         mid = HR // 4
-        w["final_conv_dgrad"] = (2 * fin + 2 * 2.0 * mid * 64 * 256, HR * (2 * 64 * es + 12) + mid * 3 * 64 * es, 1)
+        if fused_tail_fwd:
+            w["final_conv_dgrad"] = (2 * fin + 3 * 2.0 * mid * 64 * 256, HR * 12 + mid * 3 * 64 * es, 1)
+        else:
+            w["final_conv_dgrad"] = (2 * fin + 2 * 2.0 * mid * 64 * 256, HR * (2 * 64 * es + 12) + mid * 3 * 64 * es, 1)
     else:
         add("final_conv_dgrad", fin, HR * (2 * 64 * es + 12), 1)
         add("final_conv_wgrad", fin, HR * (64 * es + 12), 1)
@@ -217,7 +222,8 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
         kname = KERNEL_OF_BF16.get(name, KERNEL_OF[name]) if dtype == "bf16" else KERNEL_OF[name]
         rows.append({"kernel": kname, "category": name, "bound": bound, "achieved": round(ach, 2),
                      "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic.get(name),
-                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": n, "total_ms": round(ms, 3),
+                     "avg_launch_us": round(avg_s * 1e6, 2), "sampled_launches": n, "sampled_total_ms": round(ms, 3),
+                     "launches_per_step": nl, "est_ms_per_step": round(avg_s * 1e3 * nl, 4),
                      "hbm_GBs": round(by_l / avg_s / 1e9, 1), "mfma_TFs": round(fl_l / avg_s / 1e12, 2)})
     if not rows:
         return None
@@ -231,18 +237,21 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
         sub = [r for r in rows if r["category"] in parts]
         if len(sub) != len(parts):
             continue
-        n = sum(r["launches"] for r in sub)
-        ms = sum(r["total_ms"] for r in sub)
-        by = sum(work[r["category"]][1] / work[r["category"]][2] * r["launches"] for r in sub)
-        fl = sum(work[r["category"]][0] / work[r["category"]][2] * r["launches"] for r in sub)
+        n = sum(r["sampled_launches"] for r in sub)
+        ms = sum(r["sampled_total_ms"] for r in sub)
+        by = sum(work[r["category"]][1] / work[r["category"]][2] * r["sampled_launches"] for r in sub)
+        fl = sum(work[r["category"]][0] / work[r["category"]][2] * r["sampled_launches"] for r in sub)
+        nl = sum(r["launches_per_step"] for r in sub)
         sec = ms * 1e-3
         bound = "hbm" if by / (HBM_PEAK_GBS * 1e9) >= fl / (MFMA_PEAK_TF[dtype] * 1e12) else "mfma"
         ach, peak, unit = (by / sec / 1e9, HBM_PEAK_GBS, "GB/s") if bound == "hbm" else (fl / sec / 1e12, MFMA_PEAK_TF[dtype], "TFLOP/s")
         rows.append({"kernel": MERGED_KERNEL[merged], "category": merged, "bound": bound, "achieved": round(ach, 2), "peak": peak,
                      "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic.get(merged),
-                     "avg_launch_us": round(ms / n * 1e3, 2), "launches": n, "total_ms": round(ms, 3),
+                     "avg_launch_us": round(ms / n * 1e3, 2), "sampled_launches": n, "sampled_total_ms": round(ms, 3),
+                     "launches_per_step": nl, "est_ms_per_step": round(ms / n * nl, 4),
                      "hbm_GBs": round(by / sec / 1e9, 1), "mfma_TFs": round(fl / sec / 1e12, 2)})
-    rows.sort(key=lambda r: -r["total_ms"])
+    # (events may ride on a 1-in-n sample of a category's launches: rank by average x launches per step, never by the sampled totals)
+    rows.sort(key=lambda r: -r["est_ms_per_step"])
     # the headline object is the dominant SINGLE kernel (one shape per launch); the qkv / tail GEMM
     # categories aggregate four different shapes each and are listed under "others"
     parts_of_merged = {c for m, parts in MERGED.items() if any(r["category"] == m for r in rows) for c in parts}
@@ -251,7 +260,7 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
     rows.remove(first)
     rows.insert(0, first)
     top = dict(rows[0])
-    top["others"] = [{k: r[k] for k in ("category", "bound", "frac", "avg_launch_us", "total_ms", "hbm_GBs", "mfma_TFs")}
+    top["others"] = [{k: r[k] for k in ("category", "bound", "frac", "avg_launch_us", "launches_per_step", "est_ms_per_step", "hbm_GBs", "mfma_TFs")}
                      for r in rows[1:] if r["category"] not in MERGED]
     return top
 

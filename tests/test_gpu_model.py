@@ -517,6 +517,42 @@ def test_backward_recomputes_qkv_with_identical_bits(key, branch):
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+def test_changing_a_storage_option_between_forward_and_backward_is_refused():
+    """Which of q | k | v the forward stores depends on `attn_bwd` (and on fused_attn_fwd / fused_c16_fwd / fused_tail): a
+    backward under another value would read workspace tensors the forward never wrote.  m2t_set_option therefore drops the
+    activations, and m2t_l1_loss / m2t_backward return M2T_ERR_STATE until the forward has run again."""
+    from m2trans_amd import _lib
+    scale, nb, B, H0, W0 = 4, 1, 1, 32, 32
+    x = O.closed_form_image(B, 3, H0, W0).cuda()
+    hr = O.closed_form_image(B, 3, H0 * scale, W0 * scale, phase=0.7).cuda()
+    lib = _lib.load()
+    loss = torch.zeros(1, device="cuda")
+    for key, val in ((b"attn_bwd", 1), (b"attn_bwd", 0), (b"fused_attn_fwd", 1), (b"fused_c16_fwd", 1), (b"fused_tail", 1)):
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(x)
+        ws, st = _lib.ptr(plan.workspace), _lib.stream_ptr()
+        grads = torch.empty_like(model.flat_params)
+
+        def fwd():
+            _lib.check(lib.m2t_forward(plan.handle, _lib.ptr(model.flat_params), _lib.ptr(x), None, 1.0, 1, ws, st), "m2t_forward")
+
+        def l1():
+            return lib.m2t_l1_loss(plan.handle, _lib.ptr(hr), 1.0, float(hr.numel()), 1.0, _lib.ptr(loss), ws, st)
+
+        def bwd():
+            return lib.m2t_backward(plan.handle, _lib.ptr(model.flat_params), _lib.ptr(x), _lib.ptr(grads), ws, st)
+
+        fwd()
+        assert l1() == 0
+        _lib.check(lib.m2t_set_option(plan.handle, key, val), "m2t_set_option")      # between the forward and the backward
+        assert bwd() != 0 and "m2t_forward" in lib.m2t_last_error_string().decode()
+        assert l1() != 0
+        fwd()                                            # a fresh forward under the new option makes the plan usable again
+        assert l1() == 0 and bwd() == 0
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(grads).all())
+
+
 def test_fused_projection_data_gradient_matches_the_gemm_path():
     """bf16, C = 64 / 256 branches: the data gradient of the qkv projection taken inside the attention backward kernel
     (option fused_qkv_dgrad, default; the window multiplies its own dq | dK | dV contributions by Wqkv^T and the

@@ -406,6 +406,48 @@ def test_bench_plain_multi_gpu_launch_builds_the_torchrun_child():
     env.update(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+    # the parent counts devices from sysfs, never through the HIP runtime
+    launch_src = src[src.index("def launch_ranks"):src.index("def stub_main")]
+    assert "torch.cuda" not in launch_src and "visible_gpu_count()" in launch_src
+
+
+def test_bench_visible_gpu_count_reads_kfd_topology(tmp_path, monkeypatch):
+    """GPUs = KFD topology nodes with SIMDs (CPU nodes have none), narrowed by the *_VISIBLE_DEVICES lists."""
+    import bench
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\nmem_banks_count 1\n")
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count(str(tmp_path)) == 2
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
+    assert bench.visible_gpu_count(str(tmp_path)) == 1
+    assert bench.visible_gpu_count(str(tmp_path / "missing")) == 0
+
+
+def test_bench_two_rank_control_flow_end_to_end_on_a_stub_step():
+    """`python bench.py --gpus 2 --stub-step`: the parent relays its arguments to a torch.distributed.run child, both gloo ranks
+    pass the WORLD_SIZE guard, warm up, time EXACTLY K steps between barriers, MAX-reduce the time, and only rank 0 prints
+    the one JSON line.  Rank 1's stand-in step is 2x slower than rank 0's: the reported time must be rank 1's."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--stub-step",
+                        "--batch", "5"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 only
+    d = json.loads(lines[0])
+    assert d["stub"] and d["invalid"] and d["value"] is None
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2                     # arguments relayed to the ranks
+    assert d["config"]["world_size"] == 2 and d["config"]["global_batch"] == 10 and d["config"]["backend"] == "gloo"
+    # rank 1 sleeps 20 ms per step, rank 0 10 ms: the barrier-bracketed MAX is >= 20 ms per step
+    assert d["ms_per_step"] >= 19.5 and d["ms_per_step"] < 60.0, d
+    assert "launching" in r.stderr and "torch.distributed.run" in r.stderr
 
 
 def test_bf16_gelu_approximation_error_bound():
