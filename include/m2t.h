@@ -64,10 +64,11 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           when the main chain still waited for the side stream once per branch)
  *   "wgrad_big_tiles"   [-1] qkv weight gradient of the C = 256 branches with 128 x 128 output tiles: value = target number of
  *                           workgroups (64..512), 0 = off, -1 = auto (256 from 24 576 branch pixels on, i.e. batch >= 24)
- *   "fused_tail"        [2] bf16 x4: 1 = one fused kernel for the high-resolution half of the tail backward (k_tail_bwd.hip); 2 = the same
+ *   "fused_tail"        [3] bf16 x4: 1 = one fused kernel for the high-resolution half of the tail backward (k_tail_bwd.hip); 2 = the same
  *                           and tail.3 expansion + PixelShuffle + GELU + tail conv of the FORWARD in one kernel (k_tail_fwd.hip): gelu(t2)
  *                           and gelu'(t2) are then never stored, the fused backward recomputes them per tile
- *                           (m2t_plan_query("stores_t2") tells whether ws:t2act / ws:t2der are written); 0 = the plain kernels
+ *                           (m2t_plan_query("stores_t2") tells whether ws:t2act / ws:t2der are written); 3 = 2 with the forward as the
+ *                           row-streaming kernel of round 4 (k_tail_stream.hip, same bits); 0 = the plain kernels
  *   "attn_bwd"          [3] bf16 attention backward: 0 = chunked kernels + halo gather + data-gradient GEMM, 1 = whole-window-
  *                           resident / wave-per-window kernels, 2 = 1 + the data gradient of the qkv projection inside the
  *                           C = 64 / 256 kernels (k_attn_res.hip), 3 = 2 + one kernel for the C = 16 branch's overlap-add,

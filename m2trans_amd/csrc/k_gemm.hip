@@ -377,9 +377,14 @@ tail_expand_kernel(const T* __restrict__ X, const T* __restrict__ Wp, const floa
         if (!ok[mt]) continue;
         float v[16], dv[16];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt) {
+          float b4[4], a4[4], d4[4];
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) gelu_tail_both<T>(acc[mt][nt][q4] + bv[4 * nt + q4], v[4 * nt + q4], dv[4 * nt + q4]);
+          for (int q4 = 0; q4 < 4; ++q4) b4[q4] = bv[4 * nt + q4];
+          gelu_tail_both4<T>(acc[mt][nt], b4, a4, d4);
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) { v[4 * nt + q4] = a4[q4]; dv[4 * nt + q4] = d4[q4]; }
+        }
         const long long pix = pixbase[mt] + (long long)i * Wd * r + j;
         store16f(Y + pix * 64 + 16 * g, v);
         store16f(Yd + pix * 64 + 16 * g, dv);

@@ -149,7 +149,8 @@ struct m2t_plan {
   bool use_side = true;
   bool debug_skip_side = false;        // timing experiments only: skip every parameter-gradient kernel (results are WRONG)
   bool use_fused_tail_bwd = true;      // x4 bf16: k_tail_bwd.hip instead of four HR kernels                              } option "fused_tail":
-  bool use_fused_tail_fwd = true;      // x4 bf16: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored } 0 / 1 / 2
+  bool use_fused_tail_fwd = true;      // x4 bf16: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored } 0 / 1 / 2 / 3
+  bool use_stream_tail_fwd = true;     // ... as the row-streaming kernel (k_tail_stream.hip, round 4: 152 vs 229 us, same bits); 2 = the 16x16-tile kernel
                                        // (with bf16 mode's exp2 / rcp GELU: 5.30 vs 5.34 ms per step and 1.6 GB less HBM traffic;
                                        // with the erf form of round 2 it was 1 % slower)
   int gate_branch = -1;                // side-stream gate: -1 ungated (a branch's side work follows its attention launch), else the branch (3..0)
@@ -397,7 +398,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "side_stream") return p->use_side;
     if (o == "gate_branch") return p->gate_branch + 1000;      // (offset: -1 is the "unknown key" value of this function)
     if (o == "wgrad_big_tiles") return p->wgrad_big_tiles + 1000;
-    if (o == "fused_tail") return (p->scale == 4 && p->dt != M2T_F32) ? (p->use_fused_tail_bwd ? (p->use_fused_tail_fwd ? 2 : 1) : 0) : 0;
+    if (o == "fused_tail") return (p->scale == 4 && p->dt != M2T_F32) ? (p->use_fused_tail_bwd ? (p->use_fused_tail_fwd ? (p->use_stream_tail_fwd ? 3 : 2) : 1) : 0) : 0;
     if (o == "attn_bwd") return p->dt == M2T_F32 ? 0 : (p->use_resident_attn_bwd ? (p->use_fused_qkv_dgrad ? (p->use_c16_prep ? 3 : 2) : 1) : 0);
     if (o == "conv_rows") return p->dt != M2T_F32 ? p->use_conv_rows : 0;
     if (o == "fused_conv_bwd") return p->dt != M2T_F32 && p->use_fused_conv_bwd && conv3x3_c64_bwd_fusable(p->B, p->H, p->W);
@@ -511,8 +512,12 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
   const float* wlast = params + p->poff.at(s == 4 ? "tail.6.weight" : "tail.3.weight");
   if (s == 4 && dt != M2T_F32 && p->use_fused_tail_fwd && p->use_fused_tail_bwd) {
     M2TProfScope ps(M2T_PROF_TAIL_FWD_FUSED, st);
-    CK(launch_tail_fwd_fused(WSP("t1act"), packed_ptr(p, workspace, "t3"), params + p->poff.at("tail.3.bias"), wlast, (float*)WSP("srpre"),
-                             B, p->Hsp, p->Wsp, st));
+    if (p->use_stream_tail_fwd)
+      CK(launch_tail_fwd_stream(WSP("t1act"), 0, packed_ptr(p, workspace, "t3"), params + p->poff.at("tail.3.bias"), wlast, (float*)WSP("srpre"),
+                                B, 2 * H, 2 * W, 2, 0, st));
+    else
+      CK(launch_tail_fwd_fused(WSP("t1act"), packed_ptr(p, workspace, "t3"), params + p->poff.at("tail.3.bias"), wlast, (float*)WSP("srpre"),
+                               B, p->Hsp, p->Wsp, st));
   } else {
   if (s == 4) {
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st);
@@ -962,8 +967,8 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }
   if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
   if (k == "fused_tail") {
-    if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_tail: 0..2");
-    p->use_fused_tail_bwd = value >= 1; p->use_fused_tail_fwd = value == 2; p->have_acts = false; return 0;
+    if (value < 0 || value > 3) return m2t_set_error(M2T_ERR_ARG, "fused_tail: 0..3");
+    p->use_fused_tail_bwd = value >= 1; p->use_fused_tail_fwd = value >= 2; p->use_stream_tail_fwd = value == 3; p->have_acts = false; return 0;
   }
   if (k == "attn_bwd") {
     if (value < 0 || value > 3) return m2t_set_error(M2T_ERR_ARG, "attn_bwd: 0..3");

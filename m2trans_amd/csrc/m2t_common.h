@@ -182,29 +182,109 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 #define M2T_GELU_A 1.59484566f
 #define M2T_GELU_B 7.40076173e-2f
 #define M2T_GELU_C -6.95025211e-4f
-__device__ __forceinline__ void gelu_fast_both(float x, float& act, float& der) {
-  const float tc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
-  const float t2 = tc * tc;
-  const float u = fmaf(fmaf(M2T_GELU_C, t2, M2T_GELU_B), t2, M2T_GELU_A);
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * (tc * u));      // exp(-z), z = t u(t^2)
-  const float s = __builtin_amdgcn_rcpf(1.0f + e);                               // sigma(z)
+// the same coefficients times -log2(e): exp(-z) = exp2(t (A2 + B2 t^2 + C2 t^4)) without a separate scaling multiply
+#define M2T_GELU_A2 (-1.4426950408889634f * M2T_GELU_A)
+#define M2T_GELU_B2 (-1.4426950408889634f * M2T_GELU_B)
+#define M2T_GELU_C2 (-1.4426950408889634f * M2T_GELU_C)
+// Two values at once.  A wave64 fp32 VALU instruction takes 4 cycles on gfx950 and the packed forms (v_pk_mul_f32, v_pk_add_f32,
+// v_pk_fma_f32) process two values per lane in the same 4: the tail kernels are bound by exactly this arithmetic (measured with
+// s_memtime stamps, round 4), so the polynomial part is written on float2 -- 3 packed + 3 scalar (med3, exp2, rcp) issue slots per
+// value instead of 9 scalar ones; with the derivative 5.5 + 3 instead of 15.  Element-wise IEEE operations: the scalar wrappers
+// below give the same bits.
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ void gelu_fast_core2(f32x2 x, f32x2& tc, f32x2& t2, f32x2& e, f32x2& s) {
+  tc[0] = __builtin_amdgcn_fmed3f(x[0], -8.0f, 8.0f);
+  tc[1] = __builtin_amdgcn_fmed3f(x[1], -8.0f, 8.0f);
+  t2 = tc * tc;
+  const f32x2 u = pk_fma(pk_fma((f32x2){M2T_GELU_C2, M2T_GELU_C2}, t2, (f32x2){M2T_GELU_B2, M2T_GELU_B2}), t2, (f32x2){M2T_GELU_A2, M2T_GELU_A2});
+  const f32x2 z = tc * u;                                                          // -log2(e) t u(t^2)
+  e[0] = __builtin_amdgcn_exp2f(z[0]);                                             // exp(-t u)
+  e[1] = __builtin_amdgcn_exp2f(z[1]);
+  const f32x2 d = e + (f32x2){1.0f, 1.0f};
+  s[0] = __builtin_amdgcn_rcpf(d[0]);                                              // sigma(t u)
+  s[1] = __builtin_amdgcn_rcpf(d[1]);
+}
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+  f32x2 tc, t2, e, s;
+  gelu_fast_core2(x, tc, t2, e, s);
+  return x * s;
+}
+__device__ __forceinline__ void gelu_fast_both2(f32x2 x, f32x2& act, f32x2& der) {
+  f32x2 tc, t2, e, s;
+  gelu_fast_core2(x, tc, t2, e, s);
   act = x * s;
-  const float du = fmaf(fmaf(5.0f * M2T_GELU_C, t2, 3.0f * M2T_GELU_B), t2, M2T_GELU_A);
-  der = fmaf(act * (e * s), du, s);                                              // 1 - s = e s
+  const f32x2 du = pk_fma(pk_fma((f32x2){5.0f * M2T_GELU_C, 5.0f * M2T_GELU_C}, t2, (f32x2){3.0f * M2T_GELU_B, 3.0f * M2T_GELU_B}), t2,
+                          (f32x2){M2T_GELU_A, M2T_GELU_A});
+  der = pk_fma(act * (e * s), du, s);                                              // s + t s (1 - s) u'(t),  1 - s = e s
 }
-__device__ __forceinline__ float gelu_fast(float x) {
-  const float tc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
-  const float t2 = tc * tc;
-  const float u = fmaf(fmaf(M2T_GELU_C, t2, M2T_GELU_B), t2, M2T_GELU_A);
-  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * (tc * u));
-  return x * __builtin_amdgcn_rcpf(1.0f + e);
+__device__ __forceinline__ void gelu_fast_both(float x, float& act, float& der) {
+  f32x2 a, d;
+  gelu_fast_both2((f32x2){x, x}, a, d);
+  act = a[0]; der = d[0];
 }
+__device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2((f32x2){x, x})[0]; }
 // the tail's activation by storage type: exact (erf) for fp32 parity mode, the approximation for bf16 storage
 template <typename T> __device__ __forceinline__ void gelu_tail_both(float x, float& act, float& der) {
   if constexpr (sizeof(T) == 2) gelu_fast_both(x, act, der); else gelu_erf_both(x, act, der);
 }
 template <typename T> __device__ __forceinline__ float gelu_tail(float x) {
   if constexpr (sizeof(T) == 2) return gelu_fast(x); else return gelu_erf(x);
+}
+// four values (one accumulator tile's registers of a lane) + their bias: act (and der) by storage type
+template <typename T> __device__ __forceinline__ void gelu_tail4(const f32x4& acc, const float (&bias)[4], float (&act)[4]) {
+  if constexpr (sizeof(T) == 2) {
+    const f32x2 a0 = gelu_fast2((f32x2){acc[0], acc[1]} + (f32x2){bias[0], bias[1]});
+    const f32x2 a1 = gelu_fast2((f32x2){acc[2], acc[3]} + (f32x2){bias[2], bias[3]});
+    act[0] = a0[0]; act[1] = a0[1]; act[2] = a1[0]; act[3] = a1[1];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) act[r] = gelu_erf(acc[r] + bias[r]);
+  }
+}
+// eight values = the two accumulator tiles whose rows interleave to 8 consecutive channels (k_tail_stream.hip), in STAGES over the
+// four pairs: independent transcendentals sit next to each other, so hipcc needs no s_nop behind each v_exp / v_rcp (a wait
+// state is due before a VALU instruction reads a transcendental's result; in the pair-by-pair form it filled them with 66 s_nop
+// per step of the row-streaming kernel, which is bound by instruction issue).  Same element-wise operations: same bits.
+template <typename T> __device__ __forceinline__ void gelu_tail8(const f32x4& lo, const f32x4& hi, const f32x4& blo, const f32x4& bhi, float (&act)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    f32x2 x[4] = {(f32x2){lo[0], lo[1]} + (f32x2){blo[0], blo[1]}, (f32x2){lo[2], lo[3]} + (f32x2){blo[2], blo[3]},
+                  (f32x2){hi[0], hi[1]} + (f32x2){bhi[0], bhi[1]}, (f32x2){hi[2], hi[3]} + (f32x2){bhi[2], bhi[3]}};
+    f32x2 z[4], e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      z[i][0] = __builtin_amdgcn_fmed3f(x[i][0], -8.0f, 8.0f);
+      z[i][1] = __builtin_amdgcn_fmed3f(x[i][1], -8.0f, 8.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 t2 = z[i] * z[i];
+      const f32x2 u = pk_fma(pk_fma((f32x2){M2T_GELU_C2, M2T_GELU_C2}, t2, (f32x2){M2T_GELU_B2, M2T_GELU_B2}), t2, (f32x2){M2T_GELU_A2, M2T_GELU_A2});
+      z[i] = z[i] * u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { e[i][0] = __builtin_amdgcn_exp2f(z[i][0]); e[i][1] = __builtin_amdgcn_exp2f(z[i][1]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = e[i] + (f32x2){1.0f, 1.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { z[i][0] = __builtin_amdgcn_rcpf(e[i][0]); z[i][1] = __builtin_amdgcn_rcpf(e[i][1]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const f32x2 a = x[i] * z[i]; act[2 * i] = a[0]; act[2 * i + 1] = a[1]; }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { act[r] = gelu_erf(lo[r] + blo[r]); act[4 + r] = gelu_erf(hi[r] + bhi[r]); }
+  }
+}
+template <typename T> __device__ __forceinline__ void gelu_tail_both4(const f32x4& acc, const float (&bias)[4], float (&act)[4], float (&der)[4]) {
+  if constexpr (sizeof(T) == 2) {
+    f32x2 a0, d0, a1, d1;
+    gelu_fast_both2((f32x2){acc[0], acc[1]} + (f32x2){bias[0], bias[1]}, a0, d0);
+    gelu_fast_both2((f32x2){acc[2], acc[3]} + (f32x2){bias[2], bias[3]}, a1, d1);
+    act[0] = a0[0]; act[1] = a0[1]; act[2] = a1[0]; act[3] = a1[1];
+    der[0] = d0[0]; der[1] = d0[1]; der[2] = d1[0]; der[3] = d1[1];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gelu_erf_both(acc[r] + bias[r], act[r], der[r]);
+  }
 }
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {   // torch 'reflect' (no edge repeat)

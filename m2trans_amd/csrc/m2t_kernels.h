@@ -163,6 +163,12 @@ int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* 
 int launch_tail_fwd_fused(const void* a1, const void* w3p, const float* b3, const float* wf, float* out, int B, int H, int W,
                           hipStream_t st);
 
+// ---- k_tail_stream.hip -------------------------------------------------------------------
+// bf16: expansion 1x1 (64 -> 64 R^2) + PixelShuffle(R) + GELU + tail conv as ONE row-streaming kernel; R = 2 (x4's tail.3 stage on the
+// NHWC mid-resolution map, or x2's tail.0 stage on the P64 body output) or 3 (x3).  seg_rows <= 2: default segment length.
+int launch_tail_fwd_stream(const void* a, int a_is_p64, const void* wp, const float* bias, const float* wf, float* out, int B, int Hi,
+                           int Wi, int R, int seg_rows, hipStream_t st);
+
 // ---- k_tail_bwd.hip ----------------------------------------------------------------------
 // x4 tail, bf16: tail conv data + weight gradient, GELU backward, tail.3 data + weight + bias gradient in one pass
 // over the stored activation / derivative tensors (g(t2) never reaches HBM).  Slabs: wf [n][32][64], w3 [n][256][64],

@@ -39,7 +39,7 @@ KERNEL_OF = {
     "attn_fused_c64": "window_attn_fused_fwd_kernel<C=64,L=1> (qkv projection + window attention + IWT/residual)",
     "attn_fused_c256": "window_attn_fused_fwd_kernel<C=256,L=2> (qkv projection + window attention + IWT^2/residual)",
     "attn_fused_c16": "window_attn_fused_c16_fwd_kernel (InstanceNorm apply + qkv projection + window attention + residual, wave per window)",
-    "tail_fwd_fused": "tail_fwd_fused_kernel (tail.3 1x1 expansion + PixelShuffle + GELU + tail conv)",
+    "tail_fwd_fused": "tail_fwd_stream_kernel<R=2> (tail.3 1x1 expansion + PixelShuffle + GELU + tail conv, row-streaming)",
     "conv3x3_bwd": "conv3x3_c64_bwd_rows_kernel (64->64 3x3 conv: data gradient + weight / bias gradient in one row-streaming pass)",
 }
 KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these categories
@@ -177,7 +177,7 @@ def plan_options(plan) -> dict:
     """The kernel-selection options in force on a plan (m2t_plan_query("opt:<key>")): which kernels ran decides which
     rows of `algorithmic_work` apply."""
     o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_c16_fwd", "conv_rows", "fused_conv_bwd")}
-    o["fused_tail_fwd"] = plan.query("opt:fused_tail") == 2
+    o["fused_tail_fwd"] = plan.query("opt:fused_tail") >= 2
     o["c16_recompute"] = plan.query("opt:fused_c16_fwd") == 2
     o["c64_recompute"] = plan.query("opt:fused_attn_fwd") == 2
     o["fused_qkv_dgrad"] = plan.query("opt:attn_bwd") >= 2

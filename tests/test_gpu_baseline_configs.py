@@ -113,7 +113,7 @@ def check_vs_oracle(scale, lr, B, dtype, nb=8, verbose=True):
             assert torch.equal(sr1, sr) and loss1 == loss and torch.equal(grads1, grads), "fused forward tail is not bit-identical"
         trace = hip_forward_trace(plan, scale, nb, B, H, W)
         if scale == 4:
-            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_tail", 2), "m2t_set_option")
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_tail", 3), "m2t_set_option")
         rep = {}
         loss_o, sr_o, g_o = O.l1_loss_and_grads(x, hr, p, scale, nb, emulate_bf16=True, force=trace, stage_report=rep)
         rows = grad_table(model, grads, g_o)

@@ -175,7 +175,7 @@ def test_bf16_fast_kernels_match_plain_kernels():
     for fast in (1, 0):
         model, _ = build_model(scale, nb, "bf16")
         plan = model._plan_for(x)
-        for key, val in ((b"attn_bwd", 3 if fast else 0), (b"gate_branch", -1), (b"fused_conv_bwd", fast), (b"side_stream", fast), (b"fused_tail", 2 if fast else 0)):
+        for key, val in ((b"attn_bwd", 3 if fast else 0), (b"gate_branch", -1), (b"fused_conv_bwd", fast), (b"side_stream", fast), (b"fused_tail", 3 if fast else 0)):
             _lib.check(_lib.load().m2t_set_option(plan.handle, key, val), "m2t_set_option")
         sr = model(x)
         torch.nn.L1Loss()(sr, hr).backward()
@@ -700,23 +700,26 @@ def test_fused_conv_backward_matches_the_two_kernel_path():
 
 
 def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():
-    """bf16 x4: tail.3 expansion + PixelShuffle + GELU + tail conv in one kernel (gelu(t2) / gelu'(t2) never stored) and the
-    fused tail backward that recomputes them per tile, against the kernels that store and re-read them.  Same operand
-    fragments, k order, bias add, erf evaluation and tap summation -> the output and EVERY gradient must agree bit for
-    bit.  Sizes: a reflect-padded 40x56 input (64x64 padded: border tiles only) and 128x96 (interior tiles too)."""
+    """bf16 x4: tail.3 expansion + PixelShuffle + GELU + tail conv in one kernel (gelu(t2) / gelu'(t2) never stored) -- the
+    row-streaming kernel of round 4 (option fused_tail = 3, default) and the 16x16-tile kernel it replaced (= 2) -- and the
+    fused tail backward that recomputes them per tile, against the kernels that store and re-read them (= 1).  Same operand
+    fragments, k order, bias add, GELU evaluation and tap summation -> the output and EVERY gradient must agree bit for
+    bit.  Sizes: a reflect-padded 40x56 input (64x64 padded: border strips / tiles only), 128x96 (interior too) and 72x200
+    (several row segments and strips, the last ones clamped)."""
     from m2trans_amd import _lib
-    for (B, H, W) in ((2, 40, 56), (3, 128, 96)):
+    for (B, H, W) in ((2, 40, 56), (3, 128, 96), (1, 72, 200)):
         scale, nb = 4, 1
         x = O.closed_form_image(B, 3, H, W).cuda()
         hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
         outs = []
-        for fused in (1, 0):
+        for fused in (3, 2, 1):
             model, _ = build_model(scale, nb, "bf16")
             plan = model._plan_for(x)
-            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_tail", 2 if fused else 1), "m2t_set_option")
-            assert plan.query("stores_t2") == 1 - fused
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_tail", fused), "m2t_set_option")
+            assert plan.query("opt:fused_tail") == fused and plan.query("stores_t2") == (1 if fused == 1 else 0)
             sr = model(x)
             torch.nn.L1Loss()(sr, hr).backward()
             outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone()))
-        assert torch.equal(outs[0][0], outs[1][0]), (B, H, W)
-        assert torch.equal(outs[0][1], outs[1][1]), (B, H, W)
+        for other in outs[1:]:
+            assert torch.equal(outs[0][0], other[0]), (B, H, W)
+            assert torch.equal(outs[0][1], other[1]), (B, H, W)
