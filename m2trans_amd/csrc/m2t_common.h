@@ -274,6 +274,44 @@ template <typename T> __device__ __forceinline__ void gelu_tail8(const f32x4& lo
     for (int r = 0; r < 4; ++r) { act[r] = gelu_erf(lo[r] + blo[r]); act[4 + r] = gelu_erf(hi[r] + bhi[r]); }
   }
 }
+// ... and with the derivative (the recomputing backward kernels): act = gelu(x), der = gelu'(x), staged the same way
+template <typename T> __device__ __forceinline__ void gelu_tail_both8(const f32x4& lo, const f32x4& hi, const f32x4& blo, const f32x4& bhi, float (&act)[8],
+                                                                     float (&der)[8]) {
+  if constexpr (sizeof(T) == 2) {
+    f32x2 x[4] = {(f32x2){lo[0], lo[1]} + (f32x2){blo[0], blo[1]}, (f32x2){lo[2], lo[3]} + (f32x2){blo[2], blo[3]},
+                  (f32x2){hi[0], hi[1]} + (f32x2){bhi[0], bhi[1]}, (f32x2){hi[2], hi[3]} + (f32x2){bhi[2], bhi[3]}};
+    f32x2 t2[4], z[4], e[4], s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      z[i][0] = __builtin_amdgcn_fmed3f(x[i][0], -8.0f, 8.0f);
+      z[i][1] = __builtin_amdgcn_fmed3f(x[i][1], -8.0f, 8.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      t2[i] = z[i] * z[i];
+      const f32x2 u = pk_fma(pk_fma((f32x2){M2T_GELU_C2, M2T_GELU_C2}, t2[i], (f32x2){M2T_GELU_B2, M2T_GELU_B2}), t2[i], (f32x2){M2T_GELU_A2, M2T_GELU_A2});
+      z[i] = z[i] * u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { e[i][0] = __builtin_amdgcn_exp2f(z[i][0]); e[i][1] = __builtin_amdgcn_exp2f(z[i][1]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = e[i] + (f32x2){1.0f, 1.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s[i][0] = __builtin_amdgcn_rcpf(z[i][0]); s[i][1] = __builtin_amdgcn_rcpf(z[i][1]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x2 a = x[i] * s[i];
+      const f32x2 du = pk_fma(pk_fma((f32x2){5.0f * M2T_GELU_C, 5.0f * M2T_GELU_C}, t2[i], (f32x2){3.0f * M2T_GELU_B, 3.0f * M2T_GELU_B}), t2[i],
+                              (f32x2){M2T_GELU_A, M2T_GELU_A});
+      const f32x2 d = pk_fma(a * (e[i] * s[i]), du, s[i]);
+      act[2 * i] = a[0]; act[2 * i + 1] = a[1];
+      der[2 * i] = d[0]; der[2 * i + 1] = d[1];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { gelu_erf_both(lo[r] + blo[r], act[r], der[r]); gelu_erf_both(hi[r] + bhi[r], act[4 + r], der[4 + r]); }
+  }
+}
 template <typename T> __device__ __forceinline__ void gelu_tail_both4(const f32x4& acc, const float (&bias)[4], float (&act)[4], float (&der)[4]) {
   if constexpr (sizeof(T) == 2) {
     f32x2 a0, d0, a1, d1;

@@ -18,6 +18,14 @@ __device__ unsigned long long* g_stamps = nullptr;
 __device__ int g_stamp_tile;
 #define M2T_TAIL_STAMP(i) do { const long long it__ = (t - t0) / tstep; if (g_stamps && it__ >= 2 && it__ < 6 && threadIdx.x == 64 * STAMP_WAVE) g_stamps[((size_t)blockIdx.x * 4 + (it__ - 2)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #endif
+#ifdef BSTAMPS
+__device__ unsigned long long* g_bstamps = nullptr;
+#ifndef BSTAMP_WAVE
+#define BSTAMP_WAVE 0
+#endif
+// steps 5 .. 8 of the first task of every workgroup, wave BSTAMP_WAVE
+#define BS_STAMP(i) do { if (g_bstamps && task == (int)xcd_block_index() && s >= 5 && s < 9 && threadIdx.x == 64 * BSTAMP_WAVE) g_bstamps[((size_t)blockIdx.x * 4 + (s - 5)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #ifndef TAIL_FWD_SRC
 #define TAIL_FWD_SRC "../m2trans_amd/csrc/k_tail_fwd.hip"
 #endif
@@ -29,6 +37,9 @@ __device__ int g_stamp_tile;
 #ifndef NO_STREAM
 #define TS_BENCH_HOOKS
 #include "../m2trans_amd/csrc/k_tail_stream.hip"
+#ifdef WITH_BWD_STREAM      // the row-streaming backward experiment of round 4 (correct, slower than the tile kernel: profiles/README.md)
+#include "k_tail_bwd_stream_r04.hip.txt"
+#endif
 #endif
 int m2t_set_hip_error(hipError_t e, const char* f, int l) { fprintf(stderr, "HIP error %d %s at %s:%d\n", (int)e, hipGetErrorString(e), f, l); return (int)e; }
 int m2t_set_error(int c, const char* m) { fprintf(stderr, "error %d %s\n", c, m); return c; }
@@ -104,6 +115,60 @@ static int run_case(int B, int Hlr, int Wlr, bool timing) {
   double osum = 0; for (float v : ho) osum += fabs(v);
   printf("B=%d LR %dx%d: out hash %016llx (|out| %.6e)  gt1 hash %016llx  slabs=%d dWf %.9e/%.9e dW3 %.9e/%.9e db3 %.9e/%.9e\n", B, Hlr, Wlr, fnv(ho.data(), nhr * 4), osum,
          fnv(hgt.data(), nmid * 2), ns, a1, p1, a2, p2, a3, p3);
+#ifdef WITH_BWD_STREAM
+  {
+    // streaming backward against the tile kernel: g(t1) bit for bit, the three parameter gradients to fp32 summation order
+    std::vector<unsigned short> hgt2(nmid);
+    CKH(hipMemset(dgt1, 0xee, nmid * 2));
+    int ns2 = 0;
+    if (launch_tail_bwd_stream(dg, dwf, da1, dd1, dw3, dw3t, db3, dgt1, swf, sw3, sb3, &ns2, B, H, W, st)) exit(2);
+    CKH(hipStreamSynchronize(st));
+    CKH(hipMemcpy(hgt2.data(), dgt1, nmid * 2, hipMemcpyDeviceToHost));
+    size_t bad = 0, first = 0;
+    for (size_t i = 0; i < nmid; ++i) if (hgt[i] != hgt2[i]) { if (!bad) first = i; ++bad; }
+    std::vector<float> k1((size_t)ns2 * 32 * 64), k2((size_t)ns2 * 256 * 64), k3((size_t)ns2 * 256);
+    CKH(hipMemcpy(k1.data(), swf, k1.size() * 4, hipMemcpyDeviceToHost)); CKH(hipMemcpy(k2.data(), sw3, k2.size() * 4, hipMemcpyDeviceToHost));
+    CKH(hipMemcpy(k3.data(), sb3, k3.size() * 4, hipMemcpyDeviceToHost));
+    auto cmp = [&](const std::vector<float>& o, const std::vector<float>& n_, size_t n) {
+      double num = 0, den = 0;
+      for (size_t i = 0; i < n; ++i) {
+        double a = 0, b = 0;
+        for (int k = 0; k < ns; ++k) a += o[(size_t)k * n + i];
+        for (int k = 0; k < ns2; ++k) b += n_[(size_t)k * n + i];
+        num += (a - b) * (a - b); den += a * a;
+      }
+      return sqrt(num / (den + 1e-300));
+    };
+    printf("   stream bwd: g(t1) %zu of %zu differ", bad, nmid);
+    if (bad) printf(" (first %zu: pixel %zu ch %zu: %04x vs %04x)", first, first / 64, first % 64, hgt[first], hgt2[first]);
+    printf("; slabs %d; rel diff dWf %.2e dW3 %.2e db3 %.2e\n", ns2, cmp(h1, k1, 32 * 64), cmp(h2, k2, 256 * 64), cmp(h3, k3, 256));
+    if (timing) {
+      auto bs = [&]() { int q; if (launch_tail_bwd_stream(dg, dwf, da1, dd1, dw3, dw3t, db3, dgt1, swf, sw3, sb3, &q, B, H, W, st)) exit(2); };
+      printf("   tail_bwd_stream %.1f us\n", time_it(st, 30, bs));
+#ifdef BSTAMPS
+      {
+        unsigned long long* ds; const size_t nst = (size_t)512 * 4 * 16;
+        CKH(hipMalloc(&ds, nst * 8)); CKH(hipMemset(ds, 0, nst * 8));
+        CKH(hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), &ds, sizeof(ds)));
+        bs(); CKH(hipStreamSynchronize(st));
+        std::vector<unsigned long long> hs(nst);
+        CKH(hipMemcpy(hs.data(), ds, nst * 8, hipMemcpyDeviceToHost));
+        double acc[16] = {0}; int cnt = 0;
+        for (int blk = 0; blk < 512; ++blk) for (int it = 0; it < 3; ++it) {
+          const unsigned long long* a = &hs[((size_t)blk * 4 + it) * 16], *nx = &hs[((size_t)blk * 4 + it + 1) * 16];
+          if (!a[0] || !nx[0]) continue;
+          for (int i = 0; i < 8; ++i) acc[i] += (double)(a[i + 1] - a[i]);
+          acc[8] += (double)(nx[0] - a[8]); acc[9] += (double)(nx[0] - a[0]); ++cnt;
+        }
+        printf("   bwd stream stamps (wave %d, mean cycles over %d steps): ", BSTAMP_WAVE, cnt);
+        for (int i = 0; i < 10; ++i) printf("%s%.0f", i ? " | " : "", acc[i] / std::max(cnt, 1));
+        printf("\n   [0 loads+MFMA t2 | 1 Geff gather | 2 GELU, g(a2), g(t2), stores | 3 barrier 1 | 4 ring write, dW3 | 5 dWf | 6 g(t1) | 7 barrier 2 | 8 loop | 9 total]\n");
+        unsigned long long* z = nullptr; CKH(hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), &z, sizeof(z)));
+      }
+#endif
+    }
+  }
+#endif
 #ifndef NO_STREAM
   for (int segr : {0, 24, 64}) {
     CKH(hipMemset(dout, 0xff, nhr * 4));
