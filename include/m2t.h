@@ -74,8 +74,8 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           C = 64 / 256 kernels (k_attn_res.hip), 3 = 2 + one kernel for the C = 16 branch's overlap-add,
  *                           projection data gradient and branch_prep_bwd (k_attn_c16.hip; bit-identical to 2)
  *   "conv_rows"         [1] bf16 conv3x3 64 -> 64 (forward and data gradient): row-streaming kernel fed by LDS-DMA with the weights in
- *                           registers (k_conv.hip); 0 = the 8 x 16 tile kernel it replaced (3 / 4: DMA-depth / epilogue variants kept for
- *                           A/B).  All bit-identical
+ *                           registers (k_conv.hip); 0 = the 8 x 16 tile kernel it replaced (also the fallback for widths the strip
+ *                           geometry does not divide).  Bit-identical
  *   "fused_conv_bwd"    [1] bf16 conv3x3 64 -> 64 backward: data gradient and weight / bias gradient in ONE row-streaming pass over the
  *                           output gradient on the main stream (k_conv.hip; data gradient bit-identical, weight gradient the same
  *                           products summed in a different order); 0 = data gradient kernel + weight-gradient kernel on the side stream

@@ -1068,22 +1068,12 @@ int launch_conv3x3_c64(int dt, const void* x, const void* wp, const float* bias,
     if (rs > 0) {
       int rc;
       // LDS per workgroup (two per CU): ring 46 080 B + residual slots: <= 79 104 B
-      // DMA depth 2 (ring of 8 rows = 36 KB + residual slots; LDS per workgroup <= 61 KB): same-box, stand-alone, batch 16:
-      // 27.8 us against 29.4 for depth 3 and 28.8 for depth 3 with the epilogue of step s - 1 issued between the products of
-      // step s (variants 3 / 4, kept for A/B); inside the two-stream step all of them tie
-      if (variant == 3) {
-        if (res2) rc = go_c3r<2, 3, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
-        else if (res1) rc = go_c3r<1, 3, 3>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st, stat_part);
-        else rc = go_c3r<0, 3, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
-      } else if (variant == 4) {
-        if (res2) rc = go_c3r<2, 2, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
-        else if (res1) rc = go_c3r<1, 2, 2, true>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st, stat_part);
-        else rc = go_c3r<0, 2, 1, true>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
-      } else {
-        if (res2) rc = go_c3r<2, 2, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
-        else if (res1) rc = go_c3r<1, 2, 2>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st, stat_part);
-        else rc = go_c3r<0, 2, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
-      }
+      // DMA depth 2 (ring of 8 rows = 36 KB + residual slots; LDS per workgroup <= 61 KB).  (Depth 3 and the pipelined-epilogue
+      // form measured 29.4 / 28.8 us against 27.8 stand-alone and tied inside the step: their dispatch was retired in round 4,
+      // numbers in profiles/README.md)
+      if (res2) rc = go_c3r<2, 2, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
+      else if (res1) rc = go_c3r<1, 2, 2>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st, stat_part);
+      else rc = go_c3r<0, 2, 1>(x, wrows, bias, res1, res2, y, zero_page, B, H, W, rs, st);
       if (rc) return rc;
       M2T_LAUNCH_CHECK();
       return 0;

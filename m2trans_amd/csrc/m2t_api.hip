@@ -160,7 +160,7 @@ struct m2t_plan {
                                        // still waited for the side stream once per BRANCH the gate paid: round 2: 1 = 5.49, 2 = 5.60, ungated 5.64)
   bool use_resident_attn_bwd = true;   // bf16: whole-window-resident attention backward (k_attn_res.hip)         } option "attn_bwd":
   bool use_fused_conv_bwd = true;      // bf16 conv3x3 64 -> 64 backward: data + weight / bias gradient in one row-streaming pass (k_conv.hip)
-  int use_conv_rows = 1;               // bf16 conv3x3 64 -> 64: row-streaming LDS-DMA kernel (k_conv.hip); 0 = the tile kernel; 3 / 4: A/B variants
+  int use_conv_rows = 1;               // bf16 conv3x3 64 -> 64: row-streaming LDS-DMA kernel (k_conv.hip); 0 = the tile kernel
   int wgrad_big_tiles = -1;            // C = 256 qkv weight gradient: 128 x 128 output tiles (k_gemm.hip); value = target workgroups,
                                        // 0 = off, -1 = auto: 256 from 24 576 rows on (batch 32: 9.82 vs 9.93 ms; batch 16: 5.53 vs 5.49)
   bool use_fused_qkv_dgrad = true;     // bf16, C = 64 / 256: projection data gradient inside that kernel                } 0 .. 3
@@ -498,7 +498,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     }
     // x = feed_forward(xc) + x (:164); the last block also folds in `res + x` (:70)
     { M2TProfScope ps(M2T_PROF_CONV3_FWD, st);
-      const int variant = p->use_conv_rows >= 2 ? p->use_conv_rows : (p->use_conv_rows ? 0 : 1);
+      const int variant = p->use_conv_rows ? 0 : 1;
       stat_partials = (b < p->nb - 1) ? conv3x3_c64_stat_partials(dt, B, H, W, variant) : 0;
       CK(launch_conv3x3_c64(dt, xc, packed_ptr(p, workspace, k + "wf"), params + p->poff.at(pre + "feed_forward.0.bias"), X,
                             (b == p->nb - 1) ? WSP("X0") : nullptr, WSP("X" + std::to_string(b + 1)), B, H, W, st,
@@ -814,7 +814,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     }
     if (!fuse_conv)
     { M2TProfScope ps(M2T_PROF_CONV3_DGRAD, st); CK(launch_conv3x3_c64(dt, gy, packed_ptr(p, workspace, k + "wfT"), nullptr, nullptr, nullptr, gxc, B, H, W, st,
-                                                                        packed_ptr(p, workspace, k + "wfTR"), WSP("zero_page"), p->use_conv_rows >= 2 ? p->use_conv_rows : (p->use_conv_rows ? 0 : 1))); }
+                                                                        packed_ptr(p, workspace, k + "wfTR"), WSP("zero_page"), p->use_conv_rows ? 0 : 1)); }
     for (int i = 3; i >= 0; --i) {
       const int C = BR_C[i], L = BR_L[i];
       const int h = H >> L, w = W >> L;
@@ -975,7 +975,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
     // (which of qkv1 / qkv2 the forward stores depends on this option: activations of a forward run under another value are unusable)
     p->use_resident_attn_bwd = value >= 1; p->use_fused_qkv_dgrad = value >= 2; p->use_c16_prep = value == 3; p->have_acts = false; return 0;
   }
-  if (k == "conv_rows") { p->use_conv_rows = (int)value; return 0; }
+  if (k == "conv_rows") { if (value < 0 || value > 1) return m2t_set_error(M2T_ERR_ARG, "conv_rows: 0 / 1"); p->use_conv_rows = (int)value; return 0; }
   if (k == "fused_conv_bwd") { p->use_fused_conv_bwd = (value != 0); return 0; }
   if (k == "fused_attn_fwd") { if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_attn_fwd: 0..2"); p->use_fused_attn_fwd = (int)value; p->have_acts = false; return 0; }
   if (k == "fused_c16_fwd") { if (value < 0 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_c16_fwd: 0..2"); p->use_fused_c16_fwd = (int)value; p->have_acts = false; return 0; }

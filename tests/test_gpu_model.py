@@ -328,6 +328,69 @@ def test_training_drift_psnr_vs_oracle():
         assert abs(ps - ps_o) <= tol, (dt, ps, ps_o)
 
 
+@pytest.mark.parametrize("side", [1, 0])
+def test_whole_step_is_hip_graph_capturable_and_replays_the_eager_bits(side):
+    """include/m2t.h promises that every launch goes to the caller's stream (the backward's side stream is forked / joined with
+    events), so the whole step -- forward, L1 loss, two-stream backward, fused Adam -- can be captured in a HIP graph.  Capture one
+    step after a warm-up step (the first backward uploads its reduction table), replay it twice from a reset state and compare
+    parameters, moments and loss with two eager steps from the same state: identical bits."""
+    from m2trans_amd import _lib
+    from m2trans_amd.train_step import TrainStep
+    scale, nb, B, H0, W0 = 4, 2, 2, 64, 64
+    x = O.closed_form_image(B, 3, H0, W0).cuda()
+    hr = O.closed_form_image(B, 3, H0 * scale, W0 * scale, phase=0.7).cuda()
+
+    def fresh():
+        model, _ = build_model(scale, nb, "bf16")
+        ts = TrainStep(model, lr=1e-3, world_size=1)
+        plan = model._plan_for(x)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"side_stream", side), "m2t_set_option")
+        ts.step(x, hr)                                   # warm-up: plan, workspace, reduction table
+        torch.cuda.synchronize()
+        return model, ts
+
+    model_e, ts_e = fresh()
+    for _ in range(2):
+        ts_e.step(x, hr)
+    torch.cuda.synchronize()
+    want = (model_e.flat_params.clone(), ts_e.exp_avg.clone(), ts_e.exp_avg_sq.clone(), float(ts_e.loss))
+
+    model_g, ts_g = fresh()
+    state = (model_g.flat_params.clone(), ts_g.exp_avg.clone(), ts_g.exp_avg_sq.clone(), ts_g.step_count)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ts_g.step(x, hr)                                 # side-stream warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    # reset to the post-warm-up state, capture ONE step (step counter 2 -> bias correction of step 2), replay = steps 2 and 3?  The
+    # fused Adam takes the step number as an argument, so a captured step repeats ITS bias correction: compare like with like --
+    # eager reference below re-runs the same step number twice from the same state.
+    model_g.flat_params.copy_(state[0]); ts_g.exp_avg.copy_(state[1]); ts_g.exp_avg_sq.copy_(state[2]); ts_g.step_count = state[3]
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        ts_g.step(x, hr)
+    torch.cuda.synchronize()
+    captured_step = ts_g.step_count
+    model_g.flat_params.copy_(state[0]); ts_g.exp_avg.copy_(state[1]); ts_g.exp_avg_sq.copy_(state[2])
+    gr.replay()
+    torch.cuda.synchronize()
+    got1 = (model_g.flat_params.clone(), ts_g.exp_avg.clone(), ts_g.exp_avg_sq.clone(), float(ts_g.loss))
+    # eager: the same single step (same step number) from the same state
+    model_e.flat_params.copy_(state[0]); ts_e.exp_avg.copy_(state[1]); ts_e.exp_avg_sq.copy_(state[2]); ts_e.step_count = captured_step - 1
+    ts_e.step(x, hr)
+    torch.cuda.synchronize()
+    assert ts_e.step_count == captured_step
+    assert torch.equal(got1[0], model_e.flat_params) and torch.equal(got1[1], ts_e.exp_avg) and torch.equal(got1[2], ts_e.exp_avg_sq)
+    assert got1[3] == float(ts_e.loss)
+    # and a second replay from the same state gives the same bits again (no hidden host state in the captured work)
+    model_g.flat_params.copy_(state[0]); ts_g.exp_avg.copy_(state[1]); ts_g.exp_avg_sq.copy_(state[2])
+    gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(model_g.flat_params, got1[0]) and torch.equal(ts_g.exp_avg_sq, got1[2])
+    del want
+
+
 def test_training_is_bitwise_reproducible_with_the_two_stream_schedule():
     """No atomics anywhere and every cross-stream hand-over is an event: two runs of the same six bf16 steps (full
     depth, 128x128, side stream + gates + deferred reductions live) must end with bit-identical parameters and Adam
@@ -610,8 +673,8 @@ def test_c16_gather_projection_prep_kernel_is_bit_identical_to_the_three_kernels
 def test_row_streaming_conv3x3_is_bit_identical_to_the_tile_kernel():
     """bf16 3x3 conv 64 -> 64: the row-streaming kernel (LDS-DMA rings for the input and residual rows, weights in registers,
     option conv_rows, default) keeps the products and their order of the tile kernel: with the same InstanceNorm statistics the
-    whole step -- eight forward convs, eight data gradients -- agrees bit for bit between its three variants (DMA depth 2, depth 3,
-    depth 2 + pipelined epilogue), which also leave the statistics of their output as per-segment partials in the same order.
+    whole step -- eight forward convs, eight data gradients -- is reproduced bit for bit from run to run (the DMA-depth-3 and pipelined-
+    epilogue variants that were checked against it through round 3 were retired in round 4).
     The tile kernel's path takes the statistics with the two-stage kernel instead (another summation order: mean / rstd differ in the
     last bits), so against it the FIRST conv output, whose input statistics are common, must be identical and the step agree to
     bf16 noise.  Sizes: 128x128 batch 8 (256 segments of 32 rows), 96x160 batch 3 (5 strips, first / last at the image border) and
@@ -623,7 +686,7 @@ def test_row_streaming_conv3x3_is_bit_identical_to_the_tile_kernel():
         x = O.closed_form_image(B, 3, H, W).cuda()
         hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
         outs = []
-        for rows in (1, 3, 4, 0):          # default (DMA depth 2), depth 3, depth 2 + pipelined epilogue, tile kernel
+        for rows in (1, 1, 0):             # row-streaming kernel (twice: reproducible bits), tile kernel
             model, _ = build_model(scale, nb, "bf16")
             plan = model._plan_for(x)
             _lib.check(_lib.load().m2t_set_option(plan.handle, b"conv_rows", rows), "m2t_set_option")
@@ -635,10 +698,10 @@ def test_row_streaming_conv3x3_is_bit_identical_to_the_tile_kernel():
             Hp, Wp = plan.query("padded_h"), plan.query("padded_w")
             outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone(),
                          ws_nchw(plan, "X1", B, Hp, Wp, 64)))
-        for o in outs[1:3]:
+        for o in outs[1:2]:
             assert torch.equal(outs[0][0], o[0]), (B, H, W)
             assert torch.equal(outs[0][1], o[1]), (B, H, W)
-        tile = outs[3]
+        tile = outs[2]
         assert torch.equal(outs[0][2], tile[2]), (B, H, W)                      # first block: same statistics, same bits
         assert rms_rel(outs[0][0], tile[0]) < 5e-2, (B, H, W, rms_rel(outs[0][0], tile[0]))     # (as the other fused-vs-plain A/Bs: closed-form weights amplify last-bit flips)
         gd = float((outs[0][1].double() - tile[1].double()).norm()) / float(tile[1].double().norm())
