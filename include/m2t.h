@@ -231,6 +231,15 @@ int m2t_eval_metrics(const float* sr, const float* hr, int B, int H, int W, int 
 size_t m2t_eval_gmsd_scratch_bytes(int B);
 int m2t_eval_gmsd(const float* x, const float* y, int B, int H, int W, float data_range, void* scratch, double* out, void* stream);
 
+/* piq.fsim(hr, sr, data_range=1., reduction='none') of the same loop (test.py:95-96; piq 0.8.0 per environment.yml:118): FSIMc --
+ * k x k average pooling (k = max(1, round(min(H, W) / 256))), YIQ, phase congruency from a 4-orientation x 4-scale log-Gabor bank
+ * (explicit 2-D DFTs, any image size), Scharr gradient magnitude, chroma similarity, sum(S_L S_C^0.03 PC_m) / sum(PC_m).  fp64 on the
+ * device (k_fsim.hip).  x, y: float32 NCHW [B,3,H,W] on the device; out: double[B] on the device; scratch:
+ * m2t_eval_fsim_scratch_bytes(H, W) bytes (independent of B: image pairs are processed one after the other).
+ * The dependency is absent from the reference tree: PARITY UNPINNED, checked against oracle/fsim_oracle.py. */
+size_t m2t_eval_fsim_scratch_bytes(int H, int W);
+int m2t_eval_fsim(const float* x, const float* y, int B, int H, int W, float data_range, void* scratch, double* out, void* stream);
+
 /* ---- training input pipeline --------------------------------------------------------------------
  * datas/us1k.py:16-36 crop_patch + utils.py ndarray2tensor + the /255 of datas/us1k.py:169, for n samples at once,
  * cut out of uint8 HWC images that stay resident in device memory (lr_pool / hr_pool: the npy cache, back to back).

@@ -54,6 +54,8 @@ SIGNATURES = {
     "m2t_eval_metrics": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     "m2t_eval_gmsd_scratch_bytes": (C.c_size_t, [_i]),
     "m2t_eval_gmsd": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "m2t_eval_fsim_scratch_bytes": (C.c_size_t, [_i, _i]),
+    "m2t_eval_fsim": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     "m2t_crop_patches": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "m2t_image_to_tensor": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "m2t_box_mix": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),

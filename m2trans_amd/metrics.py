@@ -85,20 +85,43 @@ def gmsd_device(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> to
     return out
 
 
-def evaluate(model, pairs, scale: int, rgb_range: float = 1.0, with_gmsd: bool = False):
+def fsim_device(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
+    """``piq.fsim(x, y, data_range=data_range, reduction='none')`` (test.py:95; FSIMc, piq 0.8.0 defaults) on the device: [B,3,H,W]
+    float32 pairs -> float64 [B].  HIP kernels behind `m2t_eval_fsim` (k_fsim.hip); parity unpinned (`piq` is not vendored)."""
+    from . import _lib
+    if x.shape != y.shape or x.dim() != 4 or x.shape[1] != 3:
+        raise _lib.M2TError(f"expected two [B,3,H,W] tensors of equal shape, got {tuple(x.shape)} and {tuple(y.shape)}")
+    if not (x.is_cuda and y.is_cuda):
+        raise _lib.M2TError("fsim_device needs HIP device tensors")
+    lib = _lib.load()
+    x, y = x.contiguous().float(), y.contiguous().float()
+    B, _, H, W = x.shape
+    nbytes = lib.m2t_eval_fsim_scratch_bytes(H, W)
+    if nbytes == 0:
+        raise _lib.M2TError(f"image {H}x{W} is too small for FSIM")
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    out = torch.empty(B, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.m2t_eval_fsim(_lib.ptr(x), _lib.ptr(y), B, H, W, float(data_range), _lib.ptr(scratch), _lib.ptr(out),
+                                     _lib.stream_ptr()), "m2t_eval_fsim")
+    return out
+
+
+def evaluate(model, pairs, scale: int, rgb_range: float = 1.0, with_gmsd: bool = False, with_fsim: bool = False):
     """The reference's test loop (test.py:77-122): `pairs` yields (lr, hr) device tensors [1,3,h,w] / [1,3,h*scale,w*scale];
-    returns (avg_psnr, avg_ssim) -- with_gmsd: (avg_psnr, avg_ssim, avg_gmsd) -- rounded as the reference prints them
-    (test.py:118-121).  One host synchronisation at the end (the reference synchronises per image).  FSIM (`piq.fsim`,
-    test.py:95) is not built: its log-Gabor phase congruency needs the dependency's exact filter bank, which is neither
-    in the reference tree nor in this image."""
-    rows, grows = [], []
+    returns (avg_psnr, avg_ssim) -- with_gmsd: + avg_gmsd; with_fsim: + avg_fsim, in the order the reference prints them
+    (PSNR, SSIM, FSIM, GMSD; test.py:118-122) -- rounded as the reference rounds them.  One host synchronisation at the end
+    (the reference synchronises per image)."""
+    rows, grows, frows = [], [], []
     with torch.no_grad():
         for lr, hr in pairs:
             sr = model(lr)
             if sr.shape != hr.shape:
                 raise ValueError(f"hr {tuple(hr.shape)} does not match sr {tuple(sr.shape)}")
+            if with_fsim:
+                frows.append(fsim_device(hr, sr, 1.0))          # BEFORE the Y conversion, on RGB, like test.py:95-99
             if with_gmsd:
-                grows.append(gmsd_device(hr, sr, 1.0))          # BEFORE the Y conversion, on RGB, like test.py:95-99
+                grows.append(gmsd_device(hr, sr, 1.0))
             rows.append(y_metrics_device(sr, hr, scale, rgb_range))
     if not rows:
         raise ValueError("no evaluation pairs")
@@ -106,6 +129,9 @@ def evaluate(model, pairs, scale: int, rgb_range: float = 1.0, with_gmsd: bool =
     psnr = [-10.0 * math.log10(float(v)) for v in m[:, 0]]
     avg_psnr = round(sum(psnr) / len(psnr) + 5e-3, 2)
     avg_ssim = round(float(m[:, 1].sum()) / len(psnr) + 5e-5, 4)
+    out = [avg_psnr, avg_ssim]
+    if with_fsim:
+        out.append(round(float(torch.cat(frows).sum()) / len(psnr) + 5e-5, 4))
     if with_gmsd:
-        return avg_psnr, avg_ssim, round(float(torch.cat(grows).sum()) / len(psnr) + 5e-5, 4)
-    return avg_psnr, avg_ssim
+        out.append(round(float(torch.cat(grows).sum()) / len(psnr) + 5e-5, 4))
+    return tuple(out)

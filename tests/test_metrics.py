@@ -23,6 +23,33 @@ def _pair(B, H, W, noise=0.0, seed=0):
 
 
 # ------------------------------------------------------------------------------------------------ oracle (CPU)
+def test_fsim_oracle_anchors():
+    """FSIMc (piq.fsim, test.py:95-96, piq 0.8.0; parity unpinned -- the package is in neither tree): identical images -> 1;
+    symmetric in its arguments; more noise -> lower index; on grey images the chroma similarities are 1, so FSIMc == FSIM; the
+    whole index through explicit DFT matrices instead of numpy's FFT (an independent evaluation of every transform) agrees to
+    1e-12; odd image sizes and the k = 2 pooling branch (min(H, W) = 392 -> round(1.53) = 2) run through."""
+    from oracle import fsim_oracle as F
+    sr, hr = _pair(1, 72, 88, noise=0.03)
+    a, b = hr[0].double().numpy(), sr[0].double().numpy()
+    assert abs(F.fsim(a, a) - 1.0) < 1e-12
+    v = F.fsim(a, b)
+    assert 0.3 < v < 0.999 and abs(v - F.fsim(b, a)) < 1e-14
+    c = np.clip(b + 0.1 * np.random.default_rng(0).standard_normal(b.shape), 0, 1)
+    assert F.fsim(a, c) < v
+    ex = F.fsim(a, b, fft2=lambda z: F.dft2_explicit(z), ifft2=lambda z: F.dft2_explicit(z, True))
+    assert abs(ex - v) < 1e-12
+    ga, gb = np.repeat(a[:1], 3, 0), np.repeat(b[:1], 3, 0)
+    assert abs(F.fsim(ga, gb) - F.fsim(ga, gb, chromatic=False)) < 1e-15
+    sr2, hr2 = _pair(1, 41, 67, noise=0.02)
+    assert 0.3 < F.fsim(hr2[0].double().numpy(), sr2[0].double().numpy()) < 1.0
+    sr3, hr3 = _pair(1, 392, 400, noise=0.02)
+    assert 0.3 < F.fsim(hr3[0].double().numpy(), sr3[0].double().numpy()) < 1.0
+    # the filter bank: zero response at zero frequency, symmetric spread, the low-pass kills the corners
+    bank = F.construct_filters(64, 48)
+    assert bank.shape == (16, 64, 48) and float(np.abs(bank[:, 0, 0]).max()) == 0.0 and float(bank.max()) <= 1.0 and float(bank.min()) >= 0.0
+    assert float(bank[:, 32, 24].max()) < 1e-3
+
+
 def test_gmsd_oracle_anchors():
     """GMSD (piq.gmsd, test.py:98; parity unpinned): identical images -> every similarity is 1 -> deviation 0; symmetric in its
     arguments; a tiny case evaluated by hand (2x2-pooled luminance, Prewitt / 3 with zero padding, t = 170 / 255^2)."""
@@ -51,6 +78,31 @@ def test_gmsd_oracle_anchors():
     gx_, gy_ = gm([[0.0, lum(v)], [0.0, lum(v)]]), gm([[lum(0.3)] * 2] * 2)
     gms = (2 * gx_ * gy_ + c) / (gx_ ** 2 + gy_ ** 2 + c)
     assert abs(g - float(np.sqrt(((gms - gms.mean()) ** 2).mean()))) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,noise", [(1, 72, 88, 0.03), (2, 41, 67, 0.02), (1, 392, 400, 0.02), (1, 512, 512, 0.05)])
+def test_device_fsim_matches_oracle(B, H, W, noise):
+    """m2t_eval_fsim (k_fsim.hip: fp64, explicit DFTs, radix-select median) against the fp64 restatement: 1e-9 on the index; identical
+    images give exactly the index 1 up to rounding; odd sizes, the pooling branch, batches."""
+    from oracle import fsim_oracle as F
+    from m2trans_amd.metrics import fsim_device
+    sr, hr = _pair(B, H, W, noise=noise)
+    got = fsim_device(hr.cuda(), sr.cuda(), 1.0).cpu()
+    for b in range(B):
+        want = F.fsim(hr[b].double().numpy(), sr[b].double().numpy())
+        assert abs(float(got[b]) - want) < 1e-9, (b, float(got[b]), want)
+    same = fsim_device(hr.cuda(), hr.cuda(), 1.0).cpu()
+    assert float((same - 1.0).abs().max()) < 1e-12
+
+
+@pytest.mark.gpu
+def test_device_fsim_rejects_host_tensors():
+    from m2trans_amd import _lib
+    from m2trans_amd.metrics import fsim_device
+    sr, hr = _pair(1, 32, 32)
+    with pytest.raises(_lib.M2TError):
+        fsim_device(hr, sr)
 
 
 @pytest.mark.gpu
@@ -181,13 +233,18 @@ def test_evaluate_loop_matches_oracle_on_model_outputs():
         pairs.append((lr, hr))
     got = evaluate(model, pairs, scale)
     got3 = evaluate(model, pairs, scale, with_gmsd=True)
-    gs = []
+    got4 = evaluate(model, pairs, scale, with_gmsd=True, with_fsim=True)
+    from oracle import fsim_oracle as F
+    gs, fs = [], []
     with torch.no_grad():
         for lr, hr in pairs:
             sr = model(lr).cpu()
             ps.append(O.psnr_y(sr, hr.cpu(), scale))
             ss.append(float(O.ssim_y(sr, hr.cpu(), scale, dtype=torch.float64)[0]))
             gs.append(float(O.gmsd(hr.cpu().double(), sr.double())[0]))
+            fs.append(F.fsim(hr[0].cpu().double().numpy(), sr[0].double().numpy()))
     want = (round(sum(ps) / len(ps) + 5e-3, 2), round(sum(ss) / len(ss) + 5e-5, 4))
     assert got == want, (got, want)
     assert got3[:2] == want and abs(got3[2] - round(sum(gs) / len(gs) + 5e-5, 4)) <= 1e-4, (got3, gs)
+    # the reference's print order: PSNR, SSIM, FSIM, GMSD (test.py:122)
+    assert got4[:2] == want and got4[3] == got3[2] and abs(got4[2] - round(sum(fs) / len(fs) + 5e-5, 4)) <= 1e-4, (got4, fs)
