@@ -167,6 +167,9 @@ struct m2t_plan {
   bool use_c16_prep = true;            // bf16, C = 16: overlap-add + projection data gradient + branch_prep_bwd in one kernel }
   int use_fused_c16_fwd = 2;           // bf16, C = 16 branch: norm apply + qkv projection + attention + residual in one kernel (k_attn_c16.hip);
                                        // 2: ... and qkv1 is not stored: the wave-per-window backward recomputes it from d1 (needs attn_bwd >= 1)
+  // x2 / x3, bf16: expansion + PixelShuffle + GELU + tail conv as ONE row-streaming forward kernel and ONE recomputing backward kernel
+  // (k_tail_stream.hip, k_tail_bwd_stream.hip; option "fused_tail" >= 1): gelu(t) / gelu'(t) are never stored
+  bool stream_tail_x23() const { return dt != M2T_F32 && scale != 4 && use_fused_tail_bwd; }
   bool c16_recompute() const { return dt != M2T_F32 && use_fused_c16_fwd == 2 && use_resident_attn_bwd; }
   int use_fused_attn_fwd = 2;          // bf16, C = 64 / 256: qkv projection + attention + epilogue in one kernel (k_attn_fused.hip);
                                        // 2: ... and qkv2 (C = 64) is not stored: the resident backward recomputes it from d2 (needs attn_bwd = 2)
@@ -398,7 +401,11 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "side_stream") return p->use_side;
     if (o == "gate_branch") return p->gate_branch + 1000;      // (offset: -1 is the "unknown key" value of this function)
     if (o == "wgrad_big_tiles") return p->wgrad_big_tiles + 1000;
-    if (o == "fused_tail") return (p->scale == 4 && p->dt != M2T_F32) ? (p->use_fused_tail_bwd ? (p->use_fused_tail_fwd ? (p->use_stream_tail_fwd ? 3 : 2) : 1) : 0) : 0;
+    if (o == "fused_tail") {
+      if (p->dt == M2T_F32) return 0;
+      if (p->scale != 4) return p->stream_tail_x23() ? 3 : 0;      // x2 / x3: the row-streaming pair or the plain kernels
+      return p->use_fused_tail_bwd ? (p->use_fused_tail_fwd ? (p->use_stream_tail_fwd ? 3 : 2) : 1) : 0;
+    }
     if (o == "attn_bwd") return p->dt == M2T_F32 ? 0 : (p->use_resident_attn_bwd ? (p->use_fused_qkv_dgrad ? (p->use_c16_prep ? 3 : 2) : 1) : 0);
     if (o == "conv_rows") return p->dt != M2T_F32 ? p->use_conv_rows : 0;
     if (o == "fused_conv_bwd") return p->dt != M2T_F32 && p->use_fused_conv_bwd && conv3x3_c64_bwd_fusable(p->B, p->H, p->W);
@@ -410,6 +417,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
   }
   if (k == "stores_qkv2") return p->c64_recompute() ? 0 : 1;
   if (k == "stores_qkv1") return (p->use_fused_c16_fwd != 0 && p->c16_recompute()) ? 0 : 1;
+  if (k == "stores_t1") return p->stream_tail_x23() ? 0 : 1;
   if (k == "stores_t2") return (p->scale == 4 && !(p->dt != M2T_F32 && p->use_fused_tail_fwd && p->use_fused_tail_bwd)) ? 1 : 0;
   return -1;
 }
@@ -506,10 +514,14 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
   }
   void* Y = WSP("X" + std::to_string(p->nb));
   const int r0 = (s == 4) ? 2 : s;
+  const float* wlast = params + p->poff.at(s == 4 ? "tail.6.weight" : "tail.3.weight");
+  if (p->stream_tail_x23()) {
+    M2TProfScope ps(M2T_PROF_TAIL_FWD_FUSED, st);
+    CK(launch_tail_fwd_stream(Y, 1, packed_ptr(p, workspace, "t0"), params + p->poff.at("tail.0.bias"), wlast, (float*)WSP("srpre"), B, H, W, r0, 0, st));
+  } else {
   { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st);
     CK(launch_tail_expand(dt, Y, packed_ptr(p, workspace, "t0"), params + p->poff.at("tail.0.bias"), WSP("t1act"), WSP("t1der"), BP, H, W, r0, true, st)); }
   const void* last_act = WSP("t1act");
-  const float* wlast = params + p->poff.at(s == 4 ? "tail.6.weight" : "tail.3.weight");
   if (s == 4 && dt != M2T_F32 && p->use_fused_tail_fwd && p->use_fused_tail_bwd) {
     M2TProfScope ps(M2T_PROF_TAIL_FWD_FUSED, st);
     if (p->use_stream_tail_fwd)
@@ -526,6 +538,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
     last_act = WSP("t2act");
   }
   { M2TProfScope ps(M2T_PROF_FINAL_FWD, st); CK(launch_final_conv_fwd(dt, last_act, wlast, (float*)WSP("srpre"), B, p->Hsp, p->Wsp, st)); }
+  }
   }
   if (sr)
     CK(launch_clamp_l1((const float*)WSP("srpre"), nullptr, sr, nullptr, nullptr, nullptr, B, p->Hsp, p->Wsp, p->Hs,
@@ -662,7 +675,21 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   hipEvent_t im2col_done = nullptr;           // head_cols is produced on the side stream; the head weight gradient may run on the main one
   if (!skip) { CK(launch_head_im2col(dt, x, WSP("head_cols"), B, p->H0, p->W0, H, W, sd)); im2col_done = side_marker(); }
   const bool fused_tail = p->use_fused_tail_bwd && s == 4 && dt != M2T_F32;
-  if (fused_tail) {
+  const bool stream_x23 = p->stream_tail_x23();
+  if (stream_x23) {
+    // x2 / x3: the whole tail backward in one row-streaming launch (k_tail_bwd_stream.hip): g(body output) straight into gT
+    const int N0 = 64 * r0 * r0;
+    const int nb = tail_bwd_stream_blocks(B, H, W, r0);
+    ARENA(swf, (size_t)nb * 32 * 64);
+    ARENA(sw0, (size_t)nb * N0 * 64);
+    ARENA(sb0, (size_t)nb * N0);
+    { M2TProfScope ps(M2T_PROF_FINAL_DGRAD, st);
+      CK(launch_tail_bwd_stream(gpre, params + p->poff.at(wl), WSP("X" + std::to_string(p->nb)), nullptr, packed_ptr(p, workspace, "t0T"),
+                                params + p->poff.at("tail.0.bias"), WSP("gT"), swf, sw0, sb0, &ns, B, H, W, r0, 1, st)); }
+    defer(swf, p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0);
+    defer(sw0, p->poff.at("tail.0.weight"), ns, (long long)N0 * 64, 2, 64, r0 * r0, 64);
+    defer(sb0, p->poff.at("tail.0.bias"), ns, N0, 2, 64, r0 * r0, 1);
+  } else if (fused_tail) {
     // one pass over the high-resolution tensors (k_tail_bwd.hip): tail conv dgrad + wgrad, GELU', tail.3 dgrad + wgrad
     const int nb = tail_bwd_fused_blocks(B, p->Hsp, p->Wsp);
     ARENA(swf, (size_t)nb * 32 * 64);
@@ -704,7 +731,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   }
   }
   void* Y = WSP("X" + std::to_string(p->nb));
-  {
+  if (!stream_x23) {
     const int N0 = 64 * r0 * r0;
     fork();
     ARENA(slabs, (size_t)wgrad_slab_count(BP, N0, 64) * N0 * 64);
@@ -722,7 +749,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     ga.M = BP; ga.N = 64; ga.K = N0; ga.H = H; ga.Wd = W; ga.r = r0; ga.C = 64;
     { M2TProfScope ps(M2T_PROF_TAIL_GEMM, st); CK(launch_gemm_nt(dt, M2T_A_UNSHUF, M2T_E_PLAIN, ga, st)); }
   }
-  if (fused_tail) fork();     // the reduction (side stream) follows the main-stream producer
+  if (fused_tail || stream_x23) fork();     // the reduction (side stream) follows the main-stream producer
   CK(flush());
   mark_bucket();
   // ---- body, last block first.  gy = gradient of X[b+1] ----

@@ -169,6 +169,15 @@ int launch_tail_fwd_fused(const void* a1, const void* w3p, const float* b3, cons
 int launch_tail_fwd_stream(const void* a, int a_is_p64, const void* wp, const float* bias, const float* wf, float* out, int B, int Hi,
                            int Wi, int R, int seg_rows, hipStream_t st);
 
+// ---- k_tail_bwd_stream.hip ---------------------------------------------------------------
+// bf16: the recomputing backward of the tail's last stage as a row-streaming kernel (round 4).  tail0 = 1 (R = 2 / 3): x2's / x3's whole
+// tail on the P64 body output; tail0 = 0 (R = 2): x4's tail.3 stage (kept for A/B: slower than the tile kernel).  Hi, Wi: size of the
+// expansion's INPUT map.  Slabs: tail_bwd_stream_blocks() of each kind.
+int tail_bwd_stream_blocks(int B, int Hi, int Wi, int R);
+int launch_tail_bwd_stream(const float* gout, const float* wf, const void* a, const void* d1, const void* w3t, const float* b3, void* ga,
+                           float* slab_wf, float* slab_w3, float* slab_b3, int* nslab_out, int B, int Hi, int Wi, int R, int tail0,
+                           hipStream_t st);
+
 // ---- k_tail_bwd.hip ----------------------------------------------------------------------
 // x4 tail, bf16: tail conv data + weight gradient, GELU backward, tail.3 data + weight + bias gradient in one pass
 // over the stored activation / derivative tensors (g(t2) never reaches HBM).  Slabs: wf [n][32][64], w3 [n][256][64],

@@ -37,9 +37,8 @@ __device__ unsigned long long* g_bstamps = nullptr;
 #ifndef NO_STREAM
 #define TS_BENCH_HOOKS
 #include "../m2trans_amd/csrc/k_tail_stream.hip"
-#ifdef WITH_BWD_STREAM      // the row-streaming backward experiment of round 4 (correct, slower than the tile kernel: profiles/README.md)
-#include "k_tail_bwd_stream_r04.hip.txt"
-#endif
+#define WITH_BWD_STREAM
+#include "../m2trans_amd/csrc/k_tail_bwd_stream.hip"
 #endif
 int m2t_set_hip_error(hipError_t e, const char* f, int l) { fprintf(stderr, "HIP error %d %s at %s:%d\n", (int)e, hipGetErrorString(e), f, l); return (int)e; }
 int m2t_set_error(int c, const char* m) { fprintf(stderr, "error %d %s\n", c, m); return c; }
@@ -121,7 +120,7 @@ static int run_case(int B, int Hlr, int Wlr, bool timing) {
     std::vector<unsigned short> hgt2(nmid);
     CKH(hipMemset(dgt1, 0xee, nmid * 2));
     int ns2 = 0;
-    if (launch_tail_bwd_stream(dg, dwf, da1, dd1, dw3, dw3t, db3, dgt1, swf, sw3, sb3, &ns2, B, H, W, st)) exit(2);
+    if (launch_tail_bwd_stream(dg, dwf, da1, dd1, dw3t, db3, dgt1, swf, sw3, sb3, &ns2, B, Hm, Wm, 2, 0, st)) exit(2);
     CKH(hipStreamSynchronize(st));
     CKH(hipMemcpy(hgt2.data(), dgt1, nmid * 2, hipMemcpyDeviceToHost));
     size_t bad = 0, first = 0;
@@ -143,7 +142,7 @@ static int run_case(int B, int Hlr, int Wlr, bool timing) {
     if (bad) printf(" (first %zu: pixel %zu ch %zu: %04x vs %04x)", first, first / 64, first % 64, hgt[first], hgt2[first]);
     printf("; slabs %d; rel diff dWf %.2e dW3 %.2e db3 %.2e\n", ns2, cmp(h1, k1, 32 * 64), cmp(h2, k2, 256 * 64), cmp(h3, k3, 256));
     if (timing) {
-      auto bs = [&]() { int q; if (launch_tail_bwd_stream(dg, dwf, da1, dd1, dw3, dw3t, db3, dgt1, swf, sw3, sb3, &q, B, H, W, st)) exit(2); };
+      auto bs = [&]() { int q; if (launch_tail_bwd_stream(dg, dwf, da1, dd1, dw3t, db3, dgt1, swf, sw3, sb3, &q, B, Hm, Wm, 2, 0, st)) exit(2); };
       printf("   tail_bwd_stream %.1f us\n", time_it(st, 30, bs));
 #ifdef BSTAMPS
       {
@@ -239,7 +238,59 @@ static int run_case(int B, int Hlr, int Wlr, bool timing) {
   return 0;
 }
 
+#ifndef NO_STREAM
+// x3 (R = 3, P64 input): timing of the forward / backward row-streaming pair on the BASELINE configs[4] shape; no reference here (the
+// library's -m gpu tests compare them with the plain kernels)
+static void run_r3(int B, int Hlr, int Wlr) {
+  const int R = 3, H = R * Hlr, W = R * Wlr;
+  const size_t nlr = (size_t)B * Hlr * Wlr * 64, nhr = (size_t)B * 3 * H * W;
+  std::vector<unsigned short> ha(nlr), hw(576 * 64), hwt(64 * 576);
+  for (auto& v : ha) v = f2bf(2.f * frand());
+  for (int n = 0; n < 576; ++n) for (int k = 0; k < 64; ++k) { unsigned short v = f2bf(0.25f * frand()); hw[n * 64 + k] = v; hwt[k * 576 + n] = v; }
+  std::vector<float> hb(576), hwf(3 * 64 * 9), hg(nhr);
+  for (auto& v : hb) v = 0.2f * frand();
+  for (auto& v : hwf) v = 0.1f * frand();
+  for (auto& v : hg) v = 1e-3f * frand();
+  void *da, *dw, *dwt, *dga; float *db, *dwf, *dg, *dout, *s1, *s2, *s3;
+  CKH(hipMalloc(&da, nlr * 2)); CKH(hipMalloc(&dga, nlr * 2)); CKH(hipMalloc(&dw, hw.size() * 2)); CKH(hipMalloc(&dwt, hwt.size() * 2));
+  CKH(hipMalloc(&db, 576 * 4)); CKH(hipMalloc(&dwf, hwf.size() * 4)); CKH(hipMalloc(&dg, nhr * 4)); CKH(hipMalloc(&dout, nhr * 4));
+  CKH(hipMalloc(&s1, (size_t)512 * 32 * 64 * 4)); CKH(hipMalloc(&s2, (size_t)512 * 576 * 64 * 4)); CKH(hipMalloc(&s3, (size_t)512 * 576 * 4));
+  CKH(hipMemcpy(da, ha.data(), nlr * 2, hipMemcpyHostToDevice)); CKH(hipMemcpy(dw, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+  CKH(hipMemcpy(dwt, hwt.data(), hwt.size() * 2, hipMemcpyHostToDevice)); CKH(hipMemcpy(db, hb.data(), 576 * 4, hipMemcpyHostToDevice));
+  CKH(hipMemcpy(dwf, hwf.data(), hwf.size() * 4, hipMemcpyHostToDevice)); CKH(hipMemcpy(dg, hg.data(), nhr * 4, hipMemcpyHostToDevice));
+  hipStream_t st; CKH(hipStreamCreate(&st));
+  auto fwd = [&]() { if (launch_tail_fwd_stream(da, 1, dw, db, dwf, dout, B, Hlr, Wlr, R, 0, st)) exit(2); };
+  auto bwd = [&]() { int q; if (launch_tail_bwd_stream(dg, dwf, da, nullptr, dwt, db, dga, s1, s2, s3, &q, B, Hlr, Wlr, R, 1, st)) exit(2); };
+  printf("x3 B=%d LR %dx%d: tail_fwd_stream<3> %.1f us   tail_bwd_stream<3> %.1f us\n", B, Hlr, Wlr, time_it(st, 20, fwd), time_it(st, 20, bwd));
+#ifdef BSTAMPS
+  {
+    unsigned long long* ds; const size_t nst = (size_t)512 * 4 * 16;
+    CKH(hipMalloc(&ds, nst * 8)); CKH(hipMemset(ds, 0, nst * 8));
+    CKH(hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), &ds, sizeof(ds)));
+    bwd(); CKH(hipStreamSynchronize(st));
+    std::vector<unsigned long long> hs(nst);
+    CKH(hipMemcpy(hs.data(), ds, nst * 8, hipMemcpyDeviceToHost));
+    double acc[16] = {0}; int cnt = 0;
+    for (int blk = 0; blk < 512; ++blk) for (int it = 0; it < 3; ++it) {
+      const unsigned long long* a = &hs[((size_t)blk * 4 + it) * 16], *nx = &hs[((size_t)blk * 4 + it + 1) * 16];
+      if (!a[0] || !nx[0]) continue;
+      for (int i = 0; i < 8; ++i) acc[i] += (double)(a[i + 1] - a[i]);
+      acc[8] += (double)(nx[0] - a[8]); acc[9] += (double)(nx[0] - a[0]); ++cnt;
+    }
+    printf("   x3 bwd stamps (wave %d, mean cycles over %d steps): ", BSTAMP_WAVE, cnt);
+    for (int i = 0; i < 10; ++i) printf("%s%.0f", i ? " | " : "", acc[i] / std::max(cnt, 1));
+    printf("\n   [0 loads+MFMA t | 1 Geff gather | 2 GELU, g(act), g(t), stores | 3 barrier 1 | 4 ring write, db | 5 dWf | 6 g(a) | 7 barrier 2 | 8 loop | 9 total]\n");
+    unsigned long long* z = nullptr; CKH(hipMemcpyToSymbol(HIP_SYMBOL(g_bstamps), &z, sizeof(z)));
+  }
+#endif
+  for (void* q : {da, dga, dw, dwt, (void*)db, (void*)dwf, (void*)dg, (void*)dout, (void*)s1, (void*)s2, (void*)s3}) (void)hipFree(q);
+}
+#endif
+
 int main(int argc, char** argv) {
+#ifndef NO_STREAM
+  if (argc > 1 && argv[1][0] == '3') { run_r3(8, 256, 256); return 0; }
+#endif
   run_case(2, 16, 24, false);       // 64 x 96 HR: border tiles only
   run_case(3, 32, 24, false);
   run_case(1, 40, 64, false);

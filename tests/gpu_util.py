@@ -70,8 +70,9 @@ def hip_forward_trace(plan, scale, n_blocks, B, H, W):
         t[f"b{b}.xc"] = ws_nchw(plan, f"b{b}.xc", B, H, W, 64)
         t[f"X{b+1}"] = ws_nchw(plan, f"X{b+1}", B, H, W, 64)
     r0 = 2 if scale == 4 else scale
-    for nm in ("t1act", "t1der"):
-        t[nm] = ws_nchw(plan, nm, B, H * r0, W * r0, 64)
+    if plan.query("stores_t1") == 1:                       # (x2 / x3 bf16: the row-streaming tail keeps gelu(t) / gelu'(t) in registers)
+        for nm in ("t1act", "t1der"):
+            t[nm] = ws_nchw(plan, nm, B, H * r0, W * r0, 64)
     if scale == 4 and plan.query("stores_t2") == 1:        # the fused forward tail keeps gelu(t2) / gelu'(t2) in LDS
         for nm in ("t2act", "t2der"):
             t[nm] = ws_nchw(plan, nm, B, H * 4, W * 4, 64)

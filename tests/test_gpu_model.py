@@ -4,6 +4,8 @@ intermediate (named workspace tensors) so that a failure points at one kernel.""
 import os
 
 import numpy as np
+import math
+
 import pytest
 import torch
 
@@ -760,6 +762,38 @@ def test_fused_conv_backward_matches_the_two_kernel_path():
                 assert d < 1e-5, (B, H, W, n, d)
             else:
                 assert torch.equal(ga[n], gb[n]), (B, H, W, n)
+
+
+@pytest.mark.parametrize("scale,B,H,W", [(3, 2, 40, 56), (3, 1, 96, 128), (2, 2, 60, 90), (2, 1, 128, 64)])
+def test_x2_x3_row_streaming_tail_matches_the_plain_kernels(scale, B, H, W):
+    """bf16 x2 / x3: the whole tail (tail.0 expansion + PixelShuffle(r) + GELU + tail conv) as ONE row-streaming forward kernel and ONE
+    recomputing backward kernel (option fused_tail >= 1, default; k_tail_stream.hip / k_tail_bwd_stream.hip) against tail_expand +
+    final_conv_fwd / final_conv_dgrad + final_conv_wgrad + gemm_nt + wgrad_tn (fused_tail = 0), which store gelu(t) / gelu'(t) / g(t).
+    The forward keeps operand fragments, k order, GELU and tap order: sr bit for bit.  The backward rounds the same tensors to bf16
+    (g(t), gelu'(t)) but sums the expansion's data gradient and the three parameter gradients in another order: every parameter
+    gradient within 2e-2 of the plain path (or 1e-5 of the whole gradient), the whole gradient within 3e-3.  Reflect-padded inputs,
+    border / interior strips, several row segments."""
+    from m2trans_amd import _lib
+    nb = 1
+    x = O.closed_form_image(B, 3, H, W).cuda()
+    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+    outs = []
+    for fused in (3, 0):
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(x)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_tail", fused), "m2t_set_option")
+        assert plan.query("opt:fused_tail") == fused and plan.query("stores_t1") == (0 if fused else 1)
+        sr = model(x)
+        torch.nn.L1Loss()(sr, hr).backward()
+        outs.append((sr.detach().clone(), {n: q.grad.detach().double().cpu() for n, q in model.named_parameters() if q.requires_grad}))
+    (sa, ga), (sb, gb) = outs
+    assert torch.equal(sa, sb), (scale, B, H, W, float((sa - sb).abs().max()))
+    total = math.sqrt(sum(float(v.pow(2).sum()) for v in gb.values()))
+    diff = math.sqrt(sum(float((ga[n] - gb[n]).pow(2).sum()) for n in gb))
+    assert diff / total < 3e-3, (scale, diff / total)
+    for n in gb:
+        d = float((ga[n] - gb[n]).norm())
+        assert d <= 2e-2 * float(gb[n].norm()) or d <= 1e-5 * total, (scale, n, d / max(float(gb[n].norm()), 1e-30), d / total)
 
 
 def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():
