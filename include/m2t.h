@@ -68,7 +68,10 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           and tail.3 expansion + PixelShuffle + GELU + tail conv of the FORWARD in one kernel (k_tail_fwd.hip): gelu(t2)
  *                           and gelu'(t2) are then never stored, the fused backward recomputes them per tile
  *                           (m2t_plan_query("stores_t2") tells whether ws:t2act / ws:t2der are written); 3 = 2 with the forward as the
- *                           row-streaming kernel of round 4 (k_tail_stream.hip, same bits); 0 = the plain kernels
+ *                           row-streaming kernel of round 4 (k_tail_stream.hip, same bits); 4 = 3 with the backward as a row-streaming
+ *                           kernel too (k_tail_bwd_stream.hip: same data gradient bits, slower -- kept for A/B); 0 = the plain kernels.
+ *                           bf16 x2 / x3: >= 1 = the whole tail as ONE row-streaming forward and ONE recomputing backward kernel
+ *                           (m2t_plan_query("stores_t1") = 0: gelu(t) / gelu'(t) are never stored), 0 = the plain kernels
  *   "attn_bwd"          [3] bf16 attention backward: 0 = chunked kernels + halo gather + data-gradient GEMM, 1 = whole-window-
  *                           resident / wave-per-window kernels, 2 = 1 + the data gradient of the qkv projection inside the
  *                           C = 64 / 256 kernels (k_attn_res.hip), 3 = 2 + one kernel for the C = 16 branch's overlap-add,

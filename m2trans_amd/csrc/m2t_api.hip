@@ -151,6 +151,8 @@ struct m2t_plan {
   bool use_fused_tail_bwd = true;      // x4 bf16: k_tail_bwd.hip instead of four HR kernels                              } option "fused_tail":
   bool use_fused_tail_fwd = true;      // x4 bf16: tail.3 expansion + GELU + tail conv in one kernel, gelu(t2) / gelu'(t2) never stored } 0 / 1 / 2 / 3
   bool use_stream_tail_fwd = true;     // ... as the row-streaming kernel (k_tail_stream.hip, round 4: 152 vs 229 us, same bits); 2 = the 16x16-tile kernel
+  bool use_stream_tail_bwd = false;    // x4: the row-streaming BACKWARD (k_tail_bwd_stream.hip) instead of the tile kernel: option value 4, kept for
+                                       // A/B -- same data gradient bits, 580 against 377 us stand-alone at batch 16
                                        // (with bf16 mode's exp2 / rcp GELU: 5.30 vs 5.34 ms per step and 1.6 GB less HBM traffic;
                                        // with the erf form of round 2 it was 1 % slower)
   int gate_branch = -1;                // side-stream gate: -1 ungated (a branch's side work follows its attention launch), else the branch (3..0)
@@ -404,7 +406,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "fused_tail") {
       if (p->dt == M2T_F32) return 0;
       if (p->scale != 4) return p->stream_tail_x23() ? 3 : 0;      // x2 / x3: the row-streaming pair or the plain kernels
-      return p->use_fused_tail_bwd ? (p->use_fused_tail_fwd ? (p->use_stream_tail_fwd ? 3 : 2) : 1) : 0;
+      return p->use_fused_tail_bwd ? (p->use_fused_tail_fwd ? (p->use_stream_tail_fwd ? (p->use_stream_tail_bwd ? 4 : 3) : 2) : 1) : 0;
     }
     if (o == "attn_bwd") return p->dt == M2T_F32 ? 0 : (p->use_resident_attn_bwd ? (p->use_fused_qkv_dgrad ? (p->use_c16_prep ? 3 : 2) : 1) : 0);
     if (o == "conv_rows") return p->dt != M2T_F32 ? p->use_conv_rows : 0;
@@ -691,12 +693,17 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     defer(sb0, p->poff.at("tail.0.bias"), ns, N0, 2, 64, r0 * r0, 1);
   } else if (fused_tail) {
     // one pass over the high-resolution tensors (k_tail_bwd.hip): tail conv dgrad + wgrad, GELU', tail.3 dgrad + wgrad
-    const int nb = tail_bwd_fused_blocks(B, p->Hsp, p->Wsp);
+    const bool sbwd = p->use_stream_tail_bwd && p->use_fused_tail_fwd;      // (the streaming form always recomputes)
+    const int nb = sbwd ? tail_bwd_stream_blocks(B, 2 * H, 2 * W, 2) : tail_bwd_fused_blocks(B, p->Hsp, p->Wsp);
     ARENA(swf, (size_t)nb * 32 * 64);
     ARENA(sw3, (size_t)nb * 256 * 64);
     ARENA(sb3, (size_t)nb * 256);
     { M2TProfScope ps(M2T_PROF_FINAL_DGRAD, st);
       const bool rc = p->use_fused_tail_fwd;       // the forward did not store gelu(t2) / gelu'(t2): recompute per tile
+      if (sbwd)
+        CK(launch_tail_bwd_stream(gpre, params + p->poff.at(wl), WSP("t1act"), WSP("t1der"), packed_ptr(p, workspace, "t3T"),
+                                  params + p->poff.at("tail.3.bias"), WSP("g_t1pre"), swf, sw3, sb3, &ns, B, 2 * H, 2 * W, 2, 0, st));
+      else
       CK(launch_tail_bwd_fused(gpre, params + p->poff.at(wl), rc ? nullptr : WSP("t2act"), rc ? nullptr : WSP("t2der"), WSP("t1act"),
                                WSP("t1der"), packed_ptr(p, workspace, "t3T"), params + p->poff.at("tail.3.bias"), WSP("g_t1pre"), swf, sw3,
                                sb3, &ns, B, p->Hsp, p->Wsp, st)); }
@@ -994,8 +1001,9 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }
   if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
   if (k == "fused_tail") {
-    if (value < 0 || value > 3) return m2t_set_error(M2T_ERR_ARG, "fused_tail: 0..3");
-    p->use_fused_tail_bwd = value >= 1; p->use_fused_tail_fwd = value >= 2; p->use_stream_tail_fwd = value == 3; p->have_acts = false; return 0;
+    if (value < 0 || value > 4) return m2t_set_error(M2T_ERR_ARG, "fused_tail: 0..4");
+    p->use_fused_tail_bwd = value >= 1; p->use_fused_tail_fwd = value >= 2; p->use_stream_tail_fwd = value >= 3; p->use_stream_tail_bwd = value == 4;
+    p->have_acts = false; return 0;
   }
   if (k == "attn_bwd") {
     if (value < 0 || value > 3) return m2t_set_error(M2T_ERR_ARG, "attn_bwd: 0..3");
