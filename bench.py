@@ -347,7 +347,11 @@ def main():
                                                plan=model._plan_for(batches[0][0]))
         if roofline is not None:
             roofline["timing"] = ("HIP events on the kernel's own dispatches, launch stream, inside the timed region; "
-                                  + ("every launch" if stride == 1 else f"1 launch in {stride} of the category (uniform sample; an event-carrying dispatch costs ~10 us of launch path)"))
+                                  + ("every launch" if stride == 1 else f"1 launch in {stride} of the category (uniform sample; an event-carrying dispatch costs ~10 us of launch path)")
+                                  + ".  avg_launch_us is the IN-STEP duration: the backward's side stream runs parameter-gradient kernels beside the main "
+                                    "chain, which lengthens the kernels they meet (C = 256 attention backward: ~32 us alone, ~35 us in rocprofv3's two-stream "
+                                    "trace, whose tracing serialises part of the overlap, ~40 us here); the stand-alone durations are the single-stream "
+                                    "rocprofv3 summary in profiles/")
         m2t_profile.enable(0)
 
     if rank == 0:

@@ -39,7 +39,7 @@ KERNEL_OF = {
     "attn_fused_c64": "window_attn_fused_fwd_kernel<C=64,L=1> (qkv projection + window attention + IWT/residual)",
     "attn_fused_c256": "window_attn_fused_fwd_kernel<C=256,L=2> (qkv projection + window attention + IWT^2/residual)",
     "attn_fused_c16": "window_attn_fused_c16_fwd_kernel (InstanceNorm apply + qkv projection + window attention + residual, wave per window)",
-    "tail_fwd_fused": "tail_fwd_stream_kernel<R=2> (tail.3 1x1 expansion + PixelShuffle + GELU + tail conv, row-streaming)",
+    "tail_fwd_fused": "tail_fwd_stream_kernel (1x1 expansion + PixelShuffle + GELU + tail conv, row-streaming)",
     "conv3x3_bwd": "conv3x3_c64_bwd_rows_kernel (64->64 3x3 conv: data gradient + weight / bias gradient in one row-streaming pass)",
 }
 KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these categories
@@ -50,7 +50,7 @@ KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these cate
     "gemm_qkv": "gemm_nt_kernel / gemm_nt_wide_kernel (qkv projections)",
     "gemm_qkv_dgrad": "gemm_nt_kernel / gemm_nt_wide_kernel (qkv data gradients)",
     "tail_gemm": "tail_expand_kernel (fwd) + gemm_nt_kernel (data gradients)",
-    "final_conv_dgrad": "tail_bwd_fused_kernel (tail conv dgrad+wgrad, GELU', tail.3 dgrad+wgrad)",
+    "final_conv_dgrad": "tail_bwd_fused_kernel (x4) / tail_bwd_stream_kernel (x2, x3): tail conv dgrad+wgrad, GELU', expansion dgrad+wgrad, recomputing",
 }
 MERGED = {"conv3x3_fwd+dgrad": ("conv3x3_fwd", "conv3x3_dgrad")}
 MERGED_KERNEL = {"conv3x3_fwd+dgrad": "conv3x3_c64_rows_kernel (64->64 3x3 conv, row-streaming LDS-DMA kernel: forward and data gradient are the same kernel)"}
@@ -137,6 +137,7 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
     else:
         add("conv3x3_dgrad", nb * conv_fl, nb * B * P * 64 * es * 2, nb)
         add("conv3x3_wgrad", nb * conv_fl, nb * B * P * 64 * es * 2, nb)
+    stream_x23 = scale != 4 and dtype == "bf16" and fused_tail_fwd       # x2 / x3: the whole tail as two row-streaming kernels (round 4)
     if scale == 4:
         # tail.0: M=BP, K=64, N=256 ; tail.3: M=4BP ; each: fwd + dgrad GEMM and a wgrad
         for M in (B * P, 4 * B * P):
@@ -146,21 +147,32 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
     else:
         r2 = scale * scale
         M = B * P
-        add("tail_gemm", 2 * 2.0 * M * 64 * 64 * r2, 2 * M * (64 + 64 * r2) * es, 2)
-        add("tail_wgrad", 2.0 * M * 64 * 64 * r2, M * (64 + 64 * r2) * es, 1)
+        if not stream_x23:
+            add("tail_gemm", 2 * 2.0 * M * 64 * 64 * r2, 2 * M * (64 + 64 * r2) * es, 2)
+            add("tail_wgrad", 2.0 * M * 64 * 64 * r2, M * (64 + 64 * r2) * es, 1)
         HR = r2 * B * P
     fin = 2.0 * HR * 64 * 27
-    if scale == 4 and dtype == "bf16" and fused_tail_fwd:
-        # fused forward tail (k_tail_fwd.hip): reads gelu(t1) (HR/4 pixels x 64), writes the fp32 output; tail.3 expansion + tail conv
+    if stream_x23:
+        # k_tail_stream.hip / k_tail_bwd_stream.hip: forward reads the body output (M x 64), writes the fp32 image; backward reads
+        # g(sr) and the body output, writes g(body output); the expansion's FLOPs once forward, three times backward (recompute, data
+        # gradient, weight gradient), the tail conv's once / twice
+        M = B * P
+        ex = 2.0 * M * 64 * 64 * scale * scale
+        w["tail_fwd_fused"] = (fin + ex, M * 64 * es + HR * 12, 1)
+        w["final_conv_dgrad"] = (2 * fin + 3 * ex, HR * 12 + 2 * M * 64 * es, 1)
+    elif scale == 4 and dtype == "bf16" and fused_tail_fwd:
+        # fused forward tail (k_tail_stream.hip / k_tail_fwd.hip): reads gelu(t1) (HR/4 pixels x 64), writes the fp32 output; tail.3 expansion + tail conv
         w["tail_fwd_fused"] = (fin + 2.0 * (HR // 4) * 64 * 256, (HR // 4) * 64 * es + HR * 12, 1)
         f0, b0, n0 = w["tail_gemm"]
         w["tail_gemm"] = (f0 - 2.0 * (HR // 4) * 64 * 256, b0 - (HR // 4) * (64 + 256) * es, n0 - 1)
     else:
         add("final_conv_fwd", fin, HR * (64 * es + 12), 1)
-    if scale == 4 and dtype == "bf16":
+    if stream_x23:
+        pass
+    elif scale == 4 and dtype == "bf16":
         # fused tail backward (k_tail_bwd.hip): tail conv dgrad + wgrad, GELU', tail.3 dgrad + wgrad in one pass:
         # reads g(sr) (HR x 12 B), gelu(t1), gelu'(t1) (HR/4); writes g(t1) (HR/4).  The stored variant (option "fused_tail" = 1)
-        # also reads gelu(t2), gelu'(t2) (HR x 2 x 64 es); the default recomputing variant (= 2) does not -- it pays the tail.3
+        # also reads gelu(t2), gelu'(t2) (HR x 2 x 64 es); the default recomputing variant (>= 2) does not -- it pays the tail.3
         # expansion's FLOPs a second time instead
         mid = HR // 4
         if fused_tail_fwd:
