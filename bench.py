@@ -342,7 +342,8 @@ def main():
     roofline = None
     if rank == 0 and not args.no_kernel_events:
         roofline = m2t_profile.roofline_report(B, args.lr_size, args.scale, args.dtype, args.steps,
-                                               os.path.join(ROOT, "profiles", "pmc_traffic.json"), source_stamp(),
+                                               os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.config == 1 else f"pmc_traffic_config{args.config}.json"),
+                                               source_stamp(),
                                                workload=f"config{args.config}" if not args.preset_overridden else None,
                                                plan=model._plan_for(batches[0][0]))
         if roofline is not None:

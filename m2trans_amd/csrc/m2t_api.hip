@@ -96,7 +96,11 @@ extern "C" int m2t_profile_enable(unsigned long long category_mask) {
   if (category_mask && g_prof.pool.empty()) {
     g_prof.pool.resize(16384);
     for (auto& r : g_prof.pool) {
-      if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess)
+      // timing-only events: without the system-scope fence a default event carries, whose L2 write-back lengthens the
+      // measured kernel and the one behind it (rocprofv3 of the same step: 46 vs 31 us for a sampled C = 256 attention backward
+      // launch, 54 vs 44 us for its successor).  m2t_profile_read is only called after the streams were synchronised.
+      if (hipEventCreateWithFlags(&r.a, hipEventDisableSystemFence) != hipSuccess ||
+          hipEventCreateWithFlags(&r.b, hipEventDisableSystemFence) != hipSuccess)
         return m2t_set_error(M2T_ERR_STATE, "m2t_profile_enable: hipEventCreate failed");
       r.cat = -1;
     }

@@ -202,7 +202,7 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
     """Roofline object for the dominant (largest total time) kernel category measured in the
     timed region, plus a compact table of the others.  `traffic` (PMC bytes per launch) comes from a separate
     rocprofv3 --pmc collection (tools/pmc_traffic.py -> profiles/pmc_traffic.json); it is reported only when that
-    file was collected on THIS build (same kernel-source stamp) and workload, otherwise null."""
+    file was collected on THIS build (same kernel-source stamp), workload and compute dtype, otherwise null."""
     t = read_all()
     opts = plan_options(plan) if plan is not None else {}
     work = algorithmic_work(B, lr, scale, dtype, fused_attn_fwd=opts.get("fused_attn_fwd"), fused_tail_fwd=bool(opts.get("fused_tail_fwd", False)),
@@ -213,7 +213,8 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
     if pmc_file and os.path.exists(pmc_file):
         try:
             blob = json.load(open(pmc_file))
-            if source_stamp is not None and blob.get("source_stamp") == source_stamp and blob.get("workload", "config1") == workload:
+            if source_stamp is not None and blob.get("source_stamp") == source_stamp and blob.get("workload", "config1") == workload \
+                    and blob.get("dtype", "bf16") == dtype:
                 traffic = blob.get("traffic_bytes_per_launch", {})
         except Exception:
             traffic = {}

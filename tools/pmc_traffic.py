@@ -86,7 +86,7 @@ def main():
         elif cat:
             traffic[cat] = max(traffic[cat], fb + wb) if "(all)" in cat else (traffic[cat] + fb + wb) / 2
     out = {"note": "bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024, averaged over launches (bench.py --config " + CONFIG + ", single stream)",
-           "source_stamp": source_stamp(), "workload": "config" + CONFIG,
+           "source_stamp": source_stamp(), "workload": "config" + CONFIG, "dtype": "bf16",
            "traffic_bytes_per_launch": traffic, "kernels": detail}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     name = "pmc_traffic.json" if CONFIG == "1" else f"pmc_traffic_config{CONFIG}.json"
