@@ -347,12 +347,12 @@ def main():
                                                workload=f"config{args.config}" if not args.preset_overridden else None,
                                                plan=model._plan_for(batches[0][0]))
         if roofline is not None:
-            roofline["timing"] = ("HIP events on the kernel's own dispatches, launch stream, inside the timed region; "
+            roofline["timing"] = ("HIP events (hipEventDisableSystemFence: timing only, no L2 write-back behind the measured kernel) on the kernel's own "
+                                  "dispatches, launch stream, inside the timed region; "
                                   + ("every launch" if stride == 1 else f"1 launch in {stride} of the category (uniform sample; an event-carrying dispatch costs ~10 us of launch path)")
-                                  + ".  avg_launch_us is the IN-STEP duration: the backward's side stream runs parameter-gradient kernels beside the main "
-                                    "chain, which lengthens the kernels they meet (C = 256 attention backward: ~32 us alone, ~35 us in rocprofv3's two-stream "
-                                    "trace, whose tracing serialises part of the overlap, ~40 us here); the stand-alone durations are the single-stream "
-                                    "rocprofv3 summary in profiles/")
+                                  + ".  avg_launch_us is the IN-STEP duration (two streams) and agrees with rocprofv3's kernel trace of this command run with "
+                                    "--no-kernel-events; inside a rocprofv3 session the event-carrying launches themselves are recorded ~17 us longer "
+                                    "(profiles/README.md, round 4), which lifts the average of the summary taken WITH events by ~3 us")
         m2t_profile.enable(0)
 
     if rank == 0:

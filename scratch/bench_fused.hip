@@ -8,7 +8,7 @@
 #include <string>
 #ifdef STAMPS
 __device__ unsigned long long* g_stamps;
-#define M2T_FUSED_STAMP(i) do { if ((threadIdx.x & 63) == 0) g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define M2T_FUSED_STAMP(i) do { if ((threadIdx.x & 63) == 0) { g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); if ((i) == 0 || (i) == 7) g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #endif
 #include "../m2trans_amd/csrc/k_attn_fused.hip"
 
@@ -97,6 +97,18 @@ int main(int argc, char** argv) {
     for (int b = 0; b < nwin; ++b) d.push_back((long long)(hs[((size_t)b * 8 + wsel) * 16 + 7] - hs[((size_t)b * 8 + wsel) * 16 + 0]));
     std::sort(d.begin(), d.end());
     printf("  total (stamp 0 -> 7) median %lld cycles (s_memtime ticks at 100 MHz?)\n", d[d.size() / 2]);
+  }
+  // dispatch skew on the constant 100 MHz clock (s_memrealtime, one time base for the chip)
+  {
+    unsigned long long lo = ~0ull, hi = 0; std::vector<long long> st0, en;
+    for (int b = 0; b < nwin; ++b) for (int wv = 0; wv < NW; ++wv) {
+      const unsigned long long a = hs[((size_t)b * 8 + wv) * 16 + 8], c = hs[((size_t)b * 8 + wv) * 16 + 15];
+      if (a) lo = std::min(lo, a); if (c) hi = std::max(hi, c);
+    }
+    for (int b = 0; b < nwin; ++b) { st0.push_back((long long)(hs[((size_t)b * 8) * 16 + 8] - lo)); en.push_back((long long)(hs[((size_t)b * 8) * 16 + 15] - lo)); }
+    std::sort(st0.begin(), st0.end()); std::sort(en.begin(), en.end());
+    printf("  chip: first start -> last end %.2f us; workgroup start offsets: median %.2f us, p90 %.2f, max %.2f; end offsets: min %.2f median %.2f max %.2f us\n", (hi - lo) * 0.01,
+           st0[st0.size() / 2] * 0.01, st0[st0.size() * 9 / 10] * 0.01, st0.back() * 0.01, en.front() * 0.01, en[en.size() / 2] * 0.01, en.back() * 0.01);
   }
 #endif
   return 0;

@@ -1,0 +1,103 @@
+// Stand-alone timing harness for k_attn_res.hip (resident window-attention backward with the fused projection data gradient):
+// synthetic data, hipEvent timing, per-phase s_memtime stamps (-DSTAMPS).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off [-DSTAMPS] scratch/bench_res.hip -o scratch/bench_res[_st]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <string>
+#ifdef STAMPS
+__device__ unsigned long long* g_stamps;
+#define M2T_RES_STAMP(i) do { if ((threadIdx.x & 63) == 0) { g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  if ((i) == 0 || (i) == 7) g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#endif
+#include "base/k_attn_res_r04base.hip.txt"
+
+int m2t_set_hip_error(hipError_t e, const char* f, int l) { fprintf(stderr, "HIP error %d %s at %s:%d\n", (int)e, hipGetErrorString(e), f, l); return (int)e; }
+int m2t_set_error(int c, const char* m) { fprintf(stderr, "error %d %s\n", c, m); return c; }
+int m2t_ensure_dynamic_lds(const void* k, int b) { return (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, b); }
+void m2t_prof_begin(int, hipStream_t) {}
+void m2t_prof_end(int, hipStream_t) {}
+bool m2t_prof_take(hipEvent_t*, hipEvent_t*) { return false; }
+
+#define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+static unsigned short f2bf(float f) { union { float f; unsigned u; } c; c.f = f; unsigned u = c.u; return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
+
+int main(int argc, char** argv) {
+  const int C = argc > 1 ? atoi(argv[1]) : 256;
+  const int B = argc > 2 ? atoi(argv[2]) : 16;
+  const int L = (C == 256) ? 2 : 1;
+  const int h = 128 >> L, w = h;
+  const size_t M = (size_t)B * h * w, full = (size_t)B * 128 * 128;
+  const int nwin = B * (h / 8) * (w / 8);
+  srand(1);
+  auto fill = [&](size_t n, float amp) { std::vector<unsigned short> v(n); for (auto& x : v) x = f2bf((rand() / (float)RAND_MAX - 0.5f) * amp); return v; };
+  auto hqkv = fill(M * 3 * C, 1.0f), hgo = fill(full * 64, 0.5f), hwd = fill((size_t)3 * C * C, 0.2f), hx = fill(M * C, 1.0f), hwf = fill((size_t)3 * C * C, 0.2f);
+  std::vector<float> hrel(10 * C); for (auto& v : hrel) v = (rand() / (float)RAND_MAX - 0.5f);
+  void *dqkv, *dgo, *dgqkv, *dwin, *dwd, *dgd, *dgdwin, *dx, *dwf; float *drel, *drelw;
+  CKH(hipMalloc(&dqkv, M * 3 * C * 2)); CKH(hipMalloc(&dgo, full * 64 * 2)); CKH(hipMalloc(&dgqkv, M * 3 * C * 2));
+  CKH(hipMalloc(&dwin, (size_t)nwin * 36 * 2 * C * 2)); CKH(hipMalloc(&dwd, (size_t)3 * C * C * 2)); CKH(hipMalloc(&dgd, M * C * 2));
+  CKH(hipMalloc(&dgdwin, (size_t)nwin * 36 * C * 2)); CKH(hipMalloc(&dx, M * C * 2)); CKH(hipMalloc(&dwf, (size_t)3 * C * C * 2));
+  CKH(hipMalloc(&drel, 10 * C * 4)); CKH(hipMalloc(&drelw, (size_t)nwin * 10 * C * 4));
+  CKH(hipMemcpy(dqkv, hqkv.data(), M * 3 * C * 2, hipMemcpyHostToDevice)); CKH(hipMemcpy(dgo, hgo.data(), full * 64 * 2, hipMemcpyHostToDevice));
+  CKH(hipMemcpy(dwd, hwd.data(), (size_t)3 * C * C * 2, hipMemcpyHostToDevice)); CKH(hipMemcpy(dx, hx.data(), M * C * 2, hipMemcpyHostToDevice));
+  CKH(hipMemcpy(dwf, hwf.data(), (size_t)3 * C * C * 2, hipMemcpyHostToDevice)); CKH(hipMemcpy(drel, hrel.data(), 10 * C * 4, hipMemcpyHostToDevice));
+#ifdef STAMPS
+  unsigned long long* dst;
+  CKH(hipMalloc(&dst, (size_t)nwin * 8 * 16 * 8)); CKH(hipMemset(dst, 0, (size_t)nwin * 8 * 16 * 8));
+  CKH(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dst, sizeof(dst)));
+#endif
+  hipStream_t st; CKH(hipStreamCreate(&st));
+  const bool rc = (C == 64);
+  // go: the full-resolution g_xc tensor, P64 plane of 16 channels (ld 16)
+  auto launch = [&]() { return launch_window_attn_bwd_resident(rc ? nullptr : dqkv, drel, drel + 5 * C, dgo, 16, 0, dgqkv, dwin, drelw, B, h, w, C, L, st, dwd, dgd, dgdwin,
+                                                               rc ? dx : nullptr, rc ? dwf : nullptr); };
+  for (int i = 0; i < 5; ++i) if (launch()) return 1;
+  CKH(hipStreamSynchronize(st));
+  hipEvent_t e0, e1; CKH(hipEventCreate(&e0)); CKH(hipEventCreate(&e1));
+  const int N = 40; std::vector<float> ts;
+  for (int i = 0; i < N; ++i) {
+    CKH(hipEventRecord(e0, st)); if (launch()) return 1; CKH(hipEventRecord(e1, st)); CKH(hipEventSynchronize(e1));
+    float ms; CKH(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms * 1e3f);
+  }
+  std::sort(ts.begin(), ts.end());
+  printf("bwd_res C=%d B=%d windows=%d: event-bracketed min %.2f us median %.2f us\n", C, B, nwin, ts[0], ts[N / 2]);
+  {   // output hashes of one launch into zeroed buffers (compare builds: identical hashes = identical bits)
+    const size_t n1 = M * 3 * C * 2, n2 = (size_t)nwin * 36 * 2 * C * 2, n3 = (size_t)nwin * 10 * C * 4, n4 = M * C * 2, n5 = (size_t)nwin * 36 * C * 2;
+    CKH(hipMemset(dgqkv, 0, n1)); CKH(hipMemset(dwin, 0, n2)); CKH(hipMemset(drelw, 0, n3)); CKH(hipMemset(dgd, 0, n4)); CKH(hipMemset(dgdwin, 0, n5));
+    if (launch()) return 1;
+    CKH(hipStreamSynchronize(st));
+    auto hash = [&](void* d, size_t n) { std::vector<unsigned char> hb(n); CKH(hipMemcpy(hb.data(), d, n, hipMemcpyDeviceToHost)); unsigned long long hsh = 1469598103934665603ull;
+      const unsigned long long* p8 = (const unsigned long long*)hb.data(); for (size_t i = 0; i < n / 8; ++i) { hsh ^= p8[i]; hsh *= 1099511628211ull; } return hsh; };
+    printf("  hashes: gqkv %016llx win %016llx relw %016llx gd %016llx gdwin %016llx\n", hash(dgqkv, n1), hash(dwin, n2), hash(drelw, n3), hash(dgd, n4), hash(dgdwin, n5));
+  }
+#ifdef STAMPS
+  std::vector<unsigned long long> hs((size_t)nwin * 8 * 16);
+  CKH(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
+  const int NW = (C == 256) ? 8 : 4;
+  const char* names[7] = {"phase0 loads -> LDS (+recompute)", "phase1 S, dP MFMA", "softmax, dS, row/col sums", "phase2 dV, dK^ MFMA", "relw, dV->LDS, dq MFMA, dK^/dq->LDS",
+                          "DG: g_d = [dq|dK^|dV] W", "g_d stores + gqkv/win stores"};
+  for (int wsel : {0, NW - 1}) {
+    printf("wave %d: median cycles per segment over %d workgroups\n", wsel, nwin);
+    for (int s = 0; s < 7; ++s) {
+      std::vector<long long> d;
+      for (int b = 0; b < nwin; ++b) { const unsigned long long a = hs[((size_t)b * 8 + wsel) * 16 + s], c = hs[((size_t)b * 8 + wsel) * 16 + s + 1]; if (a && c) d.push_back((long long)(c - a)); }
+      if (d.empty()) continue;
+      std::sort(d.begin(), d.end());
+      printf("  %-40s %8lld (min %lld max %lld)\n", names[s], d[d.size() / 2], d.front(), d.back());
+    }
+    std::vector<long long> d;
+    for (int b = 0; b < nwin; ++b) d.push_back((long long)(hs[((size_t)b * 8 + wsel) * 16 + 7] - hs[((size_t)b * 8 + wsel) * 16 + 0]));
+    std::sort(d.begin(), d.end());
+    printf("  total median %lld cycles\n", d[d.size() / 2]);
+  }
+  unsigned long long lo = ~0ull, hi = 0; std::vector<long long> st0, en;
+  for (int b = 0; b < nwin; ++b) for (int wv = 0; wv < NW; ++wv) { const unsigned long long a = hs[((size_t)b * 8 + wv) * 16 + 8], c = hs[((size_t)b * 8 + wv) * 16 + 15]; if (a) lo = std::min(lo, a); if (c) hi = std::max(hi, c); }
+  for (int b = 0; b < nwin; ++b) { st0.push_back((long long)(hs[((size_t)b * 8) * 16 + 8] - lo)); en.push_back((long long)(hs[((size_t)b * 8) * 16 + 15] - lo)); }
+  std::sort(st0.begin(), st0.end()); std::sort(en.begin(), en.end());
+  printf("  chip: first start -> last end %.2f us; start offsets median %.2f p90 %.2f max %.2f; end offsets min %.2f median %.2f max %.2f us\n", (hi - lo) * 0.01,
+         st0[st0.size() / 2] * 0.01, st0[st0.size() * 9 / 10] * 0.01, st0.back() * 0.01, en.front() * 0.01, en[en.size() / 2] * 0.01, en.back() * 0.01);
+#endif
+  return 0;
+}
