@@ -62,6 +62,9 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "gate_branch"       [-1] -1: a branch's side work is released right behind its attention launch; 0..3: a block's side work waits for the
  *                           attention launch of that branch (2 = behind the two LDS-filling C = 256 launches; the default of rounds 1-2,
  *                           when the main chain still waited for the side stream once per branch)
+ *   "fork_on_kernel"    [1] the event that releases side-stream work rides on the main-stream dispatch it follows (hipExtLaunchKernelGGL
+ *                           stop event) instead of a marker packet behind it: -0.7 % step time; 0 = hipEventRecord.  Ignored (0) while the
+ *                           stream is being captured into a HIP graph
  *   "wgrad_big_tiles"   [-1] qkv weight gradient of the C = 256 branches with 128 x 128 output tiles: value = target number of
  *                           workgroups (64..512), 0 = off, -1 = auto (256 from 24 576 branch pixels on, i.e. batch >= 24)
  *   "fused_tail"        [3] bf16 x4: 1 = one fused kernel for the high-resolution half of the tail backward (k_tail_bwd.hip); 2 = the same

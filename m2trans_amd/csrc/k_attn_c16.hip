@@ -638,7 +638,7 @@ int launch_c16_dgrad_prep(void* gqkv, const void* win, const void* wT, const voi
   const long long ntile = (long long)B * h * (w / 16);
   if (ntile * 16 * 48 >= (1LL << 31)) return m2t_set_error(-2, "c16_dgrad_prep: too many pixels for 32-bit tile indexing");
   const int grid = (int)std::min<long long>((ntile + 3) / 4, 4096);
-  hipLaunchKernelGGL(c16_dgrad_prep_kernel, dim3(grid), dim3(256), 0, st, (bf16_t*)gqkv, (const bf16_t*)win, (const bf16_t*)wT,
+  M2T_LAUNCH_TIMED(c16_dgrad_prep_kernel, dim3(grid), dim3(256), 0, st, (bf16_t*)gqkv, (const bf16_t*)win, (const bf16_t*)wT,
                      (const bf16_t*)gxc, (bf16_t*)gn, B, h, w);
   M2T_LAUNCH_CHECK();
   return 0;

@@ -73,6 +73,13 @@ void m2t_prof_begin(int cat, hipStream_t st) {
   if ((M2T_PROF_DISPATCH_CATS >> cat) & 1ull) return;           // the launcher takes the events (m2t_prof_take)
   (void)hipEventRecord(g_prof.pool[(size_t)g_open.slot].a, st);
 }
+namespace { thread_local hipEvent_t g_fork_armed = nullptr; }
+hipEvent_t m2t_fork_take() {
+  if (!g_fork_armed || (g_open.slot >= 0 && !g_open.taken)) return nullptr;     // a timing pair goes first; the fork then falls back to a record
+  hipEvent_t e = g_fork_armed;
+  g_fork_armed = nullptr;
+  return e;
+}
 bool m2t_prof_take(hipEvent_t* a, hipEvent_t* b) {
   if (g_open.slot < 0 || g_open.taken) return false;
   g_open.taken = true;
@@ -159,6 +166,8 @@ struct m2t_plan {
                                        // A/B -- same data gradient bits, 580 against 377 us stand-alone at batch 16
                                        // (with bf16 mode's exp2 / rcp GELU: 5.30 vs 5.34 ms per step and 1.6 GB less HBM traffic;
                                        // with the erf form of round 2 it was 1 % slower)
+  int fork_on_kernel = 1;              // a fork event rides on the dispatch it follows (its stop event) instead of a marker packet behind it:
+                                       // same-box A/B 4.757 -> 4.726 ms (config 1), 8.536 -> 8.469 (config 3); not under stream capture
   int gate_branch = -1;                // side-stream gate: -1 ungated (a branch's side work follows its attention launch), else the branch (3..0)
                                        // behind whose attention launch a block's parameter-gradient work is released.  Same-box A/B (config 1),
                                        // end of round 3 (one buffer-set wait per block instead of one per branch): ungated 4.84 ms, 2 = 4.95,
@@ -405,6 +414,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
   if (k.rfind("opt:", 0) == 0) {        // the options in force (profile.py prices the kernels that actually run)
     const std::string o = k.substr(4);
     if (o == "side_stream") return p->use_side;
+    if (o == "fork_on_kernel") return p->fork_on_kernel;
     if (o == "gate_branch") return p->gate_branch + 1000;      // (offset: -1 is the "unknown key" value of this function)
     if (o == "wgrad_big_tiles") return p->wgrad_big_tiles + 1000;
     if (o == "fused_tail") {
@@ -611,10 +621,23 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   hipStream_t sd = p->use_side ? p->side : st;
   size_t evi = 0;
   auto next_event = [&]() -> hipEvent_t { return p->events[(evi++) % p->events.size()]; };
+  // option "fork_on_kernel": arm_fork() in front of the launch the fork follows; the event then rides on that dispatch as its stop
+  // event (no marker packet between the kernel and its successor on the main stream).  fork() records as usual if nothing took it.
+  hipEvent_t armed = nullptr;
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap_status);
+  const bool fork_on_kernel = p->fork_on_kernel && cap_status == hipStreamCaptureStatusNone;   // an event-carrying dispatch is not a graph node
+  auto arm_fork = [&]() {
+    if (sd == st || !fork_on_kernel) return;
+    armed = next_event();
+    g_fork_armed = armed;
+  };
   auto fork = [&]() {            // side stream continues from this point of the main stream
     if (sd == st) return;
-    hipEvent_t e = next_event();
-    (void)hipEventRecord(e, st);
+    hipEvent_t e;
+    if (armed && g_fork_armed == nullptr) e = armed;            // taken by the launch
+    else { e = armed ? armed : next_event(); g_fork_armed = nullptr; (void)hipEventRecord(e, st); }
+    armed = nullptr;
     (void)hipStreamWaitEvent(sd, e, 0);
   };
   auto side_marker = [&]() -> hipEvent_t {
@@ -873,6 +896,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       // bf16 C = 16 with "attn_bwd" = 3: the overlap-add, the projection data gradient and branch_prep_bwd are one kernel behind
       // the attention backward; it completes dK|dV in gqkv, so the branch's side work is released after it
       const bool c16_prep = dt != M2T_F32 && C == 16 && p->use_c16_prep && p->use_fused_qkv_dgrad && p->use_resident_attn_bwd;
+      if (!gated && fused_dgrad(i)) arm_fork();
       if (fused_dgrad(i)) {
         M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256, st);
         const bool rc64 = C == 64 && p->c64_recompute();
@@ -918,6 +942,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         // own-window products are in gd; add the ring rows of the (<= 3) neighbouring windows to the border pixels
         CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st, WSP("gdwin")));
       } else if (c16_prep) {
+        if (!gated) arm_fork();
         CK(launch_c16_dgrad_prep(gqkv, win, packed_ptr(p, workspace, k + "w1T"), gxc, gn, B, H, W, st));
         CK(release_side());
       } else {
@@ -1002,6 +1027,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   p->red_uploaded = false;     // the deferred-reduction table depends on the schedule: rebuild it on the next backward
   const std::string k(key);
   if (k == "side_stream") { p->use_side = (value != 0); return 0; }
+  if (k == "fork_on_kernel") { p->fork_on_kernel = value != 0; return 0; }
   if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }
   if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
   if (k == "fused_tail") {

@@ -50,10 +50,14 @@ void m2t_prof_end(int cat, hipStream_t st);
                                 (1ull << M2T_PROF_ATTN_FUSED_64) | (1ull << M2T_PROF_ATTN_FUSED_256) | (1ull << M2T_PROF_TAIL_FWD_FUSED) | (1ull << M2T_PROF_ATTN_FUSED_16) | \
                                 (1ull << M2T_PROF_CONV3_BWD))
 bool m2t_prof_take(hipEvent_t* a, hipEvent_t* b);
+// an armed fork event (m2t_backward, option "fork_on_kernel") rides on the dispatch as its stop event instead of being recorded by
+// a marker packet behind it; nullptr when none is armed or a timing pair already took the dispatch
+hipEvent_t m2t_fork_take();
 #define M2T_LAUNCH_TIMED(kernel, grid, block, sh, st, ...)                                                       \
   do {                                                                                                           \
     hipEvent_t ea__, eb__;                                                                                       \
     if (m2t_prof_take(&ea__, &eb__)) hipExtLaunchKernelGGL(kernel, grid, block, sh, st, ea__, eb__, 0, __VA_ARGS__); \
+    else if (hipEvent_t ef__ = m2t_fork_take()) hipExtLaunchKernelGGL(kernel, grid, block, sh, st, nullptr, ef__, 0, __VA_ARGS__); \
     else hipLaunchKernelGGL(kernel, grid, block, sh, st, __VA_ARGS__);                                           \
   } while (0)
 struct M2TProfScope {

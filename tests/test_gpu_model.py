@@ -193,6 +193,30 @@ def test_bf16_fast_kernels_match_plain_kernels():
     assert not bad, bad
 
 
+def test_fork_event_on_the_dispatch_gives_the_same_bits_as_a_recorded_event():
+    """"fork_on_kernel": the event that releases a branch's side-stream work rides on the attention-backward dispatch as its stop
+    event (default) or is recorded behind it by a marker packet (0).  Same dependency either way: every gradient bit-identical,
+    three steps in a row (a missing dependency would show as a race between the side stream's reads and the next block's writes)."""
+    from m2trans_amd import _lib
+    scale, nb, B, H, W = 4, 2, 4, 128, 128
+    x = O.closed_form_image(B, 3, H, W).cuda()
+    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+    outs = []
+    for val in (1, 0):
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(x)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fork_on_kernel", val), "m2t_set_option")
+        assert plan.query("opt:fork_on_kernel") == val
+        grads = []
+        for _ in range(3):
+            model.zero_grad(set_to_none=True)
+            torch.nn.L1Loss()(model(x), hr).backward()
+            grads.append(torch.cat([q.grad.detach().reshape(-1) for q in model.parameters() if q.requires_grad]).clone())
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+        outs.append(grads[0])
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_profile_sampling_times_every_nth_dispatch():
     """m2t_profile_sample_every(n): the dispatch-timed categories put their HIP events on every n-th launch only (bench.py uses
     n = 3 on the dominant kernel: an event-carrying dispatch costs ~10 us of launch path).  Two blocks launch the C = 256 attention
