@@ -94,11 +94,27 @@ __device__ __forceinline__ bf16x4 pack4(const f32x4& a) {
   return r;
 }
 
-template <int C, int L, int NW>
+// PREP: branch_prep of this branch (models/M2Trans_network.py:141-158: xin = (norm(x)[chunk k] + xc[chunk k - 1]) / 2, d = DWT^L(xin))
+// runs inside phase 0 instead of in its own launch in front of this kernel: the window computes xin for the (2^L)^2 pixel blocks
+// of its 100 keys (halo blocks redundantly, like their projections) from the two P64 planes -- 16-byte loads that run along
+// image rows, 10 * 2^L * 32 contiguous bytes per (key row, pixel row) --, rounds it to bf16 exactly where branch_prep_tiled_kernel
+// stores it, transforms every (key, channel) in place in LDS with the same Haar<L>::fwd, and writes xin (the residual of its own
+// epilogue) and the d rows (the backward's operand) of its OWN pixels only.  Same operations in the same order: identical bits.
+struct FusedPrepArgs {
+  const bf16_t* xn;        // plane k of the block input X  [B][H][W][16]
+  const bf16_t* xprev;     // plane k - 1 of the concat buffer xc
+  const float* mean;       // [B][64] / [B][64] statistics of X
+  const float* rstd;
+  bf16_t* xin;             // [B][H][W][16] (written: own pixels)
+  bf16_t* d;               // [B][h][w][C]  (written: own pixels)
+  int k;
+};
+template <int C, int L, int NW, bool PREP = false>
 __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wfrag,
                                                                         const float* __restrict__ rel_h, const float* __restrict__ rel_w,
                                                                         bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ldo, int oc0,
-                                                                        const bf16_t* __restrict__ res, int ldr, int h, int w) {
+                                                                        const bf16_t* __restrict__ res, int ldr, int h, int w,
+                                                                        FusedPrepArgs pa) {
   using T = bf16_t;
   using Cfg = FusedCfg<C>;
   constexpr int LD = Cfg::LD, PLD = Cfg::PLD, OLD = Cfg::OLD, ZR = Cfg::ZR;
@@ -140,7 +156,99 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
   constexpr int XIT = (101 * VEC + NTHR - 1) / NTHR;          // row 100 = the zero row: written like any other row
   constexpr int RIT = (10 * C / 4 + NTHR - 1) / NTHR;         // rel table [10][C] fp32 as float4s
   WKV wbuf[DEPTH + 1];
-  {
+  if constexpr (PREP) {
+    static_assert(L >= 1, "branch_prep in front of an L = 0 branch is the identity on d");
+    constexpr int S = 1 << L, NPX = S * S;
+    constexpr int NITEM = 100 * NPX * 2, PIT = (NITEM + NTHR - 1) / NTHR;      // 16-byte items: [key row][pixel row][key col][pixel col][half]
+    static_assert(NTHR % 2 == 0, "a thread's channel half is the same in every item");
+    const int half = tid & 1;
+    float mu[8], rs[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { mu[c] = pa.mean[gm.b * 64 + pa.k * 16 + half * 8 + c]; rs[c] = pa.rstd[gm.b * 64 + pa.k * 16 + half * 8 + c]; }
+    const int H = h * S, W = w * S;
+    Frag8<T> xf[PIT], pf[PIT];
+    bool ok[PIT];
+    f32x4 rf[RIT];
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int i = min(tid + it * NTHR, NITEM - 1);
+      const int px = (i >> 1) % S, kx = (i / (2 * S)) % 10, py = (i / (20 * S)) % S, ky = i / (20 * NPX);
+      const int yy = 8 * gm.wy + ky - 1, xx = 8 * gm.wx + kx - 1;
+      ok[it] = yy >= 0 && yy < h && xx >= 0 && xx < w;
+      const int Y = S * min(max(yy, 0), h - 1) + py, X = S * min(max(xx, 0), w - 1) + px;     // clamped: the loads are unconditional
+      const long long o = (((long long)gm.b * H + Y) * W + X) * 16 + half * 8;
+      xf[it] = load8(pa.xn + o);
+      pf[it] = load8(pa.xprev + o);
+    }
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      const int idx = min(tid + it * NTHR, 10 * C / 4 - 1);
+      const int kk = idx / (C / 4), c4 = (idx % (C / 4)) * 4;
+      const float* rp = (c4 < C / 2) ? (rel_h + kk * (C / 2) + c4) : (rel_w + kk * (C / 2) + (c4 - C / 2));
+      rf[it] = *reinterpret_cast<const f32x4*>(rp);
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) wbuf[d] = wkv(d);
+    // xin -> the key's LDS row as [pixel][16 channels] (and, for the window's own pixels, -> HBM: the epilogue's residual)
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+      const int i = tid + it * NTHR;
+      const int ic = min(i, NITEM - 1);
+      const int px = (ic >> 1) % S, kx = (ic / (2 * S)) % 10, py = (ic / (20 * S)) % S, ky = ic / (20 * NPX);
+      const bool own = ky >= 1 && ky <= 8 && kx >= 1 && kx <= 8;
+      const int row = own ? (ky - 1) * 8 + (kx - 1) : 64 + ring_index(ky, kx);
+      float q[8];
+#pragma unroll
+      for (int c = 0; c < 8; c += 2) {
+        f32x2 v = ((f32x2){xf[it].get(c), xf[it].get(c + 1)} - (f32x2){mu[c], mu[c + 1]}) * (f32x2){rs[c], rs[c + 1]};
+        v = (v + (f32x2){pf[it].get(c), pf[it].get(c + 1)}) * (f32x2){0.5f, 0.5f};
+        q[c] = ok[it] ? v[0] : 0.f;
+        q[c + 1] = ok[it] ? v[1] : 0.f;
+      }
+      if (i < NITEM) {
+        store8f(&Xs[row][(py * S + px) * 16 + half * 8], q);
+        if (own) {
+          const int Y = S * (8 * gm.wy + ky - 1) + py, X = S * (8 * gm.wx + kx - 1) + px;
+          store8f(pa.xin + (((long long)gm.b * H + Y) * W + X) * 16 + half * 8, q);
+        }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      const int idx = min(tid + it * NTHR, 10 * C / 4 - 1);
+      *reinterpret_cast<f32x4*>(&RelS[idx / (C / 4)][(idx % (C / 4)) * 4]) = rf[it];
+    }
+    if (tid < VEC) { store8(&Kh[ZR][tid * 8], frag_zero<T>()); store8(&Xs[ZR][tid * 8], frag_zero<T>()); }
+    M2T_FUSED_STAMP(10);
+    lds_barrier();
+    M2T_FUSED_STAMP(11);
+    // DWT^L in place, four channels per item (8-byte LDS accesses; two-byte ones cost the same issue slot each and made this
+    // loop 5 k cycles): element (pixel p, channel c) and element (band p, channel c) share an address
+    // lane -> (row, channel group) so that the 32 lanes of a half-wave cover all 64 banks once: rows are 132 words apart
+    // (4 banks mod 64), a lane reads 2 words, so 16 rows x 2 channel groups = 64 distinct banks
+    for (int i = tid; i < 112 * 4; i += NTHR) {
+      const int row = 16 * (i >> 6) + (i & 15), cg = (i >> 4) & 3;
+      if (row >= 100) continue;
+      bf16x4 raw[NPX];
+#pragma unroll
+      for (int n = 0; n < NPX; ++n) raw[n] = *reinterpret_cast<const bf16x4*>(&Xs[row][n * 16 + 4 * cg]);
+      f32x2 o[2][NPX];
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        f32x2 v[S][S];
+#pragma unroll
+        for (int y = 0; y < S; ++y)
+#pragma unroll
+          for (int xx = 0; xx < S; ++xx) v[y][xx] = (f32x2){(float)raw[y * S + xx][2 * c2], (float)raw[y * S + xx][2 * c2 + 1]};
+        Haar2<L>::fwd(v, o[c2]);
+      }
+#pragma unroll
+      for (int n = 0; n < NPX; ++n) {
+        const bf16x4 ov = {(bf16_t)o[0][n][0], (bf16_t)o[0][n][1], (bf16_t)o[1][n][0], (bf16_t)o[1][n][1]};
+        *reinterpret_cast<bf16x4*>(&Xs[row][n * 16 + 4 * cg]) = ov;
+      }
+    }
+  } else {
     Frag8<T> xf[XIT];
     bool ok[XIT];
     f32x4 rf[RIT];
@@ -233,22 +341,49 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
     }
   M2T_FUSED_STAMP(2);
 
-  // the residual rows of the epilogue: fetched before the first global store (vmcnt retires in order)
+  // the residual rows of the epilogue.  Without PREP they are fetched here, before the first global store (vmcnt retires in order).
+  // With PREP they are this kernel's own xin stores of phase 0, written by other waves: every wave's stores have retired when it has
+  // consumed its last weight fragment (in-order vmcnt; the release fence below states it), so the loads are issued behind the
+  // NEXT barrier instead (a barrier here would make the waves that finish the projection early wait for the late ones before they
+  // start their stores: +4 k cycles, measured).  They are consumed 10 k cycles later, when the q | k stores in front of them have long
+  // been acknowledged.
   constexpr int ES = Haar<L>::S, EPARTS = (L == 0) ? 1 : NTHR / 256, EROWS = (L == 0) ? 1 : ES / EPARTS;
   bf16x4 resv[EROWS][(L == 0) ? 1 : ES];
   const int e_item = tid & 255, e_part = tid >> 8;
   const int e_q = e_item >> 2, e_cg = e_item & 3;
-  if constexpr (L > 0) {
-    const int H = h * ES, W = w * ES;
-    const int by = 8 * gm.wy + (e_q >> 3), bx = 8 * gm.wx + (e_q & 7);
+  auto load_residual = [&]() {
+    if constexpr (L > 0) {
+      const int H = h * ES, W = w * ES;
+      const int by = 8 * gm.wy + (e_q >> 3), bx = 8 * gm.wx + (e_q & 7);
 #pragma unroll
-    for (int yy = 0; yy < EROWS; ++yy)
+      for (int yy = 0; yy < EROWS; ++yy)
 #pragma unroll
-      for (int xx = 0; xx < ES; ++xx) {
-        const long long pix = ((long long)gm.b * H + ES * by + e_part * EROWS + yy) * W + ES * bx + xx;
-        resv[yy][xx] = *reinterpret_cast<const bf16x4*>(res + pix * ldr + 4 * e_cg);
+        for (int xx = 0; xx < ES; ++xx) {
+          const long long pix = ((long long)gm.b * H + ES * by + e_part * EROWS + yy) * W + ES * bx + xx;
+          resv[yy][xx] = *reinterpret_cast<const bf16x4*>(res + pix * ldr + 4 * e_cg);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if constexpr (!PREP) load_residual();
+  else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if constexpr (PREP) {
+    // the d rows of the window's own pixels (LDS rows 0..63, intact until v overwrites them behind the next barrier) leave as whole rows
+    constexpr int DIT = (64 * VEC + NTHR - 1) / NTHR;
+#pragma unroll
+    for (int it = 0; it < DIT; it += 2) {
+      Frag8<T> dr[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = min(tid + (it + u) * NTHR, 64 * VEC - 1);
+        dr[u] = load8(&Xs[idx / VEC][(idx % VEC) * 8]);
       }
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = tid + (it + u) * NTHR;
+        if (it + u < DIT && idx < 64 * VEC) store8(pa.d + gm.query_pixel(idx / VEC) * C + (idx % VEC) * 8, dr[u]);
+      }
+    }
   }
 
   // ---- phase 2: accumulators -> LDS / HBM ----
@@ -280,6 +415,10 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
   }
   lds_barrier();                        // every wave is done reading x and the rel-pos table; Kh and Qs are complete
   M2T_FUSED_STAMP(3);
+  if constexpr (PREP) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    load_residual();
+  }
 #pragma unroll
   for (int t = 0; t < WA_KT; ++t) {
     const int key = 16 * t + lr;
@@ -447,13 +586,13 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
   M2T_FUSED_STAMP(7);
 }
 
-template <int C, int L, int NW>
+template <int C, int L, int NW, bool PREP = false>
 int go_fused(const bf16_t* x, const bf16_t* wfrag, const float* rel_h, const float* rel_w, bf16_t* qkv, bf16_t* out, int ldo, int oc0,
-             const bf16_t* res, int ldr, int nwin, int h, int w, hipStream_t st) {
+             const bf16_t* res, int ldr, int nwin, int h, int w, hipStream_t st, FusedPrepArgs pa = FusedPrepArgs{}) {
   const size_t sh = FusedCfg<C>::total;
-  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_fused_fwd_kernel<C, L, NW>, (int)sh)) return rc__;
-  M2T_LAUNCH_TIMED((window_attn_fused_fwd_kernel<C, L, NW>), dim3(nwin), dim3(NW * 64), sh, st, x, wfrag, rel_h, rel_w, qkv, out, ldo,
-                   oc0, res, ldr, h, w);
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_fused_fwd_kernel<C, L, NW, PREP>, (int)sh)) return rc__;
+  M2T_LAUNCH_TIMED((window_attn_fused_fwd_kernel<C, L, NW, PREP>), dim3(nwin), dim3(NW * 64), sh, st, x, wfrag, rel_h, rel_w, qkv, out, ldo,
+                   oc0, res, ldr, h, w, pa);
   return 0;
 }
 
@@ -479,6 +618,27 @@ int launch_window_attn_fused_fwd(const void* x_, const void* wfrag_, const float
   M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_FUSED_64 : M2T_PROF_ATTN_FUSED_256, st);
   if (C == 256 && post_levels == 2) rc = go_fused<256, 2, 8>(x, wfrag, rel_h, rel_w, qkv, out, ldo, oc0, res, ldr, nwin, h, w, st);
   else if (C == 64 && post_levels == 1) rc = go_fused<64, 1, 4>(x, wfrag, rel_h, rel_w, qkv, out, ldo, oc0, res, ldr, nwin, h, w, st);
+  if (rc != 0) return rc;
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same with branch_prep inside (bf16, k >= 1): xn = plane k of the block input, xprev = plane k - 1 of xc (both [B][H][W][16], H = h 2^L),
+// mean / rstd [B][64]; xin [B][H][W][16] and d [B][h][w][C] are WRITTEN (own pixels of every window = every pixel once); out = plane k of xc.
+int launch_window_attn_fused_prep_fwd(const void* xn, const void* xprev, const float* mean, const float* rstd, int k, void* xin, void* d,
+                                      const void* wfrag_, const float* rel_h, const float* rel_w, void* qkv_, void* out_, int B, int h, int w,
+                                      int C, int post_levels, hipStream_t st) {
+  if (h % 8 || w % 8) return m2t_set_error(-2, "window_attn_fused_prep: h,w must be multiples of 8");
+  if (!xn || !xprev || !mean || !rstd || !xin || !d || k < 1 || k > 3) return m2t_set_error(-2, "window_attn_fused_prep: null argument or k outside 1..3");
+  if (!((C == 256 && post_levels == 2) || (C == 64 && post_levels == 1)))
+    return m2t_set_error(M2T_UNSUPPORTED, "window_attn_fused_prep: unsupported (C, post_levels); built for (64, 1) and (256, 2)");
+  FusedPrepArgs pa;
+  pa.xn = (const bf16_t*)xn; pa.xprev = (const bf16_t*)xprev; pa.mean = mean; pa.rstd = rstd; pa.xin = (bf16_t*)xin; pa.d = (bf16_t*)d; pa.k = k;
+  const int nwin = B * (h / 8) * (w / 8);
+  int rc;
+  M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_FUSED_64 : M2T_PROF_ATTN_FUSED_256, st);
+  if (C == 256) rc = go_fused<256, 2, 8, true>(nullptr, (const bf16_t*)wfrag_, rel_h, rel_w, (bf16_t*)qkv_, (bf16_t*)out_, 16, 0, (const bf16_t*)xin, 16, nwin, h, w, st, pa);
+  else rc = go_fused<64, 1, 4, true>(nullptr, (const bf16_t*)wfrag_, rel_h, rel_w, (bf16_t*)qkv_, (bf16_t*)out_, 16, 0, (const bf16_t*)xin, 16, nwin, h, w, st, pa);
   if (rc != 0) return rc;
   M2T_LAUNCH_CHECK();
   return 0;

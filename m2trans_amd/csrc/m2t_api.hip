@@ -166,6 +166,7 @@ struct m2t_plan {
                                        // A/B -- same data gradient bits, 580 against 377 us stand-alone at batch 16
                                        // (with bf16 mode's exp2 / rcp GELU: 5.30 vs 5.34 ms per step and 1.6 GB less HBM traffic;
                                        // with the erf form of round 2 it was 1 % slower)
+  int use_fused_prep_fwd = 1;          // bf16 C = 64 / 256 branches: branch_prep inside the fused forward attention kernel (round 4)
   int fork_on_kernel = 1;              // a fork event rides on the dispatch it follows (its stop event) instead of a marker packet behind it:
                                        // same-box A/B 4.757 -> 4.726 ms (config 1), 8.536 -> 8.469 (config 3); not under stream capture
   int gate_branch = -1;                // side-stream gate: -1 ungated (a branch's side work follows its attention launch), else the branch (3..0)
@@ -415,6 +416,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     const std::string o = k.substr(4);
     if (o == "side_stream") return p->use_side;
     if (o == "fork_on_kernel") return p->fork_on_kernel;
+    if (o == "fused_prep_fwd") return p->use_fused_prep_fwd;
     if (o == "gate_branch") return p->gate_branch + 1000;      // (offset: -1 is the "unknown key" value of this function)
     if (o == "wgrad_big_tiles") return p->wgrad_big_tiles + 1000;
     if (o == "fused_tail") {
@@ -496,6 +498,14 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
         if (dt != M2T_F32 && p->use_fused_c16_fwd != 0 && i == 0) {
           // x1 = attn1(norm(x)[chunk 0]) + norm(x)[chunk 0] (:135-139): one launch, d1 and qkv1 written for the backward
           CK(launch_window_attn_fused_c16_fwd(X, mean, rstd, packed_ptr(p, workspace, k + "w1"), rh, rw, d, p->c16_recompute() ? nullptr : qkv, xc_i, 16, 0, B, h, w, st));
+          continue;
+        }
+        if (dt != M2T_F32 && p->use_fused_attn_fwd != 0 && p->use_fused_prep_fwd && C >= 64 && i >= 1) {
+          // branch_prep (norm apply + mix + DWT^L), the qkv projection, the window attention and IWT^L / residual in one kernel
+          const void* xn_i = (const char*)X + (size_t)i * BP * 16 * p->esz;
+          const void* xprev = (const char*)xc + (size_t)(i - 1) * BP * 16 * p->esz;
+          CK(launch_window_attn_fused_prep_fwd(xn_i, xprev, mean, rstd, i, WSP("xin"), d, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "F"),
+                                               rh, rw, (C == 64 && p->c64_recompute()) ? nullptr : qkv, xc_i, B, h, w, C, L, st));
           continue;
         }
         CK(launch_branch_prep(dt, L, X, mean, rstd, xc, i, WSP("xin"), d, B, H, W, st));
@@ -1028,6 +1038,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   const std::string k(key);
   if (k == "side_stream") { p->use_side = (value != 0); return 0; }
   if (k == "fork_on_kernel") { p->fork_on_kernel = value != 0; return 0; }
+  if (k == "fused_prep_fwd") { p->use_fused_prep_fwd = value != 0; return 0; }
   if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }
   if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
   if (k == "fused_tail") {

@@ -241,6 +241,9 @@ int launch_window_attn_fused_c16_fwd(const void* x, const float* mean, const flo
 int launch_window_attn_fused_fwd(const void* x, const void* wfrag, const float* rel_h, const float* rel_w, void* qkv, void* out,
                                  int ldo, int oc0, const void* res, int ldr, int B, int h, int w, int C, int post_levels,
                                  hipStream_t st);
+int launch_window_attn_fused_prep_fwd(const void* xn, const void* xprev, const float* mean, const float* rstd, int k, void* xin, void* d,
+                                      const void* wfrag, const float* rel_h, const float* rel_w, void* qkv, void* out, int B, int h, int w,
+                                      int C, int post_levels, hipStream_t st);
 // relw [nwin][10][C] per-window partials -> grel_h / grel_w (torch layouts)
 int launch_rel_reduce(const float* relw, float* rel_part, float* grel_h, float* grel_w, int nwin, int C, hipStream_t st);
 int launch_rel_reduce1(const float* relw, float* rel_part, int nwin, int C, int* nsplit_out, hipStream_t st);

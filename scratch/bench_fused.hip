@@ -19,6 +19,7 @@ int m2t_ensure_dynamic_lds(const void* k, int b) { return (int)hipFuncSetAttribu
 void m2t_prof_begin(int, hipStream_t) {}
 void m2t_prof_end(int, hipStream_t) {}
 bool m2t_prof_take(hipEvent_t*, hipEvent_t*) { return false; }
+hipEvent_t m2t_fork_take() { return nullptr; }
 
 #define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -58,7 +59,14 @@ int main(int argc, char** argv) {
   const bool cold = argc > 3 && atoi(argv[3]) != 0;
   void* dflush = nullptr; const size_t flush_bytes = (size_t)512 << 20;
   if (cold) CKH(hipMalloc(&dflush, flush_bytes));
-  auto launch = [&]() { return launch_window_attn_fused_fwd(dx, dwf, drel, drel + 5 * C, dqkv, dout, 16, 0, dres, 16, B, h, w, C, L, st); };
+  const bool prep = argc > 4 && atoi(argv[4]) != 0;        // branch_prep inside the kernel: dres doubles as plane k of X, dout2 as plane k - 1 of xc
+  void *dxin, *dd, *dprev; float* dstat;
+  CKH(hipMalloc(&dxin, full * 16 * 2)); CKH(hipMalloc(&dd, M * C * 2)); CKH(hipMalloc(&dprev, full * 16 * 2)); CKH(hipMalloc(&dstat, (size_t)B * 64 * 2 * 4));
+  CKH(hipMemcpy(dprev, hres.data(), full * 16 * 2, hipMemcpyHostToDevice));
+  { std::vector<float> hs2((size_t)B * 64 * 2, 1.0f); for (size_t i = 0; i < (size_t)B * 64; ++i) hs2[i] = 0.01f * (float)(i % 7); CKH(hipMemcpy(dstat, hs2.data(), hs2.size() * 4, hipMemcpyHostToDevice)); }
+  auto launch = [&]() {
+    if (prep) return launch_window_attn_fused_prep_fwd(dres, dprev, dstat, dstat + (size_t)B * 64, 2, dxin, dd, dwf, drel, drel + 5 * C, dqkv, dout, B, h, w, C, L, st);
+    return launch_window_attn_fused_fwd(dx, dwf, drel, drel + 5 * C, dqkv, dout, 16, 0, dres, 16, B, h, w, C, L, st); };
   for (int i = 0; i < 5; ++i) if (launch()) return 1;
   CKH(hipStreamSynchronize(st));
   hipEvent_t e0, e1; CKH(hipEventCreate(&e0)); CKH(hipEventCreate(&e1));
@@ -92,6 +100,12 @@ int main(int argc, char** argv) {
       if (d.empty()) continue;
       std::sort(d.begin(), d.end());
       printf("  %-28s %8lld (min %lld max %lld)\n", names[s], d[d.size() / 2], d.front(), d.back());
+    }
+    {
+      std::vector<long long> d1, d2, d3;
+      for (int b = 0; b < nwin; ++b) { const unsigned long long* r = &hs[((size_t)b * 8 + wsel) * 16]; if (r[10] && r[11]) { d1.push_back((long long)(r[10] - r[0])); d2.push_back((long long)(r[11] - r[10])); d3.push_back((long long)(r[1] - r[11])); } }
+      if (!d1.empty()) { std::sort(d1.begin(), d1.end()); std::sort(d2.begin(), d2.end()); std::sort(d3.begin(), d3.end());
+        printf("  (phase 0 with branch_prep: loads + xin -> LDS %lld, barrier %lld, Haar in place + barrier %lld)\n", d1[d1.size() / 2], d2[d2.size() / 2], d3[d3.size() / 2]); }
     }
     std::vector<long long> d;
     for (int b = 0; b < nwin; ++b) d.push_back((long long)(hs[((size_t)b * 8 + wsel) * 16 + 7] - hs[((size_t)b * 8 + wsel) * 16 + 0]));

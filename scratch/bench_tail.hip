@@ -46,6 +46,7 @@ int m2t_ensure_dynamic_lds(const void* k, int b) { return (int)hipFuncSetAttribu
 void m2t_prof_begin(int, hipStream_t) {}
 void m2t_prof_end(int, hipStream_t) {}
 bool m2t_prof_take(hipEvent_t*, hipEvent_t*) { return false; }
+hipEvent_t m2t_fork_take() { return nullptr; }
 #define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 static unsigned short f2bf(float f) { union { float f; unsigned u; } c; c.f = f; unsigned u = c.u; return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
 static float frand() { return rand() / (float)RAND_MAX - 0.5f; }

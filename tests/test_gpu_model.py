@@ -193,6 +193,33 @@ def test_bf16_fast_kernels_match_plain_kernels():
     assert not bad, bad
 
 
+@pytest.mark.parametrize("shape", [(4, 2, 128, 128), (4, 3, 64, 96)])
+def test_branch_prep_inside_the_fused_forward_attention_is_bit_identical(shape):
+    """"fused_prep_fwd": norm apply + branch mixing + DWT^L of the C = 64 / 256 branches run inside the fused forward attention kernel
+    (each window also computes the blocks of its 36 halo keys) instead of in branch_prep launches in front of it.  Same operations,
+    same rounding points: the output, the stored branch inputs d2..d4 and every gradient are bit-identical.  The second shape has
+    windows on every image border (3 x 3 and 1 x ... window grids at the coarse levels)."""
+    from m2trans_amd import _lib
+    scale, B, H, W = shape
+    nb = 2
+    x = O.closed_form_image(B, 3, H, W).cuda()
+    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+    outs = []
+    for val in (1, 0):
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(x)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_prep_fwd", val), "m2t_set_option")
+        assert plan.query("opt:fused_prep_fwd") == val
+        sr = model(x)
+        ds = [plan.ws_tensor(f"b{b}.d{i}").clone() for b in range(nb) for i in (2, 3, 4)]
+        torch.nn.L1Loss()(sr, hr).backward()
+        outs.append((sr.detach().clone(), ds, torch.cat([q.grad.detach().reshape(-1) for q in model.parameters() if q.requires_grad]).clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][2], outs[1][2])
+
+
 def test_fork_event_on_the_dispatch_gives_the_same_bits_as_a_recorded_event():
     """"fork_on_kernel": the event that releases a branch's side-stream work rides on the attention-backward dispatch as its stop
     event (default) or is recorded behind it by a marker packet (0).  Same dependency either way: every gradient bit-identical,
