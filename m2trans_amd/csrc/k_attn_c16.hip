@@ -587,13 +587,29 @@ __global__ void __launch_bounds__(256) c16_dgrad_prep_kernel(bf16_t* __restrict_
     float a0[8], a1[8], r0[3][8], r1[3][8], px4[4];
     load8f(row + col0, a0);
     load8f(row + col1, a1);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {                     // unconditional loads from a clamped source, selected below
-      const long long o = a < nsrc ? hoff[a] : 0;
-      load8f(win + o + ring0, r0[a]);
-      load8f(win + o + ring1, r1[a]);
+    // unconditional loads from a clamped source, selected below.  Only a corner pixel has a second and third source, and corners lie
+    // on the first / last row of a window: the wave's row decides (uniformly) whether those four loads are issued at all
+    const int wy = y >> 3, py = y & 7;
+    const bool border_row = (py == 0 && wy > 0) || (py == 7 && wy < nh - 1);
+    {
+      const long long o = 0 < nsrc ? hoff[0] : 0;
+      load8f(win + o + ring0, r0[0]);
+      load8f(win + o + ring1, r1[0]);
     }
     load4(gxc + pix * 16 + 4 * g, px4);
+    if (border_row) {
+#pragma unroll
+      for (int a = 1; a < 3; ++a) {
+        const long long o = a < nsrc ? hoff[a] : 0;
+        load8f(win + o + ring0, r0[a]);
+        load8f(win + o + ring1, r1[a]);
+      }
+    } else {
+#pragma unroll
+      for (int a = 1; a < 3; ++a)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { r0[a][e] = 0.f; r1[a][e] = 0.f; }
+    }
     const bool gather0 = g >= 2 && nsrc > 0, gather1 = g < 2 && nsrc > 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {

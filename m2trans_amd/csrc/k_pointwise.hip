@@ -654,6 +654,18 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_tiled_kernel(const bf16_t
   const long long npix = (long long)B * H * W;
   const int x0 = tc * TX;
   const bf16_t* sp = gd + (((long long)b * (H / S) + i) * (W / S) + x0 / S) * BW;
+  // the read-modify-write operands of phase C are requested first: their HBM round trip then runs under phases A and B instead
+  // of behind them (the workgroup is three dependent memory phases long; this removes one of its two exposed round trips)
+  constexpr int CIT = (NV + 255) / 256;
+  Frag8<bf16_t> pc[CIT], ppc[CIT];
+#pragma unroll
+  for (int it = 0; it < CIT; ++it) {
+    const int v = min(tid + it * 256, NV - 1);
+    const int row = v / (2 * TX), cv = v % (2 * TX), px = cv >> 1, half = cv & 1;
+    const long long pix = ((long long)b * H + S * i + row) * W + x0 + px;
+    pc[it] = load8(gxc + ((long long)k * npix + pix) * 16 + half * 8);
+    ppc[it] = load8(gxc + ((long long)(k - 1) * npix + pix) * 16 + half * 8);
+  }
   if (!gdwin) {
     for (int v = tid; v < NB * VB; v += 256) store8(&D[0][0] + v * 8, load8(sp + v * 8));
   } else {
@@ -686,19 +698,21 @@ __global__ void __launch_bounds__(256) branch_prep_bwd_tiled_kernel(const bf16_t
       for (int xx = 0; xx < S; ++xx) V[y][S * blk + xx][ch] = vv[y][xx];
   }
   __syncthreads();
-  for (int v = tid; v < NV; v += 256) {
-    const int row = v / (2 * TX), cv = v % (2 * TX), px = cv >> 1, half = cv & 1;
-    const long long pix = ((long long)b * H + S * i + row) * W + x0 + px;
-    float p[8], pp[8], q[8];
-    load8f(gxc + ((long long)k * npix + pix) * 16 + half * 8, p);
-    load8f(gxc + ((long long)(k - 1) * npix + pix) * 16 + half * 8, pp);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      q[c] = (V[row][px][half * 8 + c] + p[c]) * 0.5f;
-      pp[c] += q[c];
+  for (int it = 0; it < CIT; ++it) {
+    const int v = tid + it * 256;
+    if (v < NV) {
+      const int row = v / (2 * TX), cv = v % (2 * TX), px = cv >> 1, half = cv & 1;
+      const long long pix = ((long long)b * H + S * i + row) * W + x0 + px;
+      float pp[8], q[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        q[c] = (V[row][px][half * 8 + c] + pc[it].get(c)) * 0.5f;
+        pp[c] = ppc[it].get(c) + q[c];
+      }
+      store8f(gn + ((long long)k * npix + pix) * 16 + half * 8, q);
+      store8f(gxc + ((long long)(k - 1) * npix + pix) * 16 + half * 8, pp);
     }
-    store8f(gn + ((long long)k * npix + pix) * 16 + half * 8, q);
-    store8f(gxc + ((long long)(k - 1) * npix + pix) * 16 + half * 8, pp);
   }
 }
 
