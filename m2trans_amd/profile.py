@@ -78,7 +78,7 @@ def read_all():
 def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8, fused_attn_fwd: bool | None = None,
                      fused_tail_fwd: bool = False, fused_qkv_dgrad: bool | None = None, fused_c16_fwd: bool | None = None,
                      c16_recompute: bool | None = None, c64_recompute: bool | None = None, fused_conv_bwd: bool | None = None,
-                     c16_prep: bool | None = None):
+                     c16_prep: bool | None = None, fused_prep_fwd: bool | None = None):
     """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr.
     fused_attn_fwd (default: bf16 mode): the C = 64 / 256 branches run qkv projection + attention as one kernel, so
     the forward `gemm_qkv` / `attn_fwd_*` categories are then empty (the C = 16 branch runs InstanceNorm apply +
@@ -93,6 +93,8 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         c16_recompute = dtype == "bf16"
     if c64_recompute is None:             # plan option "fused_attn_fwd" = 2 (default in bf16 mode): qkv2 is not stored
         c64_recompute = dtype == "bf16"
+    if fused_prep_fwd is None:            # plan option "fused_prep_fwd" (bf16 default): branch_prep inside the fused forward attention kernels
+        fused_prep_fwd = dtype == "bf16" and bool(fused_attn_fwd)
     if c16_prep is None:                  # plan option "attn_bwd" = 3 (default in bf16 mode): no data-gradient GEMM for the C = 16 branch either
         c16_prep = dtype == "bf16" and bool(fused_qkv_dgrad)
     if fused_conv_bwd is None:            # plan option "fused_conv_bwd" (default on in bf16 mode)
@@ -121,7 +123,10 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         if (fused_c16_fwd if C_ == 16 else fused_attn_fwd):
             # reads x (+ the residual rows for C >= 64; for C = 16 the residual IS x), writes qkv + out (+ d1 for C = 16;
             # with recompute the C = 16 kernel writes d1 and out only)
-            add(f"attn_fused_c{C_}", nb * (win * 25600.0 * C_ + 2.0 * M * C_ * 3 * C_), nb * M * (3 if rc else 6) * C_ * es, nb)   # (C = 64 with recompute: x, residual in, out written = 3 C too)
+            # with branch_prep inside (C >= 64): reads the block-input plane and the previous branch's output plane (C per low-resolution
+            # pixel each) instead of d and the residual, and writes d as well (xin, its own residual, is a temporary: not priced)
+            pf = 1 if (fused_prep_fwd and C_ >= 64) else 0
+            add(f"attn_fused_c{C_}", nb * (win * 25600.0 * C_ + 2.0 * M * C_ * 3 * C_), nb * M * ((3 if rc else 6) + pf) * C_ * es, nb)   # (C = 64 with recompute: x, residual in, out written = 3 C too)
         else:
             add(f"attn_fwd_c{C_}", nb * win * 25600.0 * C_, nb * M * (4 * C_ + (C_ if C_ == 16 else 0)) * es, nb)
             add("gemm_qkv", nb * 2.0 * M * C_ * 3 * C_, nb * M * 4 * C_ * es, nb)
@@ -188,7 +193,7 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
 def plan_options(plan) -> dict:
     """The kernel-selection options in force on a plan (m2t_plan_query("opt:<key>")): which kernels ran decides which
     rows of `algorithmic_work` apply."""
-    o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_c16_fwd", "conv_rows", "fused_conv_bwd")}
+    o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_c16_fwd", "conv_rows", "fused_conv_bwd", "fused_prep_fwd")}
     o["fused_tail_fwd"] = plan.query("opt:fused_tail") >= 2
     o["c16_recompute"] = plan.query("opt:fused_c16_fwd") == 2
     o["c64_recompute"] = plan.query("opt:fused_attn_fwd") == 2
@@ -208,7 +213,7 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
     work = algorithmic_work(B, lr, scale, dtype, fused_attn_fwd=opts.get("fused_attn_fwd"), fused_tail_fwd=bool(opts.get("fused_tail_fwd", False)),
                             fused_qkv_dgrad=opts.get("fused_qkv_dgrad"), fused_c16_fwd=opts.get("fused_c16_fwd"),
                             c16_recompute=opts.get("c16_recompute"), c64_recompute=opts.get("c64_recompute"),
-                            fused_conv_bwd=opts.get("fused_conv_bwd"), c16_prep=opts.get("c16_prep"))
+                            fused_conv_bwd=opts.get("fused_conv_bwd"), c16_prep=opts.get("c16_prep"), fused_prep_fwd=opts.get("fused_prep_fwd"))
     traffic = {}
     if pmc_file and os.path.exists(pmc_file):
         try:

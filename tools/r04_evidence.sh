@@ -28,6 +28,8 @@ prof() {  # name, bench args...
 }
 prof c1_default --config 1
 python tools/timeline.py <(head -1 $O/kernel_trace_c1_default.csv) $O/kernel_trace_c1_default.csv 0 10 > $O/timeline_c1_default.txt 2>&1
+prof c1_default_no_events --config 1 --no-kernel-events
+python tools/timeline.py <(head -1 $O/kernel_trace_c1_default_no_events.csv) $O/kernel_trace_c1_default_no_events.csv 0 10 > $O/timeline_c1_default_no_events.txt 2>&1
 prof c1_single --config 1 --steps 5 --warmup 2 --no-kernel-events --no-side-stream
 prof c2_default --config 2 --steps 5 --warmup 2 --no-kernel-events
 prof c3_default --config 3 --steps 5 --warmup 2 --no-kernel-events
@@ -40,5 +42,13 @@ python tools/traffic_table.py $O/pmc_traffic.json $O/kernel_stats_c1_single.csv 
 timeout 900 python tools/pmc_sq.py > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq.txt $O/pmc_sq.txt; head -10 $O/pmc_sq.txt | cut -c1-260
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --force-comm-path --no-cpu-baseline > $O/bench_c1_rccl_one_rank.json 2> $O/bench_rccl.err; cut -c1-200 $O/bench_c1_rccl_one_rank.json
 timeout 200 ./scratch/bench_tail_new > $O/bench_tail.txt 2>&1; grep "tail_\|stream" $O/bench_tail.txt | tail -12
+# per-phase stamps of the C = 256 / C = 64 attention kernels (stand-alone harnesses): backward, forward without / with branch_prep inside
+( for c in 256 64; do ./scratch/bench_res_st $c 16; ./scratch/bench_res $c 16 | head -1; done; ./scratch/bench_res 256 32 | head -1 ) > $O/attn_bwd_stamps.txt 2>&1
+( for c in 256 64; do for p in 0 1; do ./scratch/bench_fused_st $c 16 0 $p; ./scratch/bench_fused $c 16 0 $p; done; done; ./scratch/bench_fused 256 32 0 1 ) > $O/attn_fwd_stamps.txt 2>&1
+# same-box A/B of the round's two schedule / fusion options (three alternations each, configs 1 and 3)
+( echo "A = fork_on_kernel 0, B = default"; bash tools/ab_opts.sh "--option fork_on_kernel=0" "" 3; bash tools/ab_opts.sh "--config 3 --option fork_on_kernel=0" "--config 3" 2
+  echo "A = fused_prep_fwd 0, B = default"; bash tools/ab_opts.sh "--option fused_prep_fwd=0" "" 3; bash tools/ab_opts.sh "--config 3 --option fused_prep_fwd=0" "--config 3" 2
+  echo "A = fused_tail 4 (x4 row-streaming backward), B = default"; bash tools/ab_opts.sh "--option fused_tail=4" "" 2
+  echo "config 4: A = fused_tail 0 (plain x3 tail kernels), B = default"; bash tools/ab_opts.sh "--config 4 --option fused_tail=0" "--config 4" 2 ) > $O/ab_options.txt 2>&1
 timeout 100 ./scratch/bench_valu_rate > $O/valu_rate.txt 2>&1
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
