@@ -65,6 +65,10 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "fork_on_kernel"    [1] the event that releases side-stream work rides on the main-stream dispatch it follows (hipExtLaunchKernelGGL
  *                           stop event) instead of a marker packet behind it: -0.7 % step time; 0 = hipEventRecord.  Ignored (0) while the
  *                           stream is being captured into a HIP graph
+ *   "fused_prep_fwd"    [1] bf16, C = 64 / 256 branches: branch_prep (norm apply + branch mixing + DWT^L) inside the fused forward attention kernel
+ *                           (needs "fused_attn_fwd" >= 1; bit-identical); 0 = branch_prep launches in front of it
+ *   "fused_prep_bwd"    [1] bf16: the backward of branch 4's branch_prep inside branch 3's attention backward (same level and window grid; needs
+ *                           "attn_bwd" >= 2; bit-identical); 0 = a branch_prep_bwd launch between the two
  *   "wgrad_big_tiles"   [-1] qkv weight gradient of the C = 256 branches with 128 x 128 output tiles: value = target number of
  *                           workgroups (64..512), 0 = off, -1 = auto (256 from 24 576 branch pixels on, i.e. batch >= 24)
  *   "fused_tail"        [3] bf16 x4: 1 = one fused kernel for the high-resolution half of the tail backward (k_tail_bwd.hip); 2 = the same

@@ -181,14 +181,32 @@ template <int C, int L, int NTHR> struct GoStage {
 // products -- the same pre-packed A-fragments (M2T_PACK_FRAG16), k-step-outer, rounded to bf16 where the forward stored them --
 // so every value is bit-identical to the saved one.  The x rows of the 100 keys are staged where V will live, q waits in the
 // P region; the window then loads 12.8 KB (C = 64) instead of 33.6 KB and the forward writes 25 MB less per launch.
-template <int C, int L, int NW, bool DG, bool RC = false>
+// PB: the backward of branch_prep of the NEXT branch k = i + 1 (k_pointwise.hip: g_xin = IWT^L(g_d) + g_xc[k]; g_n[k] = g_xin / 2;
+// g_xc[k - 1] += g_xin / 2) runs in this kernel's phase 0 instead of in its own launch in front of it: g_xc[k - 1] = g_xc[i] is exactly
+// the gradient this window loads, and the window's own pixels are exactly the blocks whose g_d rows it needs (same level, same window
+// grid; the ring rows of the <= 3 neighbouring windows come from the previous launch, which is why gd / gdwin are double-buffered per
+// branch).  Waves 0..3 (one (pixel, 4 channels) item per thread, as the dO staging always was) do that arithmetic -- the operations, their
+// order and the rounding points of branch_prep_bwd_tiled_kernel: identical bits -- and write g_n[k], g_xc[i] and the dO rows, while waves
+// 4..7 load and stage K^ | V alone (rel-pos table through LDS), so that neither role holds the other's registers.  Measured
+// (scratch/bench_res.hip, batch 16): the kernel grows from 34.0 to 42.6 us and replaces an 11.1 us launch plus its fork gap; phase 0
+// is 29.8 k cycles instead of 14.7 k -- the block loads are 8-byte pieces at 128-byte stride (82 KB per window at ~3 TB/s chip-wide:
+// 15 k cycles before the K | V burst can start; issued together with it both arrive late: 34 k), the arithmetic (packed fp32) 3.3 k,
+// the stores and the forward transform 7 k under the K | V burst.  Worth 0.35 % / 0.45 % of the step at batch 16 / 32; the C = 64 and
+// C = 16 consumers (different levels, recomputing kernels) are not built.
+struct ResPrepArgs {
+  const bf16_t* gdn;       // own-window g_d rows of branch k  [B][h][w][C]
+  const bf16_t* gdwinn;    // their ring rows                  [window][36][C]
+  const bf16_t* gxk;       // plane k of g_xc                  [B][H][W][16]
+  bf16_t* gnk;             // plane k of g_n (written)
+};
+template <int C, int L, int NW, bool DG, bool RC = false, bool PB = false>
 __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                                       const float* __restrict__ rel_w, const bf16_t* __restrict__ go,
                                                                       int ldg, int gc0, bf16_t* __restrict__ gqkv,
                                                                       bf16_t* __restrict__ win, float* __restrict__ relw, int h, int w,
                                                                       const bf16_t* __restrict__ wdfrag, bf16_t* __restrict__ gd,
                                                                       bf16_t* __restrict__ gdwin, const bf16_t* __restrict__ xsrc,
-                                                                      const bf16_t* __restrict__ wfrag) {
+                                                                      const bf16_t* __restrict__ wfrag, ResPrepArgs pb) {
   using T = bf16_t;
   using Cfg = ResCfg<C>;
   constexpr int LD = Cfg::LD, PLD = Cfg::PLD, DLD = Cfg::DLD, NTHR = NW * 64, VEC = C / 8, NT = C / 16, KH = NW / 4, TPW = NT / NW, NKC = C / 32;
@@ -338,6 +356,168 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) qreg[kc] = load8(&Qt[q][kc * 32 + 8 * g]);
     __syncthreads();
+  } else if constexpr (PB) {
+  static_assert(!PB || (NW == 8 && L == 2 && C == 256 && !RC), "branch_prep_bwd inside: the C = 256 / L = 2 kernel");
+  constexpr int S = 4, NB = 16;
+  float(*RelS)[C] = reinterpret_cast<float(*)[C]>(smem + Cfg::offD);             // T[kk][ch] = ch < C/2 ? rel_h[kk][ch] : rel_w[kk][ch - C/2]
+  T* CornS = reinterpret_cast<T*>(smem + Cfg::offD + sizeof(float) * 10 * C);   // [4 corners][2 sources][C]
+  static_assert(sizeof(float) * 10 * C + sizeof(T) * 8 * C <= Cfg::szD, "rel-pos table + corner ring rows staging");
+  constexpr int RIT = (10 * C / 4 + NTHR - 1) / NTHR;
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) qreg[kc] = load8(qkv + qpix * (3 * C) + kc * 32 + 8 * g);
+  f32x4 rf[RIT];
+#pragma unroll
+  for (int it = 0; it < RIT; ++it) {
+    const int idx = min(tid + it * NTHR, 10 * C / 4 - 1);
+    const int kk = idx / (C / 4), c4 = (idx % (C / 4)) * 4;
+    const float* rp = (c4 < C / 2) ? (rel_h + kk * (C / 2) + c4) : (rel_w + kk * (C / 2) + (c4 - C / 2));
+    rf[it] = *reinterpret_cast<const f32x4*>(rp);
+  }
+  auto stage_rel = [&]() {
+#pragma unroll
+    for (int it = 0; it < RIT; ++it) {
+      const int idx = min(tid + it * NTHR, 10 * C / 4 - 1);
+      *reinterpret_cast<f32x4*>(&RelS[idx / (C / 4)][(idx % (C / 4)) * 4]) = rf[it];
+    }
+  };
+  if (wv >= 4) {
+    // ---- loader role: K^ | V of the 100 keys, 256 threads ----
+    constexpr int KIT2 = (WA_NK * VEC + 255) / 256;
+    const int t2 = tid - 256;
+    // (the K | V burst starts BEHIND the barrier that the prep waves reach once their g_d rows have arrived: issued together with
+    // the prep role's loads it made both arrive late -- the window then moves 248 KB through a bandwidth-bound burst and the block
+    // arithmetic could only start at its end; this way the arithmetic runs under the K | V burst)
+    Frag8<T> kf[KIT2], vf[KIT2];
+    {
+      // the second and third ring source of the window's four corner pixels (the only pixels that have them): one 16-byte piece per
+      // loader thread into CornS[corner][source - 1][C], so that the prep role does not chase them through a dependent load loop
+      const int cn = t2 >> 6, a = 1 + ((t2 >> 5) & 1), vec = t2 & 31;
+      const int cq = (cn & 1) * 7 + (cn >> 1) * 56;                                 // query pixels 0, 7, 56, 63
+      long long ho[3];
+      const int ns = halo_sources(gm.b, 8 * gm.wy + (cq >> 3), 8 * gm.wx + (cq & 7), gm.nh, gm.nw, C, ho);
+      const Frag8<T> piece = load8(pb.gdwinn + (a < ns ? ho[a] : 0) + vec * 8);
+      stage_rel();
+      store8(&CornS[(cn * 2 + (a - 1)) * C + vec * 8], a < ns ? piece : frag_zero<T>());
+    }
+    lds_barrier();
+#pragma unroll
+    for (int it = 0; it < KIT2; ++it) {
+      const int idx = t2 + it * 256;
+      const int cv = idx % VEC, key = min(idx / VEC, WA_NK - 1);
+      const int kr = key / 10, kc = key - kr * 10;
+      const int yy = 8 * gm.wy + kr - 1, xx = 8 * gm.wx + kc - 1;
+      const long long kp = ((long long)gm.b * h + min(max(yy, 0), h - 1)) * w + min(max(xx, 0), w - 1);     // clamped: the loads are unconditional
+      kf[it] = load8(qkv + kp * (3 * C) + C + cv * 8);
+      vf[it] = load8(qkv + kp * (3 * C) + 2 * C + cv * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < KIT2; ++it) {
+      const int idx = t2 + it * 256;
+      const int cv = idx % VEC, key = idx / VEC;
+      if (key < WA_NK) {
+        const int kr = key / 10, kc = key - kr * 10;
+        const int yy = 8 * gm.wy + kr - 1, xx = 8 * gm.wx + kc - 1;
+        const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
+        const int cc = cv * 8;
+        const f32x4 ra = *reinterpret_cast<const f32x4*>(&RelS[(cc < C / 2) ? kr : kc][cc]);
+        const f32x4 rb = *reinterpret_cast<const f32x4*>(&RelS[(cc < C / 2) ? kr : kc][cc + 4]);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = (ok ? kf[it].get(e) : 0.f) + ra[e]; v[4 + e] = (ok ? kf[it].get(4 + e) : 0.f) + rb[e]; }
+        store8f(&Kh[key][cv * 8], v);
+        store8(&Vs[key][cv * 8], ok ? vf[it] : frag_zero<T>());
+      }
+    }
+    if (t2 < VEC) {
+      store8(&Kh[ZR][t2 * 8], frag_zero<T>());
+      store8(&Vs[ZR][t2 * 8], frag_zero<T>());
+    }
+  } else {
+    // ---- prep role: thread (query pixel pq = tid >> 2, 4 base channels cg): its 4x4 block of the full-resolution planes ----
+    const int pq = tid >> 2, cg = tid & 3;
+    const int H = gm.h * S, W = gm.w * S;
+    const int by = 8 * gm.wy + (pq >> 3), bx = 8 * gm.wx + (pq & 7);
+    const T* drow = pb.gdn + (((long long)gm.b * gm.h + by) * gm.w + bx) * C + 4 * cg;
+    long long hoff[3];
+    const int nsrc = halo_sources(gm.b, by, bx, gm.nh, gm.nw, C, hoff);
+    bf16x4 rd[NB], rr[NB], p3[S][S], p2[S][S];
+#pragma unroll
+    for (int n = 0; n < NB; ++n) rd[n] = *reinterpret_cast<const bf16x4*>(drow + n * 16);
+    {
+      const T* r0p = pb.gdwinn + (nsrc > 0 ? hoff[0] : 0) + 4 * cg;               // clamped: unconditional loads, selected below
+#pragma unroll
+      for (int n = 0; n < NB; ++n) rr[n] = *reinterpret_cast<const bf16x4*>(r0p + n * 16);
+    }
+#pragma unroll
+    for (int y = 0; y < S; ++y)
+#pragma unroll
+      for (int x = 0; x < S; ++x) {
+        const long long po = (((long long)gm.b * H + S * by + y) * W + S * bx + x) * 16 + 4 * cg;
+        p3[y][x] = *reinterpret_cast<const bf16x4*>(pb.gxk + po);
+        p2[y][x] = *reinterpret_cast<const bf16x4*>(go + po);
+      }
+    // two channel pairs per thread, packed fp32 (v_pk_add / v_pk_mul: IEEE per component).  g_d row of the block = own-window products
+    // + the neighbours' ring rows (fp32 adds in halo_sources' order, one rounding to bf16).  The first sums sit in front of the
+    // barrier on purpose: the loader waves start the K | V burst when these loads have landed
+    f32x2 o2[2][NB];
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const f32x2 q2 = {(float)rd[n][2 * c2], (float)rd[n][2 * c2 + 1]};
+        const f32x2 sum = q2 + (f32x2){(float)rr[n][2 * c2], (float)rr[n][2 * c2 + 1]};
+        o2[c2][n] = nsrc > 0 ? sum : q2;
+      }
+    stage_rel();
+    lds_barrier();
+    if (nsrc > 1) {                                                               // corner pixels only (4 of 64): rows staged by the loader waves
+      const int cn = ((pq & 7) == 7 ? 1 : 0) + (pq >= 56 ? 2 : 0);
+      for (int a = 1; a < nsrc; ++a) {
+        const T* rp = CornS + (cn * 2 + (a - 1)) * C + 4 * cg;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rp + n * 16);
+          o2[0][n] += (f32x2){(float)r4[0], (float)r4[1]};
+          o2[1][n] += (f32x2){(float)r4[2], (float)r4[3]};
+        }
+      }
+    }
+    f32x2 vq[2][S][S];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+#pragma unroll
+      for (int n = 0; n < NB; ++n) o2[c2][n] = (f32x2){to_f(from_f<T>(o2[c2][n][0])), to_f(from_f<T>(o2[c2][n][1]))};
+      Haar2Inv2::inv(o2[c2], vq[c2]);
+    }
+    // g_n[k] = (IWT + g_xc[k]) / 2 ; g_xc[i] += that ; the new g_xc[i] (rounded as stored) is this window's dO before DWT^L
+#pragma unroll
+    for (int y = 0; y < S; ++y)
+#pragma unroll
+      for (int x = 0; x < S; ++x) {
+        const long long po = (((long long)gm.b * H + S * by + y) * W + S * bx + x) * 16 + 4 * cg;
+        f32x2 qv[2], pp[2];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          qv[c2] = (vq[c2][y][x] + (f32x2){(float)p3[y][x][2 * c2], (float)p3[y][x][2 * c2 + 1]}) * (f32x2){0.5f, 0.5f};
+          pp[c2] = (f32x2){(float)p2[y][x][2 * c2], (float)p2[y][x][2 * c2 + 1]} + qv[c2];
+        }
+        const bf16x4 gv = {(bf16_t)qv[0][0], (bf16_t)qv[0][1], (bf16_t)qv[1][0], (bf16_t)qv[1][1]};
+        *reinterpret_cast<bf16x4*>(pb.gnk + po) = gv;
+        const bf16x4 nv = {(bf16_t)pp[0][0], (bf16_t)pp[0][1], (bf16_t)pp[1][0], (bf16_t)pp[1][1]};
+        *reinterpret_cast<bf16x4*>(const_cast<T*>(go) + po) = nv;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) vq[c2][y][x] = (f32x2){(float)nv[2 * c2], (float)nv[2 * c2 + 1]};
+      }
+    f32x2 ob[2][NB];
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) Haar2<L>::fwd(vq[c2], ob[c2]);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const bf16x4 dv = {(bf16_t)ob[0][n][0], (bf16_t)ob[0][n][1], (bf16_t)ob[1][n][0], (bf16_t)ob[1][n][1]};
+      *reinterpret_cast<bf16x4*>(&DOs[pq][n * 16 + 4 * cg]) = dv;
+    }
+  }
+  __syncthreads();
   } else {
   // ---- phase 0: every global load of the window is issued -- q first (phase 1 needs it in registers; issued behind the LDS
   // writes it cost a second exposed HBM round trip), K^ | rel, V, dO -- then written to LDS.  The burst is bandwidth-bound
@@ -939,14 +1119,14 @@ int go_fwd_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, bf16_t
   return 0;
 }
 
-template <int C, int L, int NW, bool DG = false, bool RC = false>
+template <int C, int L, int NW, bool DG = false, bool RC = false, bool PB = false>
 int go_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, const bf16_t* gout, int ldg, int gc0, bf16_t* gqkv,
            bf16_t* win, float* relw, int nwin, int h, int w, hipStream_t st, const bf16_t* wdfrag = nullptr, bf16_t* gd = nullptr,
-           bf16_t* gdwin = nullptr, const bf16_t* xsrc = nullptr, const bf16_t* wfrag = nullptr) {
+           bf16_t* gdwin = nullptr, const bf16_t* xsrc = nullptr, const bf16_t* wfrag = nullptr, ResPrepArgs pb = ResPrepArgs{}) {
   const size_t sh = ResCfg<C>::total;
-  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_bwd_res_kernel<C, L, NW, DG, RC>, (int)sh)) return rc__;
-  M2T_LAUNCH_TIMED((window_attn_bwd_res_kernel<C, L, NW, DG, RC>), dim3(nwin), dim3(NW * 64), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0,
-                     gqkv, win, relw, h, w, wdfrag, gd, gdwin, xsrc, wfrag);
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)window_attn_bwd_res_kernel<C, L, NW, DG, RC, PB>, (int)sh)) return rc__;
+  M2T_LAUNCH_TIMED((window_attn_bwd_res_kernel<C, L, NW, DG, RC, PB>), dim3(nwin), dim3(NW * 64), sh, st, qkv, rel_h, rel_w, gout, ldg, gc0,
+                     gqkv, win, relw, h, w, wdfrag, gd, gdwin, xsrc, wfrag, pb);
   return 0;
 }
 
@@ -955,7 +1135,8 @@ int go_res(const bf16_t* qkv, const float* rel_h, const float* rel_w, const bf16
 // bf16, C in {64, 256}, dwt_levels in {0, L(C)}; returns M2T_UNSUPPORTED otherwise (the caller then uses the chunked kernel)
 int launch_window_attn_bwd_resident(const void* qkv_, const float* rel_h, const float* rel_w, const void* gout_, int ldg, int gc0,
                                     void* gqkv_, void* win_, float* relw, int B, int h, int w, int C, int dwt_levels, hipStream_t st,
-                                    const void* wdfrag, void* gd, void* gdwin, const void* xsrc, const void* wfrag) {
+                                    const void* wdfrag, void* gd, void* gdwin, const void* xsrc, const void* wfrag,
+                                    const void* pb_gd, const void* pb_gdwin, const void* pb_gxk, void* pb_gnk) {
   const bf16_t* qkv = (const bf16_t*)qkv_;
   const bf16_t* gout = (const bf16_t*)gout_;
   bf16_t* gqkv = (bf16_t*)gqkv_;
@@ -964,7 +1145,15 @@ int launch_window_attn_bwd_resident(const void* qkv_, const float* rel_h, const 
   int rc = M2T_UNSUPPORTED;
   if (wdfrag) {      // fused projection data gradient: the two shapes of the model
     if (!gd || !gdwin) return m2t_set_error(-2, "window_attn_bwd_resident: fused data gradient needs gd and gdwin");
-    if (C == 256 && dwt_levels == 2)
+    if (C == 256 && dwt_levels == 2 && pb_gd) {
+      // branch_prep_bwd of the next branch inside: gout is then READ AND WRITTEN (g_xc[i] += ...), a dense 16-channel plane
+      if (!pb_gdwin || !pb_gxk || !pb_gnk || ldg != 16 || gc0 != 0 || pb_gd == gd || pb_gdwin == gdwin)
+        return m2t_set_error(-2, "window_attn_bwd_resident: fused branch_prep_bwd needs its four operands, a dense g_xc plane and gd / gdwin buffers other than the ones it writes");
+      ResPrepArgs pb;
+      pb.gdn = (const bf16_t*)pb_gd; pb.gdwinn = (const bf16_t*)pb_gdwin; pb.gxk = (const bf16_t*)pb_gxk; pb.gnk = (bf16_t*)pb_gnk;
+      rc = go_res<256, 2, 8, true, false, true>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st, (const bf16_t*)wdfrag, (bf16_t*)gd,
+                                                (bf16_t*)gdwin, nullptr, nullptr, pb);
+    } else if (C == 256 && dwt_levels == 2)
       rc = go_res<256, 2, 8, true>(qkv, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st, (const bf16_t*)wdfrag, (bf16_t*)gd, (bf16_t*)gdwin);
     else if (C == 64 && dwt_levels == 1 && xsrc && wfrag)     // q | k | v not saved: recomputed from the branch input
       rc = go_res<64, 1, 4, true, true>(nullptr, rel_h, rel_w, gout, ldg, gc0, gqkv, win, relw, nwin, h, w, st, (const bf16_t*)wdfrag, (bf16_t*)gd,

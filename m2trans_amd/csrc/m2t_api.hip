@@ -166,6 +166,7 @@ struct m2t_plan {
                                        // A/B -- same data gradient bits, 580 against 377 us stand-alone at batch 16
                                        // (with bf16 mode's exp2 / rcp GELU: 5.30 vs 5.34 ms per step and 1.6 GB less HBM traffic;
                                        // with the erf form of round 2 it was 1 % slower)
+  int use_fused_prep_bwd = 1;          // bf16: branch_prep_bwd of branch 4 inside the attention backward of branch 3 (round 4)
   int use_fused_prep_fwd = 1;          // bf16 C = 64 / 256 branches: branch_prep inside the fused forward attention kernel (round 4)
   int fork_on_kernel = 1;              // a fork event rides on the dispatch it follows (its stop event) instead of a marker packet behind it:
                                        // same-box A/B 4.757 -> 4.726 ms (config 1), 8.536 -> 8.469 (config 3); not under stream capture
@@ -347,6 +348,8 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("gn", BP * 64, es);
   p->add_ws("ga", BP * 16, es);
   p->add_ws("gd", BP * 16, es);
+  p->add_ws("gd2", BP * 16, es);       // second set: a branch's attention backward reads the previous branch's rows while it writes its own (fused_prep_bwd)
+  p->add_ws("gdwin2", BP * 9, es);
   p->add_ws("gdwin", BP * 9, es);      // ring rows of the fused projection data gradient: [windows][36][C], windows * C = BP / 4
   p->add_ws("head_cols", BP * 32, es);
   for (int i = 0; i < 4; ++i) {     // TWO sets per branch (even / odd blocks): the side stream may lag the main chain by two blocks, and
@@ -417,6 +420,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "side_stream") return p->use_side;
     if (o == "fork_on_kernel") return p->fork_on_kernel;
     if (o == "fused_prep_fwd") return p->use_fused_prep_fwd;
+    if (o == "fused_prep_bwd") return p->use_fused_prep_bwd;
     if (o == "gate_branch") return p->gate_branch + 1000;      // (offset: -1 is the "unknown key" value of this function)
     if (o == "wgrad_big_tiles") return p->wgrad_big_tiles + 1000;
     if (o == "fused_tail") {
@@ -907,13 +911,21 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       // the attention backward; it completes dK|dV in gqkv, so the branch's side work is released after it
       const bool c16_prep = dt != M2T_F32 && C == 16 && p->use_c16_prep && p->use_fused_qkv_dgrad && p->use_resident_attn_bwd;
       if (!gated && fused_dgrad(i)) arm_fork();
+      // branch 4's branch_prep_bwd runs inside branch 3's attention backward (same level, same window grid): branch 4 then leaves its
+      // own-window g_d rows in the second buffer set, and its prep launch is skipped below
+      const bool pb_consumer = i == 2 && fused_dgrad(2) && fused_dgrad(3) && p->use_fused_prep_bwd && BR_L[3] == BR_L[2];
+      const bool pb_producer = i == 3 && fused_dgrad(2) && fused_dgrad(3) && p->use_fused_prep_bwd && BR_L[3] == BR_L[2];
       if (fused_dgrad(i)) {
         M2TProfScope ps(C == 64 ? M2T_PROF_ATTN_BWD_64 : M2T_PROF_ATTN_BWD_256, st);
         const bool rc64 = C == 64 && p->c64_recompute();
         CK(launch_window_attn_bwd_resident(qkv, rh, rw, gxc_i, 16, 0, gqkv, win, relw, B, h, w, C, L, st,
-                                           packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "TF"), WSP("gd"), WSP("gdwin"),
+                                           packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "TF"),
+                                           pb_producer ? WSP("gd2") : WSP("gd"), pb_producer ? WSP("gdwin2") : WSP("gdwin"),
                                            rc64 ? WSP(k + "d" + std::to_string(i + 1)) : nullptr,
-                                           rc64 ? packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "F") : nullptr));
+                                           rc64 ? packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "F") : nullptr,
+                                           pb_consumer ? WSP("gd2") : nullptr, pb_consumer ? WSP("gdwin2") : nullptr,
+                                           pb_consumer ? (const void*)((const char*)gxc + (size_t)(i + 1) * BP * 16 * p->esz) : nullptr,
+                                           pb_consumer ? (void*)((char*)gn + (size_t)(i + 1) * BP * 16 * p->esz) : nullptr));
       } else if (C == 16 && p->c16_recompute()) {
         // qkv1 was not stored: recomputed inside the kernel from d1 (identical bits); then the halo overlap-add as usual
         { M2TProfScope ps(M2T_PROF_ATTN_BWD_16, st);
@@ -948,7 +960,9 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         return 0;
       };
       if (!c16_prep) CK(release_side());
-      if (fused_dgrad(i)) {
+      if (pb_producer) {
+        // (nothing: the next attention backward applies this branch's branch_prep_bwd while it loads its output gradient)
+      } else if (fused_dgrad(i)) {
         // own-window products are in gd; add the ring rows of the (<= 3) neighbouring windows to the border pixels
         CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st, WSP("gdwin")));
       } else if (c16_prep) {
@@ -1039,6 +1053,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (k == "side_stream") { p->use_side = (value != 0); return 0; }
   if (k == "fork_on_kernel") { p->fork_on_kernel = value != 0; return 0; }
   if (k == "fused_prep_fwd") { p->use_fused_prep_fwd = value != 0; return 0; }
+  if (k == "fused_prep_bwd") { p->use_fused_prep_bwd = value != 0; return 0; }
   if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }
   if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
   if (k == "fused_tail") {

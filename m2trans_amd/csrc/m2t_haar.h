@@ -104,3 +104,27 @@ template <> struct Haar2<2> {
     }
   }
 };
+
+// inverse butterflies on two channels at once: the association order of haar2_inv with its two shared differences / sums named
+__device__ __forceinline__ void haar2_inv2(f32x2 ll, f32x2 hl, f32x2 lh, f32x2 hh, f32x2& a, f32x2& b, f32x2& c, f32x2& d) {
+  const f32x2 hf = {0.5f, 0.5f};
+  const f32x2 m = ll - hl, p = ll + hl;
+  a = hf * ((m - lh) + hh);
+  b = hf * ((m + lh) - hh);
+  c = hf * ((p - lh) - hh);
+  d = hf * ((p + lh) + hh);
+}
+template <> struct Haar2<0> {};
+struct Haar2Inv2 {      // L = 2
+  __device__ static __forceinline__ void inv(const f32x2 (&o)[16], f32x2 (&v)[4][4]) {
+    f32x2 t[2][2][4];
+#pragma unroll
+    for (int b1 = 0; b1 < 4; ++b1)
+      haar2_inv2(o[0 * 4 + b1], o[1 * 4 + b1], o[2 * 4 + b1], o[3 * 4 + b1], t[0][0][b1], t[1][0][b1], t[0][1][b1], t[1][1][b1]);
+#pragma unroll
+    for (int I = 0; I < 2; ++I)
+#pragma unroll
+      for (int J = 0; J < 2; ++J)
+        haar2_inv2(t[I][J][0], t[I][J][1], t[I][J][2], t[I][J][3], v[2 * I][2 * J], v[2 * I + 1][2 * J], v[2 * I][2 * J + 1], v[2 * I + 1][2 * J + 1]);
+  }
+};

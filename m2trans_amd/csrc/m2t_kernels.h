@@ -228,7 +228,10 @@ int launch_window_attn_bwd_resident(const void* qkv, const float* rel_h, const f
                                     const void* wdfrag, void* gd, void* gdwin,
                                     // (C, dwt_levels) = (64, 1) with the fused data gradient: xsrc [pixel][C] = the branch input and wfrag = Wqkv as
                                     // M2T_PACK_FRAG16: qkv was not saved (may be nullptr), q | k | v are recomputed (identical bits)
-                                    const void* xsrc = nullptr, const void* wfrag = nullptr);
+                                    const void* xsrc = nullptr, const void* wfrag = nullptr,
+                                    // (256, 2) with pb_gd != nullptr: branch_prep_bwd of the NEXT branch k = i + 1 inside (its own-window g_d rows, their
+                                    // ring rows, plane k of g_xc, plane k of g_n (written)); gout = plane i of g_xc is then updated in place
+                                    const void* pb_gd = nullptr, const void* pb_gdwin = nullptr, const void* pb_gxk = nullptr, void* pb_gnk = nullptr);
 int launch_halo_gather(int dt, const void* win, void* dst, int B, int h, int w, int rw, int ld, int coff, hipStream_t st);
 // k_attn_c16.hip: the whole C = 16 branch forward (InstanceNorm apply of chunk 0 + qkv projection + attention + residual), bf16.
 // x = chunk-0 plane of the block input; wqkv [48][16] (M2T_PACK_COPY); d [B*h*w][16] and qkv [B*h*w][48] are WRITTEN

@@ -52,8 +52,16 @@ int main(int argc, char** argv) {
   hipStream_t st; CKH(hipStreamCreate(&st));
   const bool rc = (C == 64);
   // go: the full-resolution g_xc tensor, P64 plane of 16 channels (ld 16)
+  const bool pbm = argc > 3 && atoi(argv[3]) != 0 && C == 256;       // branch_prep_bwd of the next branch inside
+  void *dgd2 = nullptr, *dgdwin2 = nullptr, *dgnk = nullptr;
+  if (pbm) {
+    CKH(hipMalloc(&dgd2, M * C * 2)); CKH(hipMalloc(&dgdwin2, (size_t)nwin * 36 * C * 2)); CKH(hipMalloc(&dgnk, full * 16 * 2));
+    auto hg = fill(M * C, 0.5f), hw2 = fill((size_t)nwin * 36 * C, 0.5f);
+    CKH(hipMemcpy(dgd2, hg.data(), M * C * 2, hipMemcpyHostToDevice)); CKH(hipMemcpy(dgdwin2, hw2.data(), (size_t)nwin * 36 * C * 2, hipMemcpyHostToDevice));
+  }
   auto launch = [&]() { return launch_window_attn_bwd_resident(rc ? nullptr : dqkv, drel, drel + 5 * C, dgo, 16, 0, dgqkv, dwin, drelw, B, h, w, C, L, st, dwd, dgd, dgdwin,
-                                                               rc ? dx : nullptr, rc ? dwf : nullptr); };
+                                                               rc ? dx : nullptr, rc ? dwf : nullptr, pbm ? dgd2 : nullptr, pbm ? dgdwin2 : nullptr,
+                                                               pbm ? (const void*)((const char*)dgo + full * 16 * 2) : nullptr, pbm ? dgnk : nullptr); };
   for (int i = 0; i < 5; ++i) if (launch()) return 1;
   CKH(hipStreamSynchronize(st));
   hipEvent_t e0, e1; CKH(hipEventCreate(&e0)); CKH(hipEventCreate(&e1));
@@ -92,7 +100,14 @@ int main(int argc, char** argv) {
       std::vector<long long> d1, d2, d3;
       for (int b = 0; b < nwin; ++b) { const unsigned long long* r = &hs[((size_t)b * 8 + wsel) * 16]; if (r[10] && r[11]) { d1.push_back((long long)(r[10] - r[0])); d2.push_back((long long)(r[11] - r[10])); d3.push_back((long long)(r[1] - r[11])); } }
       if (!d1.empty()) { std::sort(d1.begin(), d1.end()); std::sort(d2.begin(), d2.end()); std::sort(d3.begin(), d3.end());
-        printf("  (phase0 split: loads -> K^ in LDS %lld, S^T product %lld, dO / V -> LDS + barrier %lld)\n", d1[d1.size() / 2], d2[d2.size() / 2], d3[d3.size() / 2]); }
+        printf("  (phase0 split: start -> role done %lld, role done -> barrier passed %lld)\n", d1[d1.size() / 2], d3[d3.size() / 2] + d2[d2.size() / 2]); }
+      std::vector<long long> e1;
+      for (int b = 0; b < nwin; ++b) { const unsigned long long* r = &hs[((size_t)b * 8 + wsel) * 16]; if (r[10]) e1.push_back((long long)(r[10] - r[0])); }
+      if (!e1.empty()) { std::sort(e1.begin(), e1.end()); printf("  (start -> end of this wave's phase-0 role %lld)\n", e1[e1.size() / 2]); }
+      std::vector<long long> e2, e3;
+      for (int b = 0; b < nwin; ++b) { const unsigned long long* r = &hs[((size_t)b * 8 + wsel) * 16]; if (r[11]) e2.push_back((long long)(r[11] - r[0])); if (r[12]) e3.push_back((long long)(r[12] - r[0])); }
+      if (!e2.empty()) { std::sort(e2.begin(), e2.end()); printf("  (start -> rel-pos barrier passed %lld)\n", e2[e2.size() / 2]); }
+      if (!e3.empty()) { std::sort(e3.begin(), e3.end()); printf("  (start -> block arithmetic done, before the stores %lld)\n", e3[e3.size() / 2]); }
     }
     std::vector<long long> d;
     for (int b = 0; b < nwin; ++b) d.push_back((long long)(hs[((size_t)b * 8 + wsel) * 16 + 7] - hs[((size_t)b * 8 + wsel) * 16 + 0]));

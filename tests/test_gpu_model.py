@@ -220,6 +220,33 @@ def test_branch_prep_inside_the_fused_forward_attention_is_bit_identical(shape):
     assert torch.equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("shape", [(4, 2, 128, 128), (4, 3, 64, 96)])
+def test_branch_prep_bwd_inside_the_attention_backward_is_bit_identical(shape):
+    """"fused_prep_bwd": the backward of branch 4's branch_prep (overlap-add of the ring rows, IWT^2, the two halvings and the
+    read-modify-write of g_xc[chunk 2]) runs in phase 0 of branch 3's attention backward instead of in a launch of its own.  Same
+    operations in the same order and the same rounding points: every gradient bit-identical, including images whose coarse window
+    grids are 3 x 2 and 2 x 1 (corner pixels with three ring sources, border windows with none on one side)."""
+    from m2trans_amd import _lib
+    scale, B, H, W = shape
+    nb = 2
+    x = O.closed_form_image(B, 3, H, W).cuda()
+    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+    outs = []
+    for val in (1, 0):
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(x)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_prep_bwd", val), "m2t_set_option")
+        assert plan.query("opt:fused_prep_bwd") == val
+        grads = []
+        for _ in range(2):
+            model.zero_grad(set_to_none=True)
+            torch.nn.L1Loss()(model(x), hr).backward()
+            grads.append(torch.cat([q.grad.detach().reshape(-1) for q in model.parameters() if q.requires_grad]).clone())
+        assert torch.equal(grads[0], grads[1])
+        outs.append(grads[0])
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_fork_event_on_the_dispatch_gives_the_same_bits_as_a_recorded_event():
     """"fork_on_kernel": the event that releases a branch's side-stream work rides on the attention-backward dispatch as its stop
     event (default) or is recorded behind it by a marker packet (0).  Same dependency either way: every gradient bit-identical,
