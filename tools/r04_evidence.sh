@@ -43,12 +43,15 @@ timeout 900 python tools/pmc_sq.py > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq.tx
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --force-comm-path --no-cpu-baseline > $O/bench_c1_rccl_one_rank.json 2> $O/bench_rccl.err; cut -c1-200 $O/bench_c1_rccl_one_rank.json
 timeout 200 ./scratch/bench_tail_new > $O/bench_tail.txt 2>&1; grep "tail_\|stream" $O/bench_tail.txt | tail -12
 # per-phase stamps of the C = 256 / C = 64 attention kernels (stand-alone harnesses): backward, forward without / with branch_prep inside
-( for c in 256 64; do ./scratch/bench_res_st $c 16; ./scratch/bench_res $c 16 | head -1; done; ./scratch/bench_res 256 32 | head -1 ) > $O/attn_bwd_stamps.txt 2>&1
+( for c in 256 64; do ./scratch/bench_res_st $c 16; ./scratch/bench_res $c 16 | head -1; done; ./scratch/bench_res 256 32 | head -1
+  echo "--- with branch_prep_bwd of the next branch inside"; ./scratch/bench_res_st 256 16 1; ./scratch/bench_res 256 16 1 | head -1; ./scratch/bench_res 256 32 1 | head -1 ) > $O/attn_bwd_stamps.txt 2>&1
 ( for c in 256 64; do for p in 0 1; do ./scratch/bench_fused_st $c 16 0 $p; ./scratch/bench_fused $c 16 0 $p; done; done; ./scratch/bench_fused 256 32 0 1 ) > $O/attn_fwd_stamps.txt 2>&1
 # same-box A/B of the round's two schedule / fusion options (three alternations each, configs 1 and 3)
 ( echo "A = fork_on_kernel 0, B = default"; bash tools/ab_opts.sh "--option fork_on_kernel=0" "" 3; bash tools/ab_opts.sh "--config 3 --option fork_on_kernel=0" "--config 3" 2
   echo "A = fused_prep_fwd 0, B = default"; bash tools/ab_opts.sh "--option fused_prep_fwd=0" "" 3; bash tools/ab_opts.sh "--config 3 --option fused_prep_fwd=0" "--config 3" 2
+  echo "A = fused_prep_bwd 0, B = default"; bash tools/ab_opts.sh "--option fused_prep_bwd=0" "" 3; bash tools/ab_opts.sh "--config 3 --option fused_prep_bwd=0" "--config 3" 2
   echo "A = fused_tail 4 (x4 row-streaming backward), B = default"; bash tools/ab_opts.sh "--option fused_tail=4" "" 2
   echo "config 4: A = fused_tail 0 (plain x3 tail kernels), B = default"; bash tools/ab_opts.sh "--config 4 --option fused_tail=0" "--config 4" 2 ) > $O/ab_options.txt 2>&1
 timeout 100 ./scratch/bench_valu_rate > $O/valu_rate.txt 2>&1
+timeout 600 python tools/soak.py 8 12 > $O/soak.txt 2>&1; tail -2 $O/soak.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
