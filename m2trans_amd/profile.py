@@ -78,7 +78,7 @@ def read_all():
 def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8, fused_attn_fwd: bool | None = None,
                      fused_tail_fwd: bool = False, fused_qkv_dgrad: bool | None = None, fused_c16_fwd: bool | None = None,
                      c16_recompute: bool | None = None, c64_recompute: bool | None = None, fused_conv_bwd: bool | None = None,
-                     c16_prep: bool | None = None, fused_prep_fwd: bool | None = None):
+                     c16_prep: bool | None = None, fused_prep_fwd: bool | None = None, fused_prep_bwd: bool | None = None):
     """Per STEP totals {category: (flops, bytes, launches)} for the x4-style model at padded LR size lr.
     fused_attn_fwd (default: bf16 mode): the C = 64 / 256 branches run qkv projection + attention as one kernel, so
     the forward `gemm_qkv` / `attn_fwd_*` categories are then empty (the C = 16 branch runs InstanceNorm apply +
@@ -95,6 +95,8 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         c64_recompute = dtype == "bf16"
     if fused_prep_fwd is None:            # plan option "fused_prep_fwd" (bf16 default): branch_prep inside the fused forward attention kernels
         fused_prep_fwd = dtype == "bf16" and bool(fused_attn_fwd)
+    if fused_prep_bwd is None:            # plan option "fused_prep_bwd" (bf16 default): branch 4's branch_prep_bwd inside branch 3's attention backward
+        fused_prep_bwd = dtype == "bf16" and bool(fused_qkv_dgrad)
     if c16_prep is None:                  # plan option "attn_bwd" = 3 (default in bf16 mode): no data-gradient GEMM for the C = 16 branch either
         c16_prep = dtype == "bf16" and bool(fused_qkv_dgrad)
     if fused_conv_bwd is None:            # plan option "fused_conv_bwd" (default on in bf16 mode)
@@ -110,7 +112,7 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         f0, b0, n0 = w.get(cat, (0.0, 0.0, 0))
         w[cat] = (f0 + fl, b0 + by, n0 + n)
 
-    for C_, L in br:
+    for bi, (C_, L) in enumerate(br):
         M = B * P // (4 ** L)
         win = M // 64
         dg = fused_qkv_dgrad and C_ >= 64
@@ -118,8 +120,11 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
         # kernel also g_d (C) and 2 M 3C C more FLOPs
         rc = (c16_recompute and C_ == 16 and fused_c16_fwd) or (c64_recompute and C_ == 64 and fused_attn_fwd and dg)
         # with recompute: reads d (C) instead of q|k|v (3C), + the projection's FLOPs again
+        # branch 3 (index 2) with branch 4's branch_prep_bwd inside: also reads branch 4's g_d rows and g_xc[chunk 3], writes g_n[chunk 3] and
+        # the updated g_xc[chunk 2] (C per low-resolution pixel each)
+        pbk = 4 if (fused_prep_bwd and dg and bi == 2) else 0
         add(f"attn_bwd_c{C_}", nb * (win * 64000.0 * C_ + (2.0 * M * C_ * 3 * C_ if dg else 0.0) + (2.0 * M * C_ * 3 * C_ if rc else 0.0)),
-            nb * M * ((8 if dg else 7) - (2 if rc else 0)) * C_ * es, nb)
+            nb * M * ((8 if dg else 7) - (2 if rc else 0) + pbk) * C_ * es, nb)
         if (fused_c16_fwd if C_ == 16 else fused_attn_fwd):
             # reads x (+ the residual rows for C >= 64; for C = 16 the residual IS x), writes qkv + out (+ d1 for C = 16;
             # with recompute the C = 16 kernel writes d1 and out only)
@@ -193,7 +198,7 @@ def algorithmic_work(B: int, lr: int, scale: int, dtype: str, n_blocks: int = 8,
 def plan_options(plan) -> dict:
     """The kernel-selection options in force on a plan (m2t_plan_query("opt:<key>")): which kernels ran decides which
     rows of `algorithmic_work` apply."""
-    o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_c16_fwd", "conv_rows", "fused_conv_bwd", "fused_prep_fwd")}
+    o = {k: bool(plan.query("opt:" + k)) for k in ("fused_attn_fwd", "fused_c16_fwd", "conv_rows", "fused_conv_bwd", "fused_prep_fwd", "fused_prep_bwd")}
     o["fused_tail_fwd"] = plan.query("opt:fused_tail") >= 2
     o["c16_recompute"] = plan.query("opt:fused_c16_fwd") == 2
     o["c64_recompute"] = plan.query("opt:fused_attn_fwd") == 2
@@ -213,7 +218,7 @@ def roofline_report(B: int, lr: int, scale: int, dtype: str, steps: int, pmc_fil
     work = algorithmic_work(B, lr, scale, dtype, fused_attn_fwd=opts.get("fused_attn_fwd"), fused_tail_fwd=bool(opts.get("fused_tail_fwd", False)),
                             fused_qkv_dgrad=opts.get("fused_qkv_dgrad"), fused_c16_fwd=opts.get("fused_c16_fwd"),
                             c16_recompute=opts.get("c16_recompute"), c64_recompute=opts.get("c64_recompute"),
-                            fused_conv_bwd=opts.get("fused_conv_bwd"), c16_prep=opts.get("c16_prep"), fused_prep_fwd=opts.get("fused_prep_fwd"))
+                            fused_conv_bwd=opts.get("fused_conv_bwd"), c16_prep=opts.get("c16_prep"), fused_prep_fwd=opts.get("fused_prep_fwd"), fused_prep_bwd=opts.get("fused_prep_bwd"))
     traffic = {}
     if pmc_file and os.path.exists(pmc_file):
         try:

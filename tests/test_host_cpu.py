@@ -367,8 +367,11 @@ def test_roofline_work_table_matches_the_profiler_categories():
         assert abs((wd[cat][0] - w[cat][0]) - 8 * 2.0 * M * C * 3 * C) < 1.0          # the projection once more per launch ...
         assert abs((w[cat][1] - wd[cat][1]) - 8 * M * 2 * C * 2) < 1.0                # ... for 2 C fewer bf16 values read per pixel
     assert wd["attn_bwd_c256"] == w["attn_bwd_c256"]
-    fl, by, n = w["attn_bwd_c256"]
+    fl, by, n = P.algorithmic_work(16, 128, 4, "bf16", fused_prep_bwd=False)["attn_bwd_c256"]
     assert n == 16 and abs(fl / n - 10.64e9) < 0.05e9 and abs(by / n - 67.1e6) < 0.2e6
+    # round 4: branch 3's launches (8 of the 16) carry branch 4's branch_prep_bwd: + 4 C bf16 values per low-resolution pixel = 100.7 MB
+    fl2, by2, n2 = w["attn_bwd_c256"]
+    assert n2 == 16 and fl2 == fl and abs(by2 / n2 - (67.1e6 + 100.66e6) / 2) < 0.3e6
     w0 = P.algorithmic_work(16, 128, 4, "bf16", fused_attn_fwd=False, fused_qkv_dgrad=False, c16_recompute=False, c64_recompute=False)
     tot = lambda t, keys: sum(t[k][0] for k in keys if k in t)
     fwd_keys = ["attn_fwd_c16", "attn_fwd_c64", "attn_fwd_c256", "attn_fused_c16", "attn_fused_c64", "attn_fused_c256", "gemm_qkv"]
