@@ -295,13 +295,15 @@ int launch_instnorm_stats(int dt, const void* x, float* mean, float* rstd, float
 // every 4th partial; N = sum n_i, mean = sum n_i mean_i / N, M2 = sum (M2_i + n_i (mean_i - mean)^2) -- no division per merge, all
 // loads in flight at once, two LDS exchanges, every sum in a fixed order.  (The 64-thread pair tree this replaces took 15 us per
 // launch, more than the 12.5 us pass over the map that the epilogue partials had saved.)
+// NI partials per thread: 16 covers nsplit <= 64 (128 x 128 maps), 64 covers nsplit <= 256 (256 x 256); same sums in the same order
+template <int NI>
 __global__ void __launch_bounds__(256) instnorm_finalize_kernel(const float* __restrict__ part, float* __restrict__ mean,
                                                                 float* __restrict__ rstd, int nsplit, float eps) {
   const int b = blockIdx.x, ch = threadIdx.x & 63, q = threadIdx.x >> 6;
   __shared__ float sh[3][4][64];
-  float n[16], m[16], v[16];
+  float n[NI], m[NI], v[NI];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int s = q + 4 * i;
     n[i] = 0.f; m[i] = 0.f; v[i] = 0.f;
     if (s < nsplit) {
@@ -311,14 +313,14 @@ __global__ void __launch_bounds__(256) instnorm_finalize_kernel(const float* __r
   }
   float sn = 0.f, sm = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { sn += n[i]; sm = fmaf(n[i], m[i], sm); }
+  for (int i = 0; i < NI; ++i) { sn += n[i]; sm = fmaf(n[i], m[i], sm); }
   sh[0][q][ch] = sn; sh[1][q][ch] = sm;
   __syncthreads();
   const float N = (sh[0][0][ch] + sh[0][1][ch]) + (sh[0][2][ch] + sh[0][3][ch]);
   const float mu = ((sh[1][0][ch] + sh[1][1][ch]) + (sh[1][2][ch] + sh[1][3][ch])) / fmaxf(N, 1.f);
   float sq = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { const float d = m[i] - mu; sq += fmaf(n[i] * d, d, v[i]); }
+  for (int i = 0; i < NI; ++i) { const float d = m[i] - mu; sq += fmaf(n[i] * d, d, v[i]); }
   sh[2][q][ch] = sq;
   __syncthreads();
   if (q == 0) {
@@ -328,8 +330,9 @@ __global__ void __launch_bounds__(256) instnorm_finalize_kernel(const float* __r
   }
 }
 int launch_instnorm_finalize(const float* part, float* mean, float* rstd, int B, int nsplit, hipStream_t st) {
-  if (nsplit < 1 || nsplit > 2 * M2T_NORM_SPLIT) return m2t_set_error(-2, "instnorm_finalize: 1 .. 64 partials per image");
-  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(B), dim3(256), 0, st, part, mean, rstd, nsplit, 1e-5f);
+  if (nsplit < 1 || nsplit > 8 * M2T_NORM_SPLIT) return m2t_set_error(-2, "instnorm_finalize: 1 .. 256 partials per image");
+  if (nsplit <= 64) hipLaunchKernelGGL(instnorm_finalize_kernel<16>, dim3(B), dim3(256), 0, st, part, mean, rstd, nsplit, 1e-5f);
+  else hipLaunchKernelGGL(instnorm_finalize_kernel<64>, dim3(B), dim3(256), 0, st, part, mean, rstd, nsplit, 1e-5f);
   M2T_LAUNCH_CHECK();
   return 0;
 }

@@ -328,7 +328,7 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   }
   p->add_ws("xin", BP * 16, es);
   p->add_ws("a", BP * 16, es);
-  p->add_ws("norm_part", (size_t)B * 2 * M2T_NORM_SPLIT * 64 * 3, 4);      // (the conv epilogue leaves up to 64 partials per image)
+  p->add_ws("norm_part", (size_t)B * 8 * M2T_NORM_SPLIT * 64 * 3, 4);      // (the conv epilogue leaves up to 256 partials per image)
   p->add_ws("norm_s", (size_t)B * 64 * 2, 4);
   const int r0 = (s == 4) ? 2 : s;
   // tail activations: gelu(t) and gelu'(t) of each expansion (the pre-activation t itself is never needed again)
