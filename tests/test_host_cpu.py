@@ -463,3 +463,22 @@ def test_bf16_gelu_approximation_error_bound():
     assert float((der - O.gelu_derivative(t)).abs().max()) < 1e-4
     a32, d32 = O.gelu_fast_both(t.float())
     assert float((a32.double() - act).abs().max() / 1e4) < 1e-6 and float((d32.double() - der).abs().max()) < 1e-5
+
+
+def test_every_plan_option_is_documented_in_the_header_and_readable():
+    """include/m2t.h is the contract: every key m2t_set_option accepts must be described there (with its default in brackets), and
+    m2t_plan_query("opt:<key>") must know it, so that a bench line can echo what was in force.  Parsed from the source: no GPU needed."""
+    import os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    api = open(os.path.join(root, "m2trans_amd", "csrc", "m2t_api.hip")).read()
+    hdr = open(os.path.join(root, "include", "m2t.h")).read()
+    body = api[api.index('extern "C" int m2t_set_option'):]
+    body = body[:body.index("\n}\n")]
+    keys = sorted(set(re.findall(r'k == "([a-z_0-9]+)"', body)))
+    assert len(keys) >= 13 and "fork_on_kernel" in keys and "fused_prep_fwd" in keys and "fused_prep_bwd" in keys
+    query = api[api.index("long long m2t_plan_query"):]
+    for k in keys:
+        assert re.search(r'\*\s+"%s"\s+\[-?\d+\]' % k, hdr), f"option {k} is not documented (with its default) in include/m2t.h"
+        if k != "debug_skip_side":
+            assert f'o == "{k}"' in query, f'm2t_plan_query("opt:{k}") is missing'
+
