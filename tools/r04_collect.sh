@@ -17,3 +17,4 @@ cp $O/bench_tail.txt profiles/r04_bench_tail.txt; cp $O/valu_rate.txt profiles/r
 cp $O/attn_bwd_stamps.txt profiles/r04_attn_bwd_stamps.txt; cp $O/attn_fwd_stamps.txt profiles/r04_attn_fwd_stamps.txt
 cp $O/ab_options.txt profiles/r04_ab_options.txt; cp $O/soak.txt profiles/r04_soak.txt
 cp $O/pmc_traffic.json profiles/pmc_traffic.json; cp $O/pmc_traffic_config4.json profiles/pmc_traffic_config4.json
+cp $O/pmc_traffic_config3.json profiles/pmc_traffic_config3.json

@@ -10,6 +10,7 @@ timeout 1700 python -m pytest tests -q -m gpu --durations=10 2>&1 | tail -30 > $
 tail -3 $O/pytest.log
 timeout 900 python tools/pmc_traffic.py > $O/pmc_traffic.log 2>&1; cp profiles/pmc_traffic.json $O/pmc_traffic.json; tail -20 $O/pmc_traffic.log
 timeout 900 python tools/pmc_traffic.py --config 4 > $O/pmc_traffic_config4.log 2>&1; cp profiles/pmc_traffic_config4.json $O/pmc_traffic_config4.json; tail -8 $O/pmc_traffic_config4.log
+timeout 900 python tools/pmc_traffic.py --config 3 > $O/pmc_traffic_config3.log 2>&1; cp profiles/pmc_traffic_config3.json $O/pmc_traffic_config3.json; tail -4 $O/pmc_traffic_config3.log
 for c in 1 2 3 4; do
   extra="--no-cpu-baseline"; [ $c = 1 ] && extra=""
   timeout 600 python bench.py --config $c $extra > $O/bench_c$c.json 2> $O/bench_c$c.err
