@@ -28,6 +28,10 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 
+PRESETS = {1: dict(batch=16, lr_size=128, scale=4, sem=False), 2: dict(batch=32, lr_size=128, scale=4, sem=True),
+           3: dict(batch=32, lr_size=128, scale=4, sem=False), 4: dict(batch=8, lr_size=256, scale=3, sem=False)}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +61,9 @@ def parse():
     ap.add_argument("--semantic-loss", action="store_true",
                     help="BASELINE configs[2]: add the MedCLIP(Swin-T) image-text regulariser (random-init tower, hash text features)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=None)
+    ap.add_argument("--no-also", action="store_true",
+                    help="default run only: skip the short runs of the other BASELINE workloads that fill the line's `also` list")
+    ap.add_argument("--also-steps", type=int, default=6, help="timed steps of each `also` run (>= 5)")
     ap.add_argument("--stub-step", action="store_true",
                     help="HARNESS SELF-TEST on CPU: run this script's N-rank control flow with gloo and a sleeping stand-in for the step; "
                          "prints an `invalid` line with no throughput")
@@ -64,8 +71,7 @@ def parse():
     # presets = BASELINE.json configs[i]; configs[0] (x2 64x64 CPU forward) is a parity case, not a bench line
     if args.config is None:
         args.config = 1 if args.gpus == 1 else 3
-    preset = {1: dict(batch=16, lr_size=128, scale=4, sem=False), 2: dict(batch=32, lr_size=128, scale=4, sem=True),
-              3: dict(batch=32, lr_size=128, scale=4, sem=False), 4: dict(batch=8, lr_size=256, scale=3, sem=False)}[args.config]
+    preset = PRESETS[args.config]
     args.preset_overridden = any(v is not None for v in (args.batch, args.lr_size, args.scale))
     if args.batch is None:
         args.batch = preset["batch"]
@@ -146,120 +152,162 @@ def cpu_baseline(args):
                       f"{n} timed steps after 1 warm-up, torch CPU {torch.get_num_threads()} threads"}
 
 
-def child_command(argv, n_gpus: int, port: int):
-    """The launcher line a plain `python bench.py --gpus N` turns into: one rank per GPU under torch.distributed.run
-    (the same line the driver uses when it launches the ranks itself)."""
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
-            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+def child_command(argv, n_gpus: int, port=None):
+    """The launcher line a plain `python bench.py --gpus N` turns into: one rank per GPU under torch.distributed.run.
+    port = None: `--standalone --local-addr 127.0.0.1` (a c10d store on a port the LAUNCHER binds itself -- no probe-then-reuse
+    race); an explicit port gives the driver's own line (--master-addr 127.0.0.1 --master-port P)."""
+    rdzv = ["--standalone", "--local-addr", "127.0.0.1"] if port is None else ["--master-addr", "127.0.0.1", "--master-port", str(port)]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}"] + rdzv + [os.path.abspath(__file__)] + list(argv)
 
 
-def free_port() -> int:
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def visible_gpu_count(sysfs_root: str = "/sys/class/kfd/kfd/topology/nodes") -> int:
+def visible_gpu_count(sysfs_root=None):
     """GPUs this process could open, counted WITHOUT the HIP runtime (torch.cuda.device_count() falls back to
     hipGetDeviceCount when amdsmi is absent, which initialises HIP in the parent): KFD topology nodes with SIMDs are
-    GPUs (CPU nodes have simd_count 0), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES."""
+    GPUs (CPU nodes have simd_count 0), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.
+    Returns None when the topology cannot be read (sysfs not mounted, restricted container): UNKNOWN is not zero, and the
+    caller then lets the ranks fail with the real error instead of refusing."""
+    if sysfs_root is None:
+        sysfs_root = os.environ.get("M2T_KFD_TOPOLOGY", "/sys/class/kfd/kfd/topology/nodes")
     n = 0
     try:
-        for node in sorted(os.listdir(sysfs_root)):
-            try:
-                props = dict(l.split(None, 1) for l in open(os.path.join(sysfs_root, node, "properties")).read().splitlines() if " " in l)
-            except OSError:
-                continue
+        nodes = sorted(os.listdir(sysfs_root))
+    except OSError:
+        return None
+    readable = 0
+    for node in nodes:
+        try:
+            props = dict(l.split(None, 1) for l in open(os.path.join(sysfs_root, node, "properties")).read().splitlines() if " " in l)
+        except OSError:
+            continue
+        readable += 1
+        try:
             if int(props.get("simd_count", "0")) > 0:
                 n += 1
-    except OSError:
-        return 0
+        except ValueError:
+            continue
+    if readable == 0:
+        return None
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
-            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+            toks = [t.strip() for t in v.split(",") if t.strip() != ""]
+            if "-1" in toks:                         # the runtime stops reading the list at -1
+                toks = toks[:toks.index("-1")]
+            n = min(n, len(toks))
     return n
+
+
+def rank_environment(base=None, n_gpus: int = 1):
+    """Environment of the rank processes.  HSA_ENABLE_IPC_MODE_LEGACY: this pool's host driver only supports dmabuf IPC, and
+    without `0` RCCL between processes fails with `hipIpcGetMemHandle: invalid argument`; a value the caller exported wins
+    (other drivers may need the legacy mode) and whatever is in force is logged."""
+    env = dict(os.environ if base is None else base)
+    src = "caller" if "HSA_ENABLE_IPC_MODE_LEGACY" in env else "bench.py default"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(1, n_gpus))))
+    return env, f"HSA_ENABLE_IPC_MODE_LEGACY={env['HSA_ENABLE_IPC_MODE_LEGACY']} ({src})"
 
 
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (never an exec), relay rank 0's
-    JSON line, return the child's status.  The parent stays strictly GPU-free: devices are counted from sysfs."""
+    JSON line, return the child's status.  The parent stays strictly GPU-free: devices are counted from sysfs, and it refuses
+    only when sysfs POSITIVELY reports fewer GPUs than requested."""
     import subprocess
     if not args.stub_step:
         visible = visible_gpu_count()
-        if visible < args.gpus:
+        if visible is None:
+            print("bench.py: KFD topology not readable, device count unknown: launching the ranks anyway", file=sys.stderr)
+        elif visible < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {visible} device(s) are visible", file=sys.stderr)
             return 2
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(1, args.gpus))))
-    cmd = child_command(sys.argv[1:], args.gpus, free_port())
-    print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    env, ipc = rank_environment(n_gpus=args.gpus)
+    cmd = child_command(sys.argv[1:], args.gpus)
+    print("bench.py: " + ipc + "; launching " + " ".join(cmd), file=sys.stderr, flush=True)
     return subprocess.run(cmd, env=env).returncode
+
+
+def group_report(device_index: int) -> dict:
+    """What a SCALE record needs to be audited: the number of ranks READ BACK from the process group (not the flag), its
+    backend, and the device index every rank actually computes on (all-gathered; two ranks on one device = a broken launch)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"pg_ranks": 1, "rccl_ranks": None, "backend": None, "rank_devices": [device_index]}
+    backend = dist.get_backend()
+    on_gpu = backend == "nccl"
+    mine = torch.tensor([dist.get_rank(), device_index], dtype=torch.int64, device=torch.device("cuda", device_index) if on_gpu else "cpu")
+    alls = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(alls, mine)
+    devs = [int(t[1]) for t in sorted(alls, key=lambda t: int(t[0]))]
+    n = dist.get_world_size()
+    return {"pg_ranks": n, "rccl_ranks": n if on_gpu else None, "backend": backend, "rank_devices": devs,
+            "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
 
 
 def stub_main(args, world: int, rank: int) -> None:
     """--stub-step: the N-rank CONTROL FLOW of this script (launcher relay, WORLD_SIZE guard, barrier-bracketed timed region,
-    MAX-over-ranks time, rank-0-only JSON line) on CPU with gloo and a sleeping stand-in for the step.  A self-test of the
-    harness for boxes without GPUs (tests/test_host_cpu.py); its line says `invalid` and carries no throughput."""
+    MAX-over-ranks time, rank-0-only JSON line, process-group read-back, exposed-communication accounting) on CPU with gloo and a
+    sleeping stand-in for the step.  A self-test of the harness for boxes without GPUs (tests/test_host_cpu.py); its line says
+    `invalid` and carries no throughput."""
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus says {args.gpus}")
+    grp = group_report(int(os.environ.get("LOCAL_RANK", "0")))
     per_step = 0.01 * (1 + rank)                 # rank r is (r + 1) x slower: the MAX reduction must report the slowest rank
-    for _ in range(args.warmup):
+    grad = torch.ones(1024)
+    exposed = 0.0
+
+    def step():
+        nonlocal exposed
         time.sleep(per_step)
+        if world > 1:                            # the stand-in for the gradient exchange: the wait for it is the exposed time
+            t = time.perf_counter()
+            dist.all_reduce(grad)
+            exposed += time.perf_counter() - t
+
+    for _ in range(args.warmup):
+        step()
     if world > 1:
         dist.barrier()
+    exposed = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        time.sleep(per_step)
+        step()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     own = dt
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
+        t = torch.tensor([dt, exposed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        dt, exposed = float(t[0]), float(t[1])
     if rank == 0:
         print(json.dumps({"metric": "bench.py control-flow self-test (no GPU work)", "value": None, "invalid": True, "stub": True,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
                           "rank0_ms_per_step": round(1000.0 * own / args.steps, 3), "scaling": "weak",
+                          "rccl_ranks": grp["rccl_ranks"], "pg_ranks": grp["pg_ranks"], "rank_devices": grp["rank_devices"],
+                          "exposed_comm_ms_per_step": round(1000.0 * exposed / args.steps, 3),
                           "config": {"per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                                     "backend": "gloo", "world_size": dist.get_world_size() if dist.is_initialized() else 1}}), flush=True)
+                                     "backend": "gloo", "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+                                     "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}}), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_ranks(args))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU")
-    if args.stub_step:
-        return stub_main(args, world, rank)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    pg = None
-    backend = None
-    if world > 1 or (args.force_comm_path and "RANK" in os.environ):
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        backend = torch.distributed.get_backend()
-        if torch.distributed.get_world_size() != args.gpus and world > 1:
-            raise SystemExit(f"process group has {torch.distributed.get_world_size()} ranks, --gpus says {args.gpus}")
+WORKLOAD_NOTE = {1: "L1 loss only (BASELINE configs[1])", 2: "L1 + MedCLIP(Swin-T) regulariser (BASELINE configs[2])",
+                 3: "L1 loss only (BASELINE configs[3]: 32 patches per GPU, 256 on 8 GPUs)",
+                 4: "L1 loss only (BASELINE configs[4])"}
 
+
+def run_workload(args, device, rank: int, world: int, backend, grp: dict, cpu_base: bool) -> dict:
+    """Build the model + step driver for `args`, warm up, time EXACTLY args.steps steps between barriers, and return the JSON
+    object of the line (rank 0; other ranks return {})."""
     from m2trans_amd import _lib
     from m2trans_amd.M2Trans_network import create_model
     from m2trans_amd.train_step import TrainStep
+    from m2trans_amd import profile as m2t_profile
     import types
     _lib.load()
     torch.manual_seed(33)
@@ -275,7 +323,7 @@ def main():
     if args.semantic_loss:
         from m2trans_amd.losses import SemanticLoss
         sem = SemanticLoss(criterion="l1", N_patches=3, device=device, compute_dtype=args.dtype, max_batch=B, synthetic_text=True)
-        enc = sem._enc = None
+        sem._enc = None
         from m2trans_amd.losses import SwinEncoder
         e = SwinEncoder(2 * B, _lib.F32 if args.dtype == "fp32" else _lib.BF16, device)
         g = torch.Generator().manual_seed(33)
@@ -285,43 +333,42 @@ def main():
         del e
         sem.load_image_encoder(state)
         captions = [f"synthetic ultrasound caption {i}" for i in range(B)]
-    ts = TrainStep(model, lr=1e-4, lambda_l1=1.0, process_group=pg, world_size=world,
+    ts = TrainStep(model, lr=1e-4, lambda_l1=1.0, process_group=None, world_size=world,
                    semantic_loss=sem, lambda_clip=0.01 if sem is not None else 0.0,
                    overlap_comm=not args.no_overlap_comm, force_comm_path=args.force_comm_path,
                    overlap_semantic=not args.no_overlap_semantic)
     batches = [synthetic_batch(B, args.lr_size, args.scale, rank, s, device) for s in range(2)]
+    plan = model._plan_for(batches[0][0])
     if args.debug_skip_side:
-        plan = model._plan_for(batches[0][0])
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"debug_skip_side", 1), "m2t_set_option")
     for kv in args.option:
         key, val = kv.split("=")
-        plan = model._plan_for(batches[0][0])
         _lib.check(_lib.load().m2t_set_option(plan.handle, key.encode(), int(val)), "m2t_set_option")
     if args.no_side_stream:
-        plan = model._plan_for(batches[0][0])
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"side_stream", 0), "m2t_set_option")
 
-    from m2trans_amd import profile as m2t_profile
     dominant_mask = 0
-    # a non-default stream: the plan's CU-masked side stream is a blocking stream and would serialise
-    # against the legacy default stream
+    # a non-default stream: the plan's side stream is a blocking stream and would serialise against the legacy default stream
     if not args.null_stream:
         torch.cuda.synchronize()
         torch.cuda.set_stream(torch.cuda.Stream(device=device))
+    events_on = rank == 0 and not args.no_kernel_events
     for s in range(args.warmup):
-        if rank == 0 and not args.no_kernel_events and s == args.warmup - 1:
+        if events_on and s == args.warmup - 1:
             m2t_profile.enable()      # last warm-up step: time every category to find the dominant kernel
         ts.step(*batches[s % 2], captions)
     torch.cuda.synchronize()
-    if rank == 0 and not args.no_kernel_events and args.warmup > 0:
+    if events_on and args.warmup > 0:
         tt = m2t_profile.read_all()
         dominant_mask = m2t_profile.dominant_mask(tt)                    # dominant single-shape kernel
         m2t_profile.enable(0)
+    ts.measure_exposed_comm = ts.bucket is not None                      # events around the compute stream's wait for the exchange
+    ts.exposed_comm_events = []
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     stride = 1
-    if rank == 0 and not args.no_kernel_events:
+    if events_on:
         # HIP events on the launch stream around the dominant kernel only (keeps the timed region honest)
         stride = 1 if (args.all_kernel_events or not dominant_mask) else max(1, args.kernel_event_stride)
         m2t_profile.enable(m2t_profile.ALL_MASK if args.all_kernel_events else (dominant_mask or m2t_profile.ALL_MASK), sample_every=stride)
@@ -334,18 +381,20 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    exposed_ms = None
+    if ts.bucket is not None:
+        exposed_ms = sum(a.elapsed_time(b) for a, b in ts.exposed_comm_events) / max(1, args.steps)
+    ts.measure_exposed_comm = False
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt, exposed_ms or 0.0], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
+        dt, exposed_ms = float(t[0]), float(t[1])
     loss = float(ts.loss)
     roofline = None
-    if rank == 0 and not args.no_kernel_events:
-        roofline = m2t_profile.roofline_report(B, args.lr_size, args.scale, args.dtype, args.steps,
-                                               os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.config == 1 else f"pmc_traffic_config{args.config}.json"),
-                                               source_stamp(),
-                                               workload=f"config{args.config}" if not args.preset_overridden else None,
-                                               plan=model._plan_for(batches[0][0]))
+    if events_on:
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.config == 1 else f"pmc_traffic_config{args.config}.json")
+        wl = f"config{args.config}" if not args.preset_overridden else None
+        roofline = m2t_profile.roofline_report(B, args.lr_size, args.scale, args.dtype, args.steps, pmc, source_stamp(), workload=wl, plan=plan)
         if roofline is not None:
             roofline["timing"] = ("HIP events (hipEventDisableSystemFence: timing only, no L2 write-back behind the measured kernel) on the kernel's own "
                                   "dispatches, launch stream, inside the timed region; "
@@ -353,12 +402,25 @@ def main():
                                   + ".  avg_launch_us is the IN-STEP duration (two streams) and agrees with rocprofv3's kernel trace of this command run with "
                                     "--no-kernel-events; inside a rocprofv3 session the event-carrying launches themselves are recorded ~17 us longer "
                                     "(profiles/README.md, round 4), which lifts the average of the summary taken WITH events by ~3 us")
+            if not args.all_kernel_events:
+                # the other categories (side-stream weight-gradient GEMMs included) are timed AFTER the timed region, every launch of
+                # two extra steps, so that the step the value is quoted on carries events on one kernel only
+                m2t_profile.enable(m2t_profile.ALL_MASK, sample_every=1)
+                for s in range(2):
+                    ts.step(*batches[s % 2], captions)
+                torch.cuda.synchronize()
+                full = m2t_profile.roofline_report(B, args.lr_size, args.scale, args.dtype, 2, pmc, source_stamp(), workload=wl, plan=plan)
+                if full is not None:
+                    rows = [{k: full[k] for k in ("category", "bound", "frac", "avg_launch_us", "launches_per_step", "est_ms_per_step", "hbm_GBs", "mfma_TFs")}] + full["others"]
+                    rows = [r for r in rows if r["category"] != roofline["category"]]
+                    rows.sort(key=lambda r: -r["est_ms_per_step"])
+                    roofline["others"] = rows[:5]
+                    roofline["others_timing"] = ("top five other categories by est_ms_per_step; timed on two extra steps behind the timed region with events on "
+                                                 "EVERY dispatch of every category (the all-events mode costs ~8 % of the step and lengthens what it times by a few us)")
         m2t_profile.enable(0)
-
+    out = {}
     if rank == 0:
-        what = {1: "L1 loss only (BASELINE configs[1])", 2: "L1 + MedCLIP(Swin-T) regulariser (BASELINE configs[2])",
-                3: "L1 loss only (BASELINE configs[3]: 32 patches per GPU, 256 on 8 GPUs)",
-                4: "L1 loss only (BASELINE configs[4])"}[args.config]
+        what = WORKLOAD_NOTE[args.config]
         if args.preset_overridden:
             what = ("L1 + MedCLIP(Swin-T) regulariser" if args.semantic_loss else "L1 loss only") + " (preset overridden on the command line)"
         # every switch that changes the measured work or schedule is echoed, so an experiment cannot pass for a headline
@@ -381,11 +443,17 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic U[0,1) LR/HR patches resident in HBM, seed-33 reference init" + (
                 "; MedCLIP image tower = random-init Swin-T, text features = hash stand-ins (weights not vendored)" if args.semantic_loss else ""),
+            # audit fields of a multi-GPU record: ranks read back from the process group, the device of every rank, and the time the
+            # compute stream spent WAITING for the gradient exchange (by events around its wait on the communication stream; MAX over ranks)
+            "rccl_ranks": grp["rccl_ranks"],
+            "rank_devices": grp["rank_devices"],
+            "exposed_comm_ms_per_step": None if exposed_ms is None else round(exposed_ms, 4),
             "config": {"workload": f"x{args.scale} SR train step (fwd + L1 + bwd + Adam), {args.lr_size}x{args.lr_size} LR "
                                    f"patches, batch {B}/GPU, " + what,
                        "global_batch": world * B, "per_gpu_batch": B, "parallelism": f"dp{world}",
                        "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if backend else "none (single process)",
-                       "world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                       "world_size": grp["pg_ranks"],
+                       "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "grad_exchange": ("none" if ts.bucket is None else
                                          ("bucketed all-reduce overlapped with backward" if ts.overlap_comm else "one all-reduce after backward")),
                        "final_loss": round(loss, 6),
@@ -396,6 +464,85 @@ def main():
             out["config"]["experiment_flags"] = experiment
         if args.debug_skip_side:
             out["invalid"] = True          # parameter-gradient kernels skipped: not a train step
+    # release this workload's HBM (plans, workspaces, moments) before the next one
+    del ts, model, plan, batches, sem
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    if rank == 0 and cpu_base:
+        out["cpu_baseline"] = cpu_baseline(args)
+    return out
+
+
+ALSO_RUNS = [("config3", dict(config=3, dtype="bf16")), ("config4", dict(config=4, dtype="bf16")),
+             ("config2", dict(config=2, dtype="bf16")), ("config1_fp32", dict(config=1, dtype="fp32"))]
+
+
+def also_args(args, config: int, dtype: str):
+    """The argument set of one `also` run: the preset of BASELINE configs[config] at `dtype`, few steps, default options."""
+    import copy
+    a = copy.copy(args)
+    pre = PRESETS[config]
+    a.config, a.dtype = config, dtype
+    a.batch, a.lr_size, a.scale, a.semantic_loss = pre["batch"], pre["lr_size"], pre["scale"], pre["sem"]
+    a.preset_overridden = False
+    a.steps, a.warmup = max(5, args.also_steps), 2
+    a.cpu_baseline_batch = 2 if a.lr_size <= 128 else 1
+    return a
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU")
+    if args.stub_step:
+        return stub_main(args, world, rank)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    backend = None
+    if world > 1 or (args.force_comm_path and "RANK" in os.environ):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rank == 0:
+            print("bench.py: " + rank_environment(os.environ, world)[1], file=sys.stderr, flush=True)
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = torch.distributed.get_backend()
+        if torch.distributed.get_world_size() != args.gpus and world > 1:
+            raise SystemExit(f"process group has {torch.distributed.get_world_size()} ranks, --gpus says {args.gpus}")
+    grp = group_report(local_rank)
+    if world > 1 and len(set(grp["rank_devices"])) != world:
+        raise SystemExit(f"bench.py: ranks share a device: {grp['rank_devices']} (one rank per GPU is the contract)")
+
+    t_start = time.perf_counter()
+    out = run_workload(args, device, rank, world, backend, grp, cpu_base=False)
+    # the default line also carries short runs of the other BASELINE workloads, so that the driver's record shows them
+    plain_default = (world == 1 and args.config == 1 and not args.preset_overridden and args.dtype == "bf16" and not args.option
+                     and not any((args.no_side_stream, args.null_stream, args.no_overlap_comm, args.force_comm_path, args.all_kernel_events,
+                                  args.no_overlap_semantic, args.debug_skip_side, args.no_kernel_events)))
+    if plain_default and not args.no_also and rank == 0:
+        also = []
+        for name, kw in ALSO_RUNS:
+            if time.perf_counter() - t_start > 75.0:          # keep the whole default run within ~2 minutes
+                also.append({"workload": name, "skipped": "time box"})
+                continue
+            a = also_args(args, **kw)
+            try:
+                r = run_workload(a, device, rank, world, backend, grp, cpu_base=False)
+            except Exception as e:                              # an `also` run never takes the headline down with it
+                also.append({"workload": name, "error": f"{type(e).__name__}: {e}"[:300]})
+                continue
+            rf = r.get("roofline") or {}
+            also.append({"workload": name, "what": r["config"]["workload"], "dtype": r["dtype"], "value": r["value"], "unit": r["unit"],
+                         "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"], "per_gpu_batch": r["config"]["per_gpu_batch"],
+                         "final_loss": r["config"]["final_loss"],
+                         "dominant_kernel": {k: rf.get(k) for k in ("category", "kernel", "bound", "frac", "avg_launch_us", "launches_per_step", "achieved", "peak", "unit", "traffic")},
+                         "others": rf.get("others")})
+        out["also"] = also
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -30,6 +30,9 @@ from . import _lib
 from ._lib import M2TError
 
 _BRANCH_C = (16, 64, 256, 256)
+# plans (+ their workspaces, ~0.25 GB per 128x128 image in bf16) kept per model: an eval loop over images of arbitrary sizes
+# (test.py:77-122, metrics.evaluate) would otherwise grow HBM by one workspace per distinct shape, forever
+PLAN_CACHE_SIZE = int(os.environ.get("M2T_PLAN_CACHE", "8"))
 
 
 def create_model(args):
@@ -47,14 +50,16 @@ class Plan:
     def __init__(self, B: int, H0: int, W0: int, scale: int, n_blocks: int, dtype: int, device):
         lib = _lib.load()
         h = C.c_void_p()
-        _lib.check(lib.m2t_plan_create(C.byref(h), B, H0, W0, scale, n_blocks, dtype), "m2t_plan_create")
-        self.handle = h
-        self.B, self.H0, self.W0, self.scale, self.n_blocks, self.dtype = B, H0, W0, scale, n_blocks, dtype
-        self.device = device
-        self.gen = 0
-        nbytes = self.query("workspace_bytes")
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.handle = None
+        # everything the plan may create on a device (events, the side stream) belongs to `device`, not to whatever is current
         with torch.cuda.device(device):
+            _lib.check(lib.m2t_plan_create(C.byref(h), B, H0, W0, scale, n_blocks, dtype), "m2t_plan_create")
+            self.handle = h
+            self.B, self.H0, self.W0, self.scale, self.n_blocks, self.dtype = B, H0, W0, scale, n_blocks, dtype
+            self.device = device
+            self.gen = 0
+            nbytes = self.query("workspace_bytes")
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
             _lib.check(lib.m2t_plan_init_workspace(self.handle, _lib.ptr(self.workspace), _lib.stream_ptr()),
                        "m2t_plan_init_workspace")
 
@@ -137,7 +142,7 @@ class M2Trans(nn.Module):
         self.n_blocks = int(args.n_blocks)
         cd = getattr(args, "compute_dtype", None) or os.environ.get("M2T_COMPUTE_DTYPE", "fp32")
         self.compute_dtype = str(cd)
-        self._plans: Dict[Tuple, Plan] = {}
+        self._plans: "OrderedDict[Tuple, Plan]" = OrderedDict()
         self._build_parameters(n_feats)
         self._flatten()
 
@@ -228,7 +233,7 @@ class M2Trans(nn.Module):
         self._slots = slots
         self._names = [n for n, _ in named]
         self.flat_grads = None
-        self._plans = {}
+        self._plans = OrderedDict()
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -284,24 +289,37 @@ class M2Trans(nn.Module):
             return _lib.BF16
         raise M2TError(f"unknown compute_dtype {self.compute_dtype!r}")
 
-    def _plan_for(self, x: torch.Tensor) -> Plan:
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise M2TError("expected input of shape [B,3,H,W]")
+    def _device_ok(self, x) -> None:
         if not x.is_cuda:
             raise M2TError("M2Trans (MI355X build) runs only on a HIP device tensor; there is no CPU fallback")
         if self.flat_params.device != x.device:
             raise M2TError(f"model parameters are on {self.flat_params.device}, input on {x.device}")
+
+    def _check_plan(self, plan: Plan) -> None:
+        """The library's parameter inventory must be this module's (names, offsets, sizes)."""
+        if plan.query("num_params") != self.flat_params.numel():
+            raise M2TError("parameter inventory of the library and of the module differ")
+        for n, (o, k, _) in zip(self._names, self._slots):
+            if plan.query("param:" + n) != o or plan.query("numel:" + n) != k:
+                raise M2TError(f"parameter layout mismatch for {n}")
+
+    def _plan_for(self, x: torch.Tensor) -> Plan:
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise M2TError("expected input of shape [B,3,H,W]")
+        self._device_ok(x)
         B, _, H0, W0 = x.shape
         key = (B, H0, W0, self._dtype_code(), x.device.index)
         plan = self._plans.get(key)
         if plan is None:
             plan = Plan(B, H0, W0, self.scale, self.n_blocks, key[3], x.device)
-            if plan.query("num_params") != self.flat_params.numel():
-                raise M2TError("parameter inventory of the library and of the module differ")
-            for n, (o, k, _) in zip(self._names, self._slots):
-                if plan.query("param:" + n) != o or plan.query("numel:" + n) != k:
-                    raise M2TError(f"parameter layout mismatch for {n}")
+            self._check_plan(plan)
             self._plans[key] = plan
+            # least-recently-used plans go first; a plan whose backward is still pending is kept alive by its autograd node
+            # (ctx.plan), only the cache entry is dropped
+            while len(self._plans) > max(1, PLAN_CACHE_SIZE):
+                self._plans.popitem(last=False)
+        else:
+            self._plans.move_to_end(key)
         return plan
 
     def _run_forward(self, plan: Plan, x: torch.Tensor, keep: bool, want_sr: bool = True):

@@ -65,9 +65,26 @@ def import_checkpoint(ckpt: dict, model, train_step=None) -> int:
     schedule with ``cosine_lr(train_step.scheduler_last_epoch + k)`` after k further scheduler steps -- like the
     reference, whose resumed run re-uses the saved epoch's rate for its first epoch (train.py:103,358)."""
     model.load_state_dict(ckpt["model_state_dict"], strict=True)
-    if train_step is not None and ckpt.get("optimizer_state_dict", {}).get("state"):
+    if train_step is None:
+        return int(ckpt.get("epoch", 0)) + 1
+    opt = ckpt.get("optimizer_state_dict") or {}
+    sch = ckpt.get("scheduler_state_dict")
+    if not opt.get("state") and not opt.get("param_groups") and sch is None:
+        # weights only = the reference's --pretrain load (train.py:85-88): model weights alone, fresh Adam moments, fresh
+        # CosineAnnealingLR, start_epoch stays 1 (train.py:62)
+        train_step.exp_avg.zero_()
+        train_step.exp_avg_sq.zero_()
+        train_step.step_count = 0
+        train_step.scheduler_last_epoch = 0
+        return 1
+    if sch is None:
+        # Adam state without the schedule it belongs to: the reference's --resume (train.py:97-103) always loads both, and
+        # continuing epoch-N moments / learning rate on a schedule restarted at 0 would silently train something else
+        raise ValueError("checkpoint carries optimizer_state_dict but no scheduler_state_dict: not a resume checkpoint of "
+                         "train.py:341-349; pass the model weights alone (a --pretrain load) or a complete checkpoint")
+    if opt.get("state"):
         idx = _param_index(model)
-        st = ckpt["optimizer_state_dict"]["state"]
+        st = opt["state"]
         step = 0
         for n, (o, k, shp) in zip(model._names, model._slots):
             s = st.get(idx[n]) or st.get(str(idx[n]))
@@ -77,15 +94,8 @@ def import_checkpoint(ckpt: dict, model, train_step=None) -> int:
             train_step.exp_avg_sq[o:o + k].copy_(s["exp_avg_sq"].reshape(-1).to(train_step.exp_avg_sq))
             step = int(float(s["step"]))
         train_step.step_count = step
-    if train_step is not None:
-        pg = ckpt.get("optimizer_state_dict", {}).get("param_groups")
-        if pg:
-            train_step.set_lr(pg[0]["lr"])
-        sch = ckpt.get("scheduler_state_dict")
-        if sch is not None:
-            train_step.scheduler_last_epoch = int(sch.get("last_epoch", 0))
-        else:
-            # no scheduler state: only --resume restores the schedule (train.py:97-103) and resume checkpoints always carry it;
-            # a --pretrain load (train.py:85-88) takes the model weights alone and starts CosineAnnealingLR fresh
-            train_step.scheduler_last_epoch = 0
+    pg = opt.get("param_groups")
+    if pg:
+        train_step.set_lr(pg[0]["lr"])
+    train_step.scheduler_last_epoch = int(sch.get("last_epoch", 0))
     return int(ckpt.get("epoch", 0)) + 1

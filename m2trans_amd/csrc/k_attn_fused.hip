@@ -133,8 +133,11 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
   float(*Os)[OLD] = reinterpret_cast<float(*)[OLD]>(smem + Cfg::offK);        // phase 4 on: overlays Kh | Qs
   float(*red)[2][64] = reinterpret_cast<float(*)[2][64]>(smem + Cfg::offR);   // [max | sum][key half][query]
 
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int lr = lane & 15, g = lane >> 4;
+  // (not const: with PREP they are re-derived from a laundered copy of tid behind phase 2 -- at 256 VGPRs every index value that is
+  // live ACROSS the projection but not used in it is spilled to scratch (hipcc does not rematerialise `tid >> 2`), and its reload in the
+  // softmax phase then waits, vmcnt(0), for the q | k | v stores in flight)
+  int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int lr = lane & 15, g = lane >> 4;
   const WinGeom gm = make_geom(h, w);
   const bf16x8* wf8 = reinterpret_cast<const bf16x8*>(wfrag);
   // fragment (projection p, channel tile ct of it, k-step ks): one contiguous 1 KB per wave
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
       for (int m = 0; m < TPW; ++m) mma16(aq[t][m], wqf[ks][m], b);
     }
   M2T_FUSED_STAMP(2);
-
+  if constexpr (PREP) asm volatile("" : "+v"(lr));     // phase 2's key indices 16 t + lr: new values, not phase 1's row indices kept alive
   // the residual rows of the epilogue.  Without PREP they are fetched here, before the first global store (vmcnt retires in order).
   // With PREP they are this kernel's own xin stores of phase 0, written by other waves: every wave's stores have retired when it has
   // consumed its last weight fragment (in-order vmcnt; the release fence below states it), so the loads are issued behind the
@@ -349,8 +352,8 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
   // been acknowledged.
   constexpr int ES = Haar<L>::S, EPARTS = (L == 0) ? 1 : NTHR / 256, EROWS = (L == 0) ? 1 : ES / EPARTS;
   bf16x4 resv[EROWS][(L == 0) ? 1 : ES];
-  const int e_item = tid & 255, e_part = tid >> 8;
-  const int e_q = e_item >> 2, e_cg = e_item & 3;
+  int e_item = tid & 255, e_part = tid >> 8;
+  int e_q = e_item >> 2, e_cg = e_item & 3;
   auto load_residual = [&]() {
     if constexpr (L > 0) {
       const int H = h * ES, W = w * ES;
@@ -416,6 +419,9 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
   lds_barrier();                        // every wave is done reading x and the rel-pos table; Kh and Qs are complete
   M2T_FUSED_STAMP(3);
   if constexpr (PREP) {
+    asm volatile("" : "+v"(tid));        // a new value for the register allocator: what follows extends no live range across phase 1
+    lane = tid & 63; wv = tid >> 6; lr = lane & 15; g = lane >> 4;
+    e_item = tid & 255; e_part = tid >> 8; e_q = e_item >> 2; e_cg = e_item & 3;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     load_residual();
   }

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
   T(*A1)[TB_LD] = reinterpret_cast<T(*)[TB_LD]>(smem + off);  off += sizeof(T) * 64 * TB_LD;    // a1 tile [mid pixel][k]
   T(*W3s)[264] = reinterpret_cast<T(*)[264]>(smem + off);                                      // W3^T [k][n'] (whole strip)
 
-  const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w8 = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR arithmetic
   const int lr = lane & 15, g = lane >> 4;
   const int H = a.H, W = a.W, Hm = H / 2, Wm = W / 2;
   const int tw = W / TB_T, th = H / TB_T;

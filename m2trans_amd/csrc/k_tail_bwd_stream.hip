@@ -98,7 +98,9 @@ __global__ void __launch_bounds__(BSCfg<R>::NTHR, (R == 2 ? 2 : 4)) tail_bwd_str
   T(*A2)[16][BS_LDG] = reinterpret_cast<T(*)[16][BS_LDG]>(smem + Cfg::oA2);                 // act    [sub][pixel][c]
   T(*GE)[16][BS_LDE] = reinterpret_cast<T(*)[16][BS_LDE]>(smem + Cfg::oGE);                 // Geff   [sub][pixel][(tap,oc)]
   T(*A1)[BS_LDG] = reinterpret_cast<T(*)[BS_LDG]>(smem + Cfg::oA1);                         // input  [pixel][k]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // (wv through readfirstlane: the wave index, the sub-pixel position and everything derived from them are wave-uniform and live in
+  //  SGPRs -- the address arithmetic they feed is scalar and does not compete with the accumulators for the 128 / 256 vector registers)
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, g = lane >> 4;
   // R = 2: every wave is a producer and owns the dW / db tiles of its sub-pixel position (88 accumulator registers, 256 per wave,
   // two workgroups per CU).  R = 3: nine producers cannot carry 16 dW tiles each at three waves per SIMD (168 registers), so the
@@ -128,19 +130,6 @@ __global__ void __launch_bounds__(BSCfg<R>::NTHR, (R == 2 ? 2 : 4)) tail_bwd_str
     reinterpret_cast<float*>(Bs)[i] = p.b3[(32 * kc + 8 * gg + 4 * hf + r) * NW + w];
   }
   for (int i = tid; i < 3 * RSLOT * BS_RROW; i += NTHR) Gr[i] = 0.f;
-  bf16x4 ones4;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) ones4[e] = (T)1.0f;
-  // this lane's eight Geff sources: k-slot 8 g + j = (tap, oc) = (n / 3, n % 3); pixel row R r + sy, column R (ci + lr) + sx;
-  // source row R r + sy - ky + 1 = window row sy - ky + 2 of the step's R + 2 ring rows, ring column R lr + sx - kx + 2.
-  // k-slots 27 .. 31 read a column the ring never writes (zero)
-  int gsrc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int n = 8 * g + j;
-    const int tap = n / 3, oc = n - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
-    gsrc[j] = (n < 27) ? ((oc * RSLOT + (sy - ky + 2)) * BS_RROW + R * lr + sx - kx + 2) : 60;
-  }
   // parameter-gradient accumulators of the whole launch.  accW: R = 2: [tau][kappa] of the wave's own position; R = 3 (helper h =
   // wv - 9): n' tiles T = h, h + 7, .. (T = 4 sub + tau), up to six of them
   // (R = 3: the helper waves run their OWN loop below -- separate code, so that the producers' registers do not carry the helpers'
@@ -157,7 +146,7 @@ __global__ void __launch_bounds__(BSCfg<R>::NTHR, (R == 2 ? 2 : 4)) tail_bwd_str
       __syncthreads();
       for (int task = xcd_block_index(); task < p.ntask; task += gridDim.x) {
         const int strip = task % p.nstrip, seg = (task / p.nstrip) % p.nseg, b = task / (p.nstrip * p.nseg);
-        const long long pixt = ((long long)b * Hi + p.rows * seg) * Wi + 16 * strip + lr;
+        const long long pixt = ((long long)b * Hi + p.rows * seg) * Wi + 16 * strip;         // wave-uniform: the lane's pixel is added as a 32-bit offset
         lds_barrier();                                            // (the producers' prologue barrier)
         for (int s = 0; s < p.rows; ++s) {
           lds_barrier();                                          // phase A of the producers is complete
@@ -181,12 +170,17 @@ __global__ void __launch_bounds__(BSCfg<R>::NTHR, (R == 2 ? 2 : 4)) tail_bwd_str
             for (int kc8 = 0; kc8 < 2 * NW; ++kc8)
               mma16(accD, load8(&W3s[16 * h + lr][32 * kc8 + 8 * g]), load8(&G[kc8 >> 1][lr][32 * (kc8 & 1) + 8 * g]));
             float v[4] = {accD[0], accD[1], accD[2], accD[3]};
-            store4(p.ga + ((long long)h * npix + pixt + (long long)s * Wi) * 16 + 4 * g, v);          // TAIL0: P64, plane = channel tile
+            int lo = 16 * lr + 4 * g;
+            asm volatile("" : "+v"(lo));                          // (or hipcc keeps p.ga + lo as a 64-bit pair across the loop -- and spills it)
+            store4(p.ga + ((long long)h * npix + pixt + (long long)s * Wi) * 16 + lo, v);          // TAIL0: P64, plane = channel tile
           }
           lds_barrier();
         }
       }
       float* out = p.slab_w3 + (long long)blockIdx.x * (64 * NW * 64);
+      int ln2 = lane;
+      asm volatile("" : "+v"(ln2));                               // (the slab addresses are computed here, not kept across the loop)
+      const int lr2 = ln2 & 15, g2 = ln2 >> 4;
 #pragma unroll
       for (int i = 0; i < NTW; ++i) {
         const int Tn = h + 7 * i;
@@ -194,11 +188,25 @@ __global__ void __launch_bounds__(BSCfg<R>::NTHR, (R == 2 ? 2 : 4)) tail_bwd_str
 #pragma unroll
           for (int kp = 0; kp < 4; ++kp)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[(long long)(16 * Tn + 4 * g + r) * 64 + 16 * kp + lr] = aW[i][kp][r];
+            for (int r = 0; r < 4; ++r) out[(long long)(16 * Tn + 4 * g2 + r) * 64 + 16 * kp + lr2] = aW[i][kp][r];
         }
       }
       return;
     }
+  }
+  // (producer-only values from here on: computed behind the helpers' branch so that none of them is live across it)
+  bf16x4 ones4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) ones4[e] = (T)1.0f;
+  // this lane's eight Geff sources: k-slot 8 g + j = (tap, oc) = (n / 3, n % 3); pixel row R r + sy, column R (ci + lr) + sx;
+  // source row R r + sy - ky + 1 = window row sy - ky + 2 of the step's R + 2 ring rows, ring column R lr + sx - kx + 2.
+  // k-slots 27 .. 31 read a column the ring never writes (zero)
+  int gsrc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int n = 8 * g + j;
+    const int tap = n / 3, oc = n - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
+    gsrc[j] = (n < 27) ? ((oc * RSLOT + (sy - ky + 2)) * BS_RROW + R * lr + sx - kx + 2) : 60;
   }
   constexpr int NTW = HELP ? 1 : 4;
   f32x4 accW[NTW][4], accB[4], accF[FT];
@@ -280,6 +288,12 @@ __global__ void __launch_bounds__(BSCfg<R>::NTHR, (R == 2 ? 2 : 4)) tail_bwd_str
     auto step = [&](int s, auto cc_tag, Frag8<T> (&cur)[2], Frag8<T> (&nxt)[2]) {
       constexpr int CC = decltype(cc_tag)::value;
       const int r = ri + s;
+      // R = 3 runs at 128 registers: left alone, hipcc hoists every lane-dependent LDS address of the four unrolled steps out of the
+      // row loop (~100 values) and spills 70 of them -- and scratch reloads are VMEM operations that retire in order with the row
+      // prefetches.  A laundered lane index per step keeps the address arithmetic inside the step (a few dozen integer operations)
+      int ln_ = lane;
+      if constexpr (R == 3) asm volatile("" : "+v"(ln_));
+      const int lr = ln_ & 15, g = ln_ >> 4, tq = lr >> 2, tp = lr & 3;
       // ---- phase A ----
       BS_STAMP(0);
       a_load(s + 1, nxt);

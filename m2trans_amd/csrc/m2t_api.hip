@@ -418,9 +418,10 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
   if (k.rfind("opt:", 0) == 0) {        // the options in force (profile.py prices the kernels that actually run)
     const std::string o = k.substr(4);
     if (o == "side_stream") return p->use_side;
-    if (o == "fork_on_kernel") return p->fork_on_kernel;
-    if (o == "fused_prep_fwd") return p->use_fused_prep_fwd;
-    if (o == "fused_prep_bwd") return p->use_fused_prep_bwd;
+    // (the EFFECTIVE state, like the keys below: an option whose precondition is off did not run)
+    if (o == "fork_on_kernel") return p->use_side && p->fork_on_kernel;
+    if (o == "fused_prep_fwd") return p->dt != M2T_F32 && p->use_fused_attn_fwd != 0 && p->use_fused_prep_fwd;
+    if (o == "fused_prep_bwd") return p->dt != M2T_F32 && p->use_resident_attn_bwd && p->use_fused_qkv_dgrad && p->use_fused_prep_bwd;
     if (o == "gate_branch") return p->gate_branch + 1000;      // (offset: -1 is the "unknown key" value of this function)
     if (o == "wgrad_big_tiles") return p->wgrad_big_tiles + 1000;
     if (o == "fused_tail") {
@@ -638,6 +639,10 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   // option "fork_on_kernel": arm_fork() in front of the launch the fork follows; the event then rides on that dispatch as its stop
   // event (no marker packet between the kernel and its successor on the main stream).  fork() records as usual if nothing took it.
   hipEvent_t armed = nullptr;
+  // the armed event is thread-local state that the NEXT timed launch of this thread takes: nothing armed by an earlier call (one that
+  // returned early between arm_fork() and its launch) may leak into this pass, and nothing armed here may outlive it on any exit path
+  g_fork_armed = nullptr;
+  struct ForkArmGuard { ~ForkArmGuard() { g_fork_armed = nullptr; } } fork_arm_guard;
   hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap_status);
   const bool fork_on_kernel = p->fork_on_kernel && cap_status == hipStreamCaptureStatusNone;   // an event-carrying dispatch is not a graph node

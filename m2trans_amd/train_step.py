@@ -73,6 +73,10 @@ class TrainStep:
         self.overlap_comm = bool(overlap_comm) and self.bucket is not None
         self.comm_stream = torch.cuda.Stream(device=flat.device) if self.overlap_comm else None
         self._last_plan = None
+        # bench.py / audits: with measure_exposed_comm the compute stream's wait for the gradient exchange is bracketed by two
+        # timing events per step (exposed_comm_events: [(before, after)]) -- what the exchange costs the step after the overlap
+        self.measure_exposed_comm = False
+        self.exposed_comm_events = []
 
     def set_lr(self, lr: float):
         self.lr = float(lr)
@@ -131,6 +135,17 @@ class TrainStep:
         kernels; the compute stream then waits for the communication stream (before Adam)."""
         if self.bucket is None:
             return
+        ev0 = None
+        if self.measure_exposed_comm:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(self.grads.device))
+        self._all_reduce_grads()
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(torch.cuda.current_stream(self.grads.device))
+            self.exposed_comm_events.append((ev0, ev1))
+
+    def _all_reduce_grads(self):
         if not self.overlap_comm or self._last_plan is None:
             self.bucket.all_reduce()
             return

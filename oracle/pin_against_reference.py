@@ -347,6 +347,29 @@ def main():
     np.savez_compressed(os.path.join(out_dir, "augment.npz"), **gold)
     report.append(f"utils.cutmix / utils.cut_out: 12 seeded calls bit-equal to utils.py ({ncm} / {nco} of them modify the batch) -> tests/golden/augment.npz")
 
+    # ---- 13. the config surface (train.py:30-34,70; utils.py:175-176; configs/*.yml): every shipped yaml is parsed the way
+    # train.py does (argparse namespace updated with the yaml dict), the REAL reference builds its model from it, and the
+    # key / value sets plus the resulting state_dict inventory (names, shapes, dtypes, in order) are written as data ----
+    import glob
+    import json as _json
+    import yaml
+    surf = {}
+    for path in sorted(glob.glob(os.path.join(REF, "configs", "*.yml"))):
+        cfg = yaml.load(open(path), Loader=yaml.FullLoader)
+        ns = types.SimpleNamespace(config=path, resume=None)
+        vars(ns).update(cfg)                                   # train.py:31-34
+        import importlib
+        m = importlib.import_module("models.{}_network".format(ns.model)).create_model(ns)      # train.py:70 / utils.py:175-176
+        inv = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+        surf[os.path.basename(path)] = {"yaml": cfg, "state_dict": inv,
+                                        "n_params": int(sum(p.numel() for p in m.parameters())),
+                                        "n_trainable": int(sum(p.numel() for p in m.parameters() if p.requires_grad))}
+    assert len(surf) == 6, sorted(surf)
+    with open(os.path.join(out_dir, "config_surface.json"), "w") as f:
+        _json.dump(surf, f, indent=1, sort_keys=False)
+    report.append(f"config surface: {len(surf)} shipped yaml files parsed as train.py:30-34 does, model built by the reference through "
+                  f"utils.import_module (train.py:70), key/value sets + state_dict inventories -> tests/golden/config_surface.json")
+
     with open(os.path.join(HERE, "PINNING.txt"), "w") as f:
         f.write("oracle/m2trans_oracle.py checked against /root/reference "
                 "(models/M2Trans_network.py, utils.py, datas/us1k.py, datas/benchmark.py) by oracle/pin_against_reference.py\n")

@@ -298,6 +298,34 @@ def test_checkpoint_round_trip_reference_format():
     assert fs2.step_count == 7 and fs2.lr == 5e-5 and fs2.scheduler_last_epoch == 2
 
 
+def test_checkpoint_without_scheduler_state_is_a_pretrain_load_or_an_error():
+    """train.py:85-88 (--pretrain): model weights alone -> fresh Adam moments, fresh cosine schedule, start_epoch 1.  A file with Adam
+    state but no scheduler state is not something train.py:341-349 writes: resuming its moments on a restarted schedule would train
+    something else, so it is refused."""
+    from m2trans_amd.M2Trans_network import create_model
+    from m2trans_amd.checkpoint import export_checkpoint, import_checkpoint
+    m = create_model(_args(4, 1))
+    ck = export_checkpoint(m, _FakeStep(m), epoch=5)
+    weights_only = {"epoch": 5, "model_state_dict": ck["model_state_dict"]}
+    m2 = create_model(_args(4, 1))
+    fs2 = _FakeStep(m2)
+    fs2.scheduler_last_epoch = 9
+    lr_before = fs2.lr
+    assert import_checkpoint(weights_only, m2, fs2) == 1               # start_epoch stays 1 (train.py:62)
+    assert torch.equal(m2.flat_params, m.flat_params)
+    assert fs2.step_count == 0 and fs2.scheduler_last_epoch == 0 and fs2.lr == lr_before
+    assert float(fs2.exp_avg.abs().max()) == 0.0 and float(fs2.exp_avg_sq.abs().max()) == 0.0
+    # model only, no step driver: the epoch bookkeeping of test.py-style loads is unchanged
+    assert import_checkpoint(weights_only, create_model(_args(4, 1))) == 6
+    broken = {k: v for k, v in ck.items() if k != "scheduler_state_dict"}
+    m3 = create_model(_args(4, 1))
+    fs3 = _FakeStep(m3)
+    before = fs3.exp_avg.clone()
+    with pytest.raises(ValueError, match="scheduler_state_dict"):
+        import_checkpoint(broken, m3, fs3)
+    assert torch.equal(fs3.exp_avg, before) and fs3.step_count == 7     # nothing half-restored
+
+
 def test_checkpoint_matches_the_reference_manifest(golden_dir):
     """export_checkpoint against the manifest of what the REAL reference saves (DataParallel model + torch.optim.Adam +
     CosineAnnealingLR run through two epochs, oracle/pin_against_reference.py section 10): same keys at every level,
@@ -397,14 +425,35 @@ def test_bench_plain_multi_gpu_launch_builds_the_torchrun_child():
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
     i = cmd.index(os.path.join(ROOT, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    # the self-launched line lets the LAUNCHER bind its rendezvous port (no probe-then-reuse race), on 127.0.0.1
+    cmd = bench.child_command(["--gpus", "2"], 2)
+    assert "--standalone" in cmd and cmd[cmd.index("--local-addr") + 1] == "127.0.0.1" and "--master-port" not in cmd
+    assert "free_port" not in open(os.path.join(ROOT, "bench.py")).read()
+    # HSA_ENABLE_IPC_MODE_LEGACY: defaulted to 0 (dmabuf IPC, what this pool's driver needs), a caller's value wins, and it is logged
+    env, note = bench.rank_environment({"PATH": "/usr/bin"}, 2)
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "bench.py default" in note
+    env, note = bench.rank_environment({"HSA_ENABLE_IPC_MODE_LEGACY": "1"}, 2)
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "1" and "caller" in note and "=1" in note
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "os.exec" not in src and "execv" not in src
-    # no GPU here: the parent must fail loudly (non-zero, no JSON line, no fallback) instead of running on fewer devices
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
-                       capture_output=True, text=True, env=env, timeout=300)
-    assert r.returncode != 0 and "{" not in r.stdout
-    assert "only" in r.stderr and "visible" in r.stderr
+    # fewer devices than ranks: the parent must fail loudly (non-zero, no JSON line, no fallback) instead of running on fewer devices.
+    # It refuses by itself only when the KFD topology POSITIVELY says so ...
+    import tempfile
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES",
+                                                            "CUDA_VISIBLE_DEVICES")}
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "0"))
+        open(os.path.join(td, "0", "properties"), "w").write("simd_count 1024\n")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, env=dict(env, M2T_KFD_TOPOLOGY=td), timeout=300)
+        assert r.returncode == 2 and "{" not in r.stdout
+        assert "only 1 device(s) are visible" in r.stderr and "launching" not in r.stderr
+        # ... and when the topology is unreadable (UNKNOWN, not zero) the ranks are started and fail with the real error
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, env=dict(env, M2T_KFD_TOPOLOGY=os.path.join(td, "missing")), timeout=300)
+        if not torch.cuda.is_available():
+            assert r.returncode != 0 and "{" not in r.stdout
+        assert "device count unknown" in r.stderr and "launching" in r.stderr
     # under a launcher whose WORLD_SIZE disagrees with --gpus the rank refuses as well
     env.update(WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
@@ -428,7 +477,16 @@ def test_bench_visible_gpu_count_reads_kfd_topology(tmp_path, monkeypatch):
     assert bench.visible_gpu_count(str(tmp_path)) == 2
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
     assert bench.visible_gpu_count(str(tmp_path)) == 1
-    assert bench.visible_gpu_count(str(tmp_path / "missing")) == 0
+    # a -1 token ends the list for the runtime: it is not a device
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "-1")
+    assert bench.visible_gpu_count(str(tmp_path)) == 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,-1,2")
+    assert bench.visible_gpu_count(str(tmp_path)) == 1
+    # unreadable / empty topology = UNKNOWN (None), not zero: the launcher then lets the ranks report the real error
+    assert bench.visible_gpu_count(str(tmp_path / "missing")) is None
+    (tmp_path / "empty").mkdir()
+    assert bench.visible_gpu_count(str(tmp_path / "empty")) is None
 
 
 def test_bench_two_rank_control_flow_end_to_end_on_a_stub_step():
@@ -438,7 +496,7 @@ def test_bench_two_rank_control_flow_end_to_end_on_a_stub_step():
     import json
     import subprocess
     import sys
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--stub-step",
                         "--batch", "5"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -451,6 +509,13 @@ def test_bench_two_rank_control_flow_end_to_end_on_a_stub_step():
     # rank 1 sleeps 20 ms per step, rank 0 10 ms: the barrier-bracketed MAX is >= 20 ms per step
     assert d["ms_per_step"] >= 19.5 and d["ms_per_step"] < 60.0, d
     assert "launching" in r.stderr and "torch.distributed.run" in r.stderr
+    # audit fields of a multi-GPU record: ranks READ BACK from the process group, the device of every rank (all-gathered, in
+    # rank order), the exposed communication time (rank 0 waits ~10 ms per step for the slower rank 1 inside the exchange)
+    assert d["pg_ranks"] == 2 and d["rccl_ranks"] is None            # gloo here; the GPU line reports rccl_ranks = world size
+    assert d["rank_devices"] == [0, 1]
+    assert 5.0 <= d["exposed_comm_ms_per_step"] < 40.0, d
+    assert d["config"]["ipc_mode_legacy"] == "0" and "HSA_ENABLE_IPC_MODE_LEGACY=0 (bench.py default)" in r.stderr
+    assert "--standalone" in r.stderr
 
 
 def test_bf16_gelu_approximation_error_bound():
@@ -482,3 +547,34 @@ def test_every_plan_option_is_documented_in_the_header_and_readable():
         if k != "debug_skip_side":
             assert f'o == "{k}"' in query, f'm2t_plan_query("opt:{k}") is missing'
 
+
+
+def test_no_kernel_outside_the_fp32_whitelist_uses_scratch(monkeypatch, tmp_path):
+    """Round 5 policy: the build FAILS when a non-fp32 kernel reports ScratchSize > 0 (a spilled value is reloaded by a VMEM operation
+    that retires in order with the kernel's prefetches and behind its stores in flight).  The sidecar files written at compile time make
+    an incremental build report what a clean one does."""
+    from m2trans_amd import build as B
+    B.build(force=False, verbose=False)                      # raises ScratchError on a violation
+    assert B.scratch_violations() == []
+    for src, rows in B.spill_report().items():
+        for name, nbytes in rows:
+            assert B._spill_allowed(name), (src, name, nbytes)
+    for s in B.SOURCES:                                      # every object has its report (a missing sidecar would hide a spill)
+        assert os.path.exists(os.path.join(B.HERE, "build", s.replace(".hip", ".spills.json"))), s
+    # the remark parser and the policy, on a fabricated report
+    remarks = ("x.hip:1:1: remark: Function Name: _ZN12_GLOBAL__N_122tail_bwd_stream_kernelILi3ELb1EEEvNS_6BSArgsE [-Rpass-analysis=kernel-resource-usage]\n"
+               "x.hip:1:1: remark:     ScratchSize [bytes/lane]: 288 [-Rpass-analysis=kernel-resource-usage]\n"
+               "x.hip:1:1: remark: Function Name: _ZN12_GLOBAL__N_122window_attn_bwd_kernelIfLi256ELi2EEEvPKT_ [-Rpass-analysis=kernel-resource-usage]\n"
+               "x.hip:1:1: remark:     ScratchSize [bytes/lane]: 64 [-Rpass-analysis=kernel-resource-usage]\n"
+               "x.hip:1:1: remark: Function Name: _ZN12_GLOBAL__N_111adam_kernelEPf [-Rpass-analysis=kernel-resource-usage]\n"
+               "x.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\n")
+    rows = B._spill_report("x.hip", remarks)
+    assert [n for _, n in rows] == [288, 64]
+    assert not B._spill_allowed(rows[0][0]) and B._spill_allowed(rows[1][0])
+    monkeypatch.setattr(B, "spill_report", lambda: {"x.hip": rows})
+    assert [v[2] for v in B.scratch_violations()] == [288]
+    monkeypatch.setattr(B, "SOURCES", [])
+    (tmp_path / "none.so").write_bytes(b"")                  # present and newer than its (zero) objects: nothing to compile or link
+    monkeypatch.setattr(B, "LIB", str(tmp_path / "none.so"))
+    with pytest.raises(B.ScratchError, match="288 B/lane"):
+        B.build(force=False, verbose=False)
