@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--force-comm-path", action="store_true", help="issue the gradient collectives even with one rank (needs an initialised process group)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=INT", help="m2t_set_option on the plan (experiments)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the whole backward on one stream")
+    ap.add_argument("--main-priority", type=int, default=None, choices=[0, -1],
+                    help="priority of the stream the step runs on (the plan's side stream inherits it).  Default: -1 (high) with the MedCLIP "
+                         "regulariser, whose encoder then runs on a normal-priority stream BEHIND the step's kernels; 0 otherwise")
     ap.add_argument("--no-overlap-semantic", action="store_true", help="SemanticLoss forward after the backward pass instead of beside it")
     ap.add_argument("--debug-skip-side", action="store_true", help="TIMING EXPERIMENT: skip all parameter-gradient kernels (wrong results)")
     ap.add_argument("--semantic-loss", action="store_true",
@@ -349,9 +352,10 @@ def run_workload(args, device, rank: int, world: int, backend, grp: dict, cpu_ba
 
     dominant_mask = 0
     # a non-default stream: the plan's side stream is a blocking stream and would serialise against the legacy default stream
+    main_priority = args.main_priority if args.main_priority is not None else (-1 if args.semantic_loss else 0)
     if not args.null_stream:
         torch.cuda.synchronize()
-        torch.cuda.set_stream(torch.cuda.Stream(device=device))
+        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=main_priority))
     events_on = rank == 0 and not args.no_kernel_events
     for s in range(args.warmup):
         if events_on and s == args.warmup - 1:
@@ -426,7 +430,7 @@ def run_workload(args, device, rank: int, world: int, backend, grp: dict, cpu_ba
         # every switch that changes the measured work or schedule is echoed, so an experiment cannot pass for a headline
         experiment = {k: v for k, v in {
             "option": args.option or None,
-            "no_side_stream": args.no_side_stream or None, "null_stream": args.null_stream or None,
+            "no_side_stream": args.no_side_stream or None, "null_stream": args.null_stream or None, "main_priority": args.main_priority,
             "no_overlap_comm": args.no_overlap_comm or None, "force_comm_path": args.force_comm_path or None,
             "all_kernel_events": args.all_kernel_events or None, "no_overlap_semantic": args.no_overlap_semantic or None, "debug_skip_side": args.debug_skip_side or None}.items() if v is not None}
         out = {
@@ -456,6 +460,7 @@ def run_workload(args, device, rank: int, world: int, backend, grp: dict, cpu_ba
                        "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                        "grad_exchange": ("none" if ts.bucket is None else
                                          ("bucketed all-reduce overlapped with backward" if ts.overlap_comm else "one all-reduce after backward")),
+                       "stream_priority": main_priority,
                        "final_loss": round(loss, 6),
                        "host_enqueue_ms_per_step": round(1000.0 * host_enqueue_s / args.steps, 3)},
             "roofline": roofline,

@@ -69,6 +69,10 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           (needs "fused_attn_fwd" >= 1; bit-identical); 0 = branch_prep launches in front of it
  *   "fused_prep_bwd"    [1] bf16: the backward of branch 4's branch_prep inside branch 3's attention backward (same level and window grid; needs
  *                           "attn_bwd" >= 2; bit-identical); 0 = a branch_prep_bwd launch between the two
+ *   "fused_norm_red"    [0] bf16 with "attn_bwd" = 3: the first reduction stage of the InstanceNorm backward (sums of g_n and g_n * xhat per image
+ *                           and channel) rides in the C = 16 prep launch -- extra workgroups for the planes of branches 2 .. 4, per-tile sums of
+ *                           plane 0 from the tiles that produce it; 0 = its own launch behind that kernel (same sums, another addition order).
+ *                           Measured 2.2 % SLOWER on the step (round 5: both roles are memory-heavy and do not overlap): off by default
  *   "wgrad_big_tiles"   [-1] qkv weight gradient of the C = 256 branches with 128 x 128 output tiles: value = target number of
  *                           workgroups (64..512), 0 = off, -1 = auto (256 from 24 576 branch pixels on, i.e. batch >= 24)
  *   "fused_tail"        [3] bf16 x4: 1 = one fused kernel for the high-resolution half of the tail backward (k_tail_bwd.hip); 2 = the same

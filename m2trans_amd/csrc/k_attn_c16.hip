@@ -17,6 +17,7 @@
 //   * LDS accesses of a wave execute in order, so wave-private buffers need no barrier at all.
 // 15 KB of LDS per wave: nothing here can starve (or be starved by) the parameter-gradient kernels.
 #include "m2t_kernels.h"
+#include "m2t_instnorm.h"
 #include "m2t_window.h"
 
 namespace {
@@ -561,10 +562,36 @@ __global__ void __launch_bounds__(256, 4) window_attn_fused_c16_fwd_kernel(const
 // same two 32-deep MFMAs the GEMM issues (k-slot = column; the second one zero beyond column 47); the tile comes back as
 // (pixel, 4 channels) per lane, is rounded like the GEMM's store, and leaves as g_n.  Bit-identical to the three kernels.
 // ---------------------------------------------------------------------------------------
+// NORM (round 5, option "fused_norm_red"): the first reduction stage of the InstanceNorm backward that follows this kernel on the main
+// chain rides in the same launch.  Workgroups 0 .. nred - 1 run instnorm_bwd_red1_body on planes 1 .. 3 of g_n (written by the three
+// earlier branches: complete) -- a bandwidth-bound role beside the issue-bound tiles, so the two overlap instead of queueing -- and
+// every tile wave leaves the sums of ITS 16 pixels of plane 0 (the values it has just produced, rounded as stored) in npart0.
+struct C16NormArgs {
+  const bf16_t* x;          // block input X, P64 (plane 0 first)
+  const float* mean;        // [B][64]
+  const float* rstd;
+  float* part;              // [B][M2T_NORM_SPLIT][64][2]   (channels 16 .. 63 written)
+  float* part0;             // [tile][2][16]
+  int nred;                 // leading workgroups in the reduction role (= B * M2T_NORM_SPLIT)
+};
+template <int N> __device__ __forceinline__ float row_ror_f(float v) {      // value of lane (i + N) mod 16 of the lane's row of 16
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+template <bool NORM>
 __global__ void __launch_bounds__(256) c16_dgrad_prep_kernel(bf16_t* __restrict__ gqkv, const bf16_t* __restrict__ win,
                                                              const bf16_t* __restrict__ wT, const bf16_t* __restrict__ gxc,
-                                                             bf16_t* __restrict__ gn, int B, int h, int w) {
+                                                             bf16_t* __restrict__ gn, int B, int h, int w, C16NormArgs na) {
   using T = bf16_t;
+  int blk = blockIdx.x, nblk = gridDim.x;
+  if constexpr (NORM) {
+    __shared__ float sh[256][8][2];
+    if (blk < na.nred) {                                    // workgroup-uniform
+      instnorm_bwd_red1_body<T, 2, 6>(gn, na.x, na.mean, na.rstd, na.part, h * w, M2T_NORM_SPLIT, blk / M2T_NORM_SPLIT, blk % M2T_NORM_SPLIT, B, sh);
+      return;
+    }
+    blk -= na.nred;
+    nblk -= na.nred;
+  }
   const int lane = threadIdx.x & 63, lr = lane & 15, g = lane >> 4;
   const int tpr = w / 16;                             // tiles per image row
   const int ntile = B * h * tpr;
@@ -576,7 +603,7 @@ __global__ void __launch_bounds__(256) c16_dgrad_prep_kernel(bf16_t* __restrict_
   // (dV; lanes g >= 2 load it too -- no divergent loads -- and drop it)
   const int col0 = 8 * g, col1 = 32 + 8 * (g & 1);
   const int ring0 = g >= 2 ? 8 * (g - 2) : 0, ring1 = 16 + 8 * (g & 1);        // the pieces' columns inside a ring row [dK | dV]
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
+  const int wave = (blk * blockDim.x + threadIdx.x) >> 6, nwave = (nblk * blockDim.x) >> 6;
   for (int t = wave; t < ntile; t += nwave) {
     const int tx = t % tpr, y = (t / tpr) % h, b = t / (tpr * h);
     const int x = 16 * tx + lr;
@@ -587,6 +614,12 @@ __global__ void __launch_bounds__(256) c16_dgrad_prep_kernel(bf16_t* __restrict_
     float a0[8], a1[8], r0[3][8], r1[3][8], px4[4];
     load8f(row + col0, a0);
     load8f(row + col1, a1);
+    float xv[4], mu4[4], rs4[4];
+    if constexpr (NORM) {                                   // (issued with the other loads of the tile)
+      load4(na.x + pix * 16 + 4 * g, xv);
+      *reinterpret_cast<f32x4*>(mu4) = *reinterpret_cast<const f32x4*>(na.mean + b * 64 + 4 * g);
+      *reinterpret_cast<f32x4*>(rs4) = *reinterpret_cast<const f32x4*>(na.rstd + b * 64 + 4 * g);
+    }
     // unconditional loads from a clamped source, selected below.  Only a corner pixel has a second and third source, and corners lie
     // on the first / last row of a window: the wave's row decides (uniformly) whether those four loads are issued at all
     const int wy = y >> 3, py = y & 7;
@@ -630,6 +663,28 @@ __global__ void __launch_bounds__(256) c16_dgrad_prep_kernel(bf16_t* __restrict_
 #pragma unroll
     for (int r = 0; r < 4; ++r) o4[r] = to_f(from_f<T>(acc[r])) + px4[r];     // g_d is a stored bf16 tensor in the unfused chain
     store4(gn + pix * 16 + 4 * g, o4);
+    if constexpr (NORM) {
+      // s1 / s2 of the tile's 16 pixels for the lane's four channels: the stored (rounded) g_n, the operations of instnorm_bwd_red1_body,
+      // then a fixed rotation tree over the 16 pixel lanes of the row (every lane ends with the total)
+      float a1v[4], a2v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gq = to_f(from_f<T>(o4[r]));
+        a1v[r] = gq;
+        a2v[r] = gq * ((xv[r] - mu4[r]) * rs4[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a1v[r] += row_ror_f<8>(a1v[r]); a2v[r] += row_ror_f<8>(a2v[r]);
+        a1v[r] += row_ror_f<4>(a1v[r]); a2v[r] += row_ror_f<4>(a2v[r]);
+        a1v[r] += row_ror_f<2>(a1v[r]); a2v[r] += row_ror_f<2>(a2v[r]);
+        a1v[r] += row_ror_f<1>(a1v[r]); a2v[r] += row_ror_f<1>(a2v[r]);
+      }
+      if (lr == 0) {
+        *reinterpret_cast<f32x4*>(na.part0 + (long long)t * 32 + 4 * g) = (f32x4){a1v[0], a1v[1], a1v[2], a1v[3]};
+        *reinterpret_cast<f32x4*>(na.part0 + (long long)t * 32 + 16 + 4 * g) = (f32x4){a2v[0], a2v[1], a2v[2], a2v[3]};
+      }
+    }
   }
 }
 
@@ -649,13 +704,23 @@ int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float*
 
 // gqkv [B*h*w][48] (dK|dV of border pixels completed in place), win [window][36][32], wT = Wqkv^T [16][48] (M2T_PACK_TRANSPOSE),
 // gxc / gn: chunk 0 planes [B*h*w][16] of the P64 gradients.  w % 16 == 0.
-int launch_c16_dgrad_prep(void* gqkv, const void* win, const void* wT, const void* gxc, void* gn, int B, int h, int w, hipStream_t st) {
+int launch_c16_dgrad_prep(void* gqkv, const void* win, const void* wT, const void* gxc, void* gn, int B, int h, int w, hipStream_t st,
+                          const void* nx, const float* mean, const float* rstd, float* npart, float* npart0) {
   if (h % 8 || w % 16) return m2t_set_error(-2, "c16_dgrad_prep: h % 8, w % 16");
   const long long ntile = (long long)B * h * (w / 16);
   if (ntile * 16 * 48 >= (1LL << 31)) return m2t_set_error(-2, "c16_dgrad_prep: too many pixels for 32-bit tile indexing");
   const int grid = (int)std::min<long long>((ntile + 3) / 4, 4096);
-  M2T_LAUNCH_TIMED(c16_dgrad_prep_kernel, dim3(grid), dim3(256), 0, st, (bf16_t*)gqkv, (const bf16_t*)win, (const bf16_t*)wT,
-                     (const bf16_t*)gxc, (bf16_t*)gn, B, h, w);
+  C16NormArgs na{};
+  if (nx) {
+    if (!mean || !rstd || !npart || !npart0) return m2t_set_error(-2, "c16_dgrad_prep: the norm reduction needs mean, rstd and both partial buffers");
+    na.x = (const bf16_t*)nx; na.mean = mean; na.rstd = rstd; na.part = npart; na.part0 = npart0; na.nred = B * M2T_NORM_SPLIT;
+    // the reduction workgroups come FIRST in the grid: they are the long bandwidth-bound ones, the tiles fill in around them
+    M2T_LAUNCH_TIMED(c16_dgrad_prep_kernel<true>, dim3(grid + na.nred), dim3(256), 0, st, (bf16_t*)gqkv, (const bf16_t*)win, (const bf16_t*)wT,
+                     (const bf16_t*)gxc, (bf16_t*)gn, B, h, w, na);
+  } else {
+    M2T_LAUNCH_TIMED(c16_dgrad_prep_kernel<false>, dim3(grid), dim3(256), 0, st, (bf16_t*)gqkv, (const bf16_t*)win, (const bf16_t*)wT,
+                     (const bf16_t*)gxc, (bf16_t*)gn, B, h, w, na);
+  }
   M2T_LAUNCH_CHECK();
   return 0;
 }

@@ -16,6 +16,7 @@
 #include "m2t_window.h"
 #include "m2t_gemm_load.h"
 #include "m2t_haar.h"
+#include "m2t_instnorm.h"
 
 // =======================================================================================
 // generic L-level DWT / IWT on an NHWC tensor slice (operator API + bit-exact tests)
@@ -759,47 +760,9 @@ template <typename T>
 __global__ void __launch_bounds__(256) instnorm_bwd_red1_kernel(const T* __restrict__ gn, const T* __restrict__ x,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 float* __restrict__ part, int P, int nsplit) {
-  // part [B][nsplit][64][2]
-  const int b = blockIdx.y, sp = blockIdx.x;
-  const long long npix = (long long)gridDim.y * P;          // gn, x are P64
-  const int cgp = threadIdx.x & 7, pl = threadIdx.x >> 3;
-  const int per = ceil_div(P, nsplit);
-  const int p0 = sp * per, p1 = min(P, p0 + per);
-  float mu[8], rs[8], s1[8], s2[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) { mu[c] = mean[b * 64 + cgp * 8 + c]; rs[c] = rstd[b * 64 + cgp * 8 + c]; s1[c] = 0.f; s2[c] = 0.f; }
-  // four pixels per trip: eight 16-byte loads in flight per lane before the first use
-  int p = p0 + pl;
-  for (; p + 96 < p1; p += 128) {
-    float g[4][8], v[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      load8f(gn + p64(npix, (long long)b * P + p + 32 * i, cgp * 8), g[i]);
-      load8f(x + p64(npix, (long long)b * P + p + 32 * i, cgp * 8), v[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { s1[c] += g[i][c]; s2[c] += g[i][c] * ((v[i][c] - mu[c]) * rs[c]); }
-  }
-  for (; p < p1; p += 32) {
-    float g[8], v[8];
-    load8f(gn + p64(npix, (long long)b * P + p, cgp * 8), g);
-    load8f(x + p64(npix, (long long)b * P + p, cgp * 8), v);
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { s1[c] += g[c]; s2[c] += g[c] * ((v[c] - mu[c]) * rs[c]); }
-  }
+  // part [B][nsplit][64][2]; the body is shared with c16_dgrad_prep_kernel (m2t_instnorm.h)
   __shared__ float sh[256][8][2];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) { sh[threadIdx.x][c][0] = s1[c]; sh[threadIdx.x][c][1] = s2[c]; }
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int ch = threadIdx.x, g = ch >> 3, c = ch & 7;
-    float a1 = 0.f, a2 = 0.f;
-    for (int l = 0; l < 32; ++l) { a1 += sh[l * 8 + g][c][0]; a2 += sh[l * 8 + g][c][1]; }
-    float* o = part + (((long long)b * nsplit + sp) * 64 + ch) * 2;
-    o[0] = a1; o[1] = a2;
-  }
+  instnorm_bwd_red1_body<T, 0, 8>(gn, x, mean, rstd, part, P, nsplit, blockIdx.y, blockIdx.x, gridDim.y, sh);
 }
 __global__ void __launch_bounds__(64) instnorm_bwd_red2_kernel(const float* __restrict__ part, float* __restrict__ s, int nsplit, float invP) {
   // all 32 partials of a channel are fetched before the first add (one round trip instead of four dependent ones:
@@ -818,43 +781,108 @@ __global__ void __launch_bounds__(64) instnorm_bwd_red2_kernel(const float* __re
   s[(b * 64 + ch) * 2 + 0] = v[0].x * invP;
   s[(b * 64 + ch) * 2 + 1] = v[0].y * invP;
 }
-template <typename T>
+// Second stage when the first one ran inside c16_dgrad_prep_kernel (round 5, option "fused_norm_red"): channels 16 .. 63 come as the
+// usual M2T_NORM_SPLIT partials (that kernel's extra workgroups), channels 0 .. 15 as one partial PER 16-PIXEL TILE of the plane-0
+// producer, part0 [tile][2][16] with the image's tiles contiguous.  One workgroup per image; fixed orders throughout.
+__global__ void __launch_bounds__(256) instnorm_bwd_red2x_kernel(const float* __restrict__ part, const float* __restrict__ part0,
+                                                                 float* __restrict__ s, int nsplit, int tiles, float invP) {
+  static_assert(M2T_NORM_SPLIT == 32, "the fixed tree below is written for 32 partials");
+  __shared__ float sl[8][32];
+  const int b = blockIdx.x, t = threadIdx.x;
+  {
+    const int v = t & 31, slice = t >> 5;                     // value v = which * 16 + channel; slice of the image's tiles
+    const float* o = part0 + (long long)b * tiles * 32 + v;
+    float a = 0.f;
+    int i = slice;
+    for (; i + 56 < tiles; i += 64) {                          // eight loads in flight, added in tile order
+      float q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = o[(long long)(i + 8 * u) * 32];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += q[u];
+    }
+    for (; i < tiles; i += 8) a += o[(long long)i * 32];
+    sl[slice][v] = a;
+  }
+  __syncthreads();
+  if (t < 32) {
+    float a = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += sl[u][t];
+    s[(b * 64 + (t & 15)) * 2 + (t >> 4)] = a * invP;
+  } else if (t >= 64 && t < 64 + 48) {
+    const int ch = 16 + (t - 64);
+    const float* o = part + ((long long)b * nsplit * 64 + ch) * 2;
+    float2 v[M2T_NORM_SPLIT];
+#pragma unroll
+    for (int q = 0; q < M2T_NORM_SPLIT; ++q)
+      v[q] = (q < nsplit) ? *reinterpret_cast<const float2*>(o + (long long)q * 128) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int st = 1; st < M2T_NORM_SPLIT; st <<= 1)
+#pragma unroll
+      for (int q = 0; q < M2T_NORM_SPLIT; q += 2 * st) { v[q].x += v[q + st].x; v[q].y += v[q + st].y; }
+    s[(b * 64 + ch) * 2 + 0] = v[0].x * invP;
+    s[(b * 64 + ch) * 2 + 1] = v[0].y * invP;
+  }
+}
+// gres2 != nullptr (block 0): a second residual gradient joins in the same pass -- g(res) = g(X0) + g(Y) of `res + x`
+// (models/M2Trans_network.py:70), which used to be an add_kernel launch of its own behind the last block (round 5)
+// (R2 is a template argument: a load under a run-time branch -- even a uniform one -- is followed by s_waitcnt vmcnt(0), which cost
+//  every launch 7 us when the second residual was a nullable pointer)
+template <typename T, bool R2>
 __global__ void __launch_bounds__(256) instnorm_bwd_apply_kernel(const T* __restrict__ gn, const T* __restrict__ x,
                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                  const float* __restrict__ s, const T* __restrict__ gres,
-                                                                 T* __restrict__ gx, int B, int P) {
+                                                                 T* __restrict__ gx, int B, int P, const T* __restrict__ gres2) {
   const int total = B * P * 8;                    // < 2^31 (checked by the launcher): 32-bit index math
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
     const int cgp = t & 7;
     const int pix = t >> 3;
     const int b = pix / P;
-    float g[8], v[8], r[8];
-    const long long o64 = p64((long long)B * P, pix, cgp * 8);     // all four tensors are P64
+    float g[8], v[8], r[8], r2[8];
+    const long long o64 = p64((long long)B * P, pix, cgp * 8);     // all tensors are P64
     load8f(gn + o64, g);
     load8f(x + o64, v);
     load8f(gres + o64, r);
+    if constexpr (R2) load8f(gres2 + o64, r2);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int ch = b * 64 + cgp * 8 + c;
       const float rs = rstd[ch];
       const float xh = (v[c] - mean[ch]) * rs;
       r[c] += rs * (g[c] - s[ch * 2] - xh * s[ch * 2 + 1]);
+      // (the unfused chain stored this sum in T before the add: the same rounding point is kept, so the bits are the add_kernel's)
+      if constexpr (R2) r[c] = to_f(from_f<T>(r[c])) + r2[c];
     }
     store8f(gx + o64, r);
   }
 }
+// part0 != nullptr (bf16): the first stage already ran (c16_dgrad_prep_kernel with its norm arguments): `part` holds channels 16 .. 63,
+// part0 [B * tiles0][2][16] the per-tile partials of channels 0 .. 15 (tiles0 tiles per image)
 int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean, const float* rstd, const void* gres,
-                        void* gx, float* part, float* s, int B, int P, hipStream_t st) {
+                        void* gx, float* part, float* s, int B, int P, hipStream_t st, const float* part0, int tiles0, const void* gres2) {
   if ((long long)B * P * 8 >= (1LL << 31)) return m2t_set_error(-2, "instnorm_bwd: B*P too large for 32-bit indexing");
   const int nsplit = M2T_NORM_SPLIT;
+  if (part0) {
+    if (dt == M2T_F32 || tiles0 < 1) return m2t_set_error(-2, "instnorm_bwd: pre-reduced partials are a bf16 path");
+    hipLaunchKernelGGL(instnorm_bwd_red2x_kernel, dim3(B), dim3(256), 0, st, (const float*)part, part0, s, nsplit, tiles0, 1.0f / (float)P);
+    M2T_LAUNCH_CHECK();
+    const int g = grid_for((long long)B * P * 8);
+    if (gres2) hipLaunchKernelGGL((instnorm_bwd_apply_kernel<bf16_t, true>), dim3(g), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, s, (const bf16_t*)gres, (bf16_t*)gx, B, P, (const bf16_t*)gres2);
+    else hipLaunchKernelGGL((instnorm_bwd_apply_kernel<bf16_t, false>), dim3(g), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, s, (const bf16_t*)gres, (bf16_t*)gx, B, P, (const bf16_t*)nullptr);
+    M2T_LAUNCH_CHECK();
+    return 0;
+  }
   if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_red1_kernel<float>, dim3(nsplit, B), dim3(256), 0, st, (const float*)gn, (const float*)x, mean, rstd, part, P, nsplit);
   else hipLaunchKernelGGL(instnorm_bwd_red1_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, part, P, nsplit);
   M2T_LAUNCH_CHECK();
   hipLaunchKernelGGL(instnorm_bwd_red2_kernel, dim3(B), dim3(64), 0, st, part, s, nsplit, 1.0f / (float)P);
   M2T_LAUNCH_CHECK();
   const int g = grid_for((long long)B * P * 8);
-  if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)gn, (const float*)x, mean, rstd, s, (const float*)gres, (float*)gx, B, P);
-  else hipLaunchKernelGGL(instnorm_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, s, (const bf16_t*)gres, (bf16_t*)gx, B, P);
+#define M2T_APPLY(T_, R2_) hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T_, R2_>), dim3(g), dim3(256), 0, st, (const T_*)gn, (const T_*)x, mean, rstd, s, (const T_*)gres, (T_*)gx, B, P, (const T_*)gres2)
+  if (dt == M2T_F32) { if (gres2) M2T_APPLY(float, true); else M2T_APPLY(float, false); }
+  else { if (gres2) M2T_APPLY(bf16_t, true); else M2T_APPLY(bf16_t, false); }
+#undef M2T_APPLY
   M2T_LAUNCH_CHECK();
   return 0;
 }
@@ -1197,66 +1225,97 @@ int launch_adam(float* p, const float* g, float* m, float* v, long long n, float
 // weight packer: ONE launch converts every fp32 master tensor into the element type and
 // layouts the kernels want, driven by a descriptor table built at plan creation.
 // =======================================================================================
+// source index of packed element e of descriptor d (the layouts are documented in m2t_kernels.h)
+__device__ __forceinline__ long long pack_src_index(const m2t_pack_desc& d, int e) {
+  switch (d.kind) {
+    case M2T_PACK_COPY: return e;
+    case M2T_PACK_TRANSPOSE: {        // src [d0][d1] -> dst [d1][d0]
+      const int r = e / d.d0, c = e % d.d0;   // dst row r (0..d1), col c (0..d0)
+      return (long long)c * d.d1 + r;
+    }
+    case M2T_PACK_CONV3: {            // src [O=d0][I=d1][9] -> dst [tap][O][I]
+      const int i = e % d.d1; const int oo = (e / d.d1) % d.d0; const int tap = e / (d.d0 * d.d1);
+      return ((long long)oo * d.d1 + i) * 9 + tap;
+    }
+    case M2T_PACK_CONV3_T: {          // src [O=d0][I=d1][9] -> dst [tap'][I][O], tap' = 8 - tap (flipped kernel)
+      const int oo = e % d.d0; const int i = (e / d.d0) % d.d1; const int tp = e / (d.d0 * d.d1);
+      return ((long long)oo * d.d1 + i) * 9 + (8 - tp);
+    }
+    case M2T_PACK_SHUF_ROWS: {        // src [C*rr][K=d2] (row c*rr+sub) -> dst [sub*C + c][K]; d0 = C, d1 = rr
+      const int kk = e % d.d2; const int np = e / d.d2;
+      const int sub = np / d.d0, c = np % d.d0;
+      return ((long long)c * d.d1 + sub) * d.d2 + kk;
+    }
+    case M2T_PACK_SHUF_ROWS_T: {      // src [C*rr][K] -> dst [K][sub*C + c]
+      const int np = e % (d.d0 * d.d1); const int kk = e / (d.d0 * d.d1);
+      const int sub = np / d.d0, c = np % d.d0;
+      return ((long long)c * d.d1 + sub) * d.d2 + kk;
+    }
+    case M2T_PACK_FRAG16: {           // src [N=d0][K=d1] -> [N/16][K/32][64][8] (see m2t_kernels.h)
+      const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
+      const int nks = d.d1 >> 5;
+      const int ks = f % nks, tile = f / nks;
+      return (long long)(16 * tile + (l & 15)) * d.d1 + 32 * ks + 8 * (l >> 4) + j;
+    }
+    case M2T_PACK_CONV3_ROWS:         // src torch [O=64][I=64][3][3] -> the A-fragments of conv3x3_c64_rows_kernel (k_conv.hip):
+    case M2T_PACK_CONV3_ROWS_T: {     // [tap][half][kc][nt][64 lanes][8]; _T: the data-gradient weights (flipped taps, O <-> I)
+      const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
+      const int nt = f & 1, kc = (f >> 1) & 1, h = (f >> 2) & 1, tap = f >> 3;
+      const int row = 32 * h + 8 * ((l & 15) >> 2) + 4 * nt + (l & 3);     // output channel of the product
+      const int k = 32 * kc + 8 * (l >> 4) + j;                             // contraction channel
+      return (d.kind == M2T_PACK_CONV3_ROWS) ? ((long long)row * 64 + k) * 9 + tap : ((long long)k * 64 + row) * 9 + (8 - tap);
+    }
+    case M2T_PACK_FRAG16_T: {         // src [K=d1][N=d0] -> fragments of the transpose [N/16][K/32][64][8]
+      const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
+      const int nks = d.d1 >> 5;
+      const int ks = f % nks, tile = f / nks;
+      return (long long)(32 * ks + 8 * (l >> 4) + j) * d.d0 + 16 * tile + (l & 15);
+    }
+  }
+  return e;
+}
+// Eight CONSECUTIVE packed elements whose index differs only in the innermost packed dimension come from source elements a fixed
+// stride apart; returns that stride, or 0 when the descriptor's innermost dimension is not a multiple of 8 (element-wise path).
+__device__ __forceinline__ long long pack_run_stride(const m2t_pack_desc& d) {
+  switch (d.kind) {
+    case M2T_PACK_COPY: return 1;
+    case M2T_PACK_TRANSPOSE: return (d.d0 % 8 == 0) ? d.d1 : 0;
+    case M2T_PACK_CONV3: return (d.d1 % 8 == 0) ? 9 : 0;
+    case M2T_PACK_CONV3_T: return (d.d0 % 8 == 0) ? (long long)d.d1 * 9 : 0;
+    case M2T_PACK_SHUF_ROWS: return (d.d2 % 8 == 0) ? 1 : 0;
+    case M2T_PACK_SHUF_ROWS_T: return (d.d0 % 8 == 0) ? (long long)d.d1 * d.d2 : 0;
+    case M2T_PACK_FRAG16: return 1;
+    case M2T_PACK_CONV3_ROWS: return 9;
+    case M2T_PACK_CONV3_ROWS_T: return 64 * 9;
+    case M2T_PACK_FRAG16_T: return d.d0;
+  }
+  return 0;
+}
 template <typename T>
 __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ master, T* __restrict__ packed,
                                                    const m2t_pack_desc* __restrict__ descs, const int2* __restrict__ blocks) {
   // one workgroup per M2T_PACK_CHUNK output elements: blocks[i] = (descriptor, chunk).  (16 workgroups per descriptor --
   // 48 dependent gathers per thread on the 196 608-element attention weights -- took 98 us at the head of every step)
+  // Round 5: a thread converts EIGHT consecutive packed elements -- one index decomposition (the divisions by run-time extents were
+  // most of the kernel's instructions), eight strided source loads, one 16-byte (bf16) store: 35.7 -> ~12 us at the head of the step.
   const int2 bk = blocks[blockIdx.x];
   const m2t_pack_desc d = descs[bk.x];
   const float* s = master + d.src_off;
   T* o = packed + d.dst_off;
   const int n = (int)d.n;                  // every packed tensor has < 2^31 elements: 32-bit index math (64-bit division is a software loop)
   const int e0 = bk.y * M2T_PACK_CHUNK, e1 = min(n, e0 + M2T_PACK_CHUNK);
-  for (int e = e0 + threadIdx.x; e < e1; e += 256) {
-    long long si = e;
-    switch (d.kind) {
-      case M2T_PACK_COPY: break;
-      case M2T_PACK_TRANSPOSE: {        // src [d0][d1] -> dst [d1][d0]
-        const int r = e / d.d0, c = e % d.d0;   // dst row r (0..d1), col c (0..d0)
-        si = (long long)c * d.d1 + r;
-      } break;
-      case M2T_PACK_CONV3: {            // src [O=d0][I=d1][9] -> dst [tap][O][I]
-        const int i = e % d.d1; const int oo = (e / d.d1) % d.d0; const int tap = e / (d.d0 * d.d1);
-        si = ((long long)oo * d.d1 + i) * 9 + tap;
-      } break;
-      case M2T_PACK_CONV3_T: {          // src [O=d0][I=d1][9] -> dst [tap'][I][O], tap' = 8 - tap (flipped kernel)
-        const int oo = e % d.d0; const int i = (e / d.d0) % d.d1; const int tp = e / (d.d0 * d.d1);
-        si = ((long long)oo * d.d1 + i) * 9 + (8 - tp);
-      } break;
-      case M2T_PACK_SHUF_ROWS: {        // src [C*rr][K=d2] (row c*rr+sub) -> dst [sub*C + c][K]; d0 = C, d1 = rr
-        const int kk = e % d.d2; const int np = e / d.d2;
-        const int sub = np / d.d0, c = np % d.d0;
-        si = ((long long)c * d.d1 + sub) * d.d2 + kk;
-      } break;
-      case M2T_PACK_SHUF_ROWS_T: {      // src [C*rr][K] -> dst [K][sub*C + c]
-        const int np = e % (d.d0 * d.d1); const int kk = e / (d.d0 * d.d1);
-        const int sub = np / d.d0, c = np % d.d0;
-        si = ((long long)c * d.d1 + sub) * d.d2 + kk;
-      } break;
-      case M2T_PACK_FRAG16: {           // src [N=d0][K=d1] -> [N/16][K/32][64][8] (see m2t_kernels.h)
-        const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
-        const int nks = d.d1 >> 5;
-        const int ks = f % nks, tile = f / nks;
-        si = (long long)(16 * tile + (l & 15)) * d.d1 + 32 * ks + 8 * (l >> 4) + j;
-      } break;
-      case M2T_PACK_CONV3_ROWS:         // src torch [O=64][I=64][3][3] -> the A-fragments of conv3x3_c64_rows_kernel (k_conv.hip):
-      case M2T_PACK_CONV3_ROWS_T: {     // [tap][half][kc][nt][64 lanes][8]; _T: the data-gradient weights (flipped taps, O <-> I)
-        const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
-        const int nt = f & 1, kc = (f >> 1) & 1, h = (f >> 2) & 1, tap = f >> 3;
-        const int row = 32 * h + 8 * ((l & 15) >> 2) + 4 * nt + (l & 3);     // output channel of the product
-        const int k = 32 * kc + 8 * (l >> 4) + j;                             // contraction channel
-        si = (d.kind == M2T_PACK_CONV3_ROWS) ? ((long long)row * 64 + k) * 9 + tap : ((long long)k * 64 + row) * 9 + (8 - tap);
-      } break;
-      case M2T_PACK_FRAG16_T: {         // src [K=d1][N=d0] -> fragments of the transpose [N/16][K/32][64][8]
-        const int j = e & 7, l = (e >> 3) & 63, f = e >> 9;
-        const int nks = d.d1 >> 5;
-        const int ks = f % nks, tile = f / nks;
-        si = (long long)(32 * ks + 8 * (l >> 4) + j) * d.d0 + 16 * tile + (l & 15);
-      } break;
+  const long long stride = pack_run_stride(d);
+  if (stride != 0 && (n & 7) == 0 && ((d.dst_off * sizeof(T)) & 15) == 0) {
+    for (int e = e0 + 8 * threadIdx.x; e < e1; e += 8 * 256) {
+      const float* sp = s + pack_src_index(d, e);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = sp[j * stride];
+      store8f(o + e, v);
     }
-    o[e] = from_f<T>(s[si]);
+    return;
   }
+  for (int e = e0 + threadIdx.x; e < e1; e += 256) o[e] = from_f<T>(s[pack_src_index(d, e)]);
 }
 int launch_pack(int dt, const float* master, void* packed, const m2t_pack_desc* descs, const void* blocks, int nblocks, hipStream_t st) {
   if (dt == M2T_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(nblocks), dim3(256), 0, st, master, (float*)packed, descs, (const int2*)blocks);

@@ -152,7 +152,12 @@ struct m2t_plan {
   std::map<std::string, WsTensor> ws;
   size_t ws_bytes = 0;
   std::vector<m2t_pack_desc> descs;
-  std::vector<int> pack_blocks;              // (descriptor, chunk) pairs: one workgroup of the packing kernel each
+  std::vector<char> desc_is_qkv;             // per descriptor: a packed form of a qkv_conv.weight
+  std::vector<int> pack_blocks;              // (descriptor, chunk) pairs: one workgroup of the packing kernel each.  Order: every
+                                             // descriptor that is always needed, then the plain copies of the C >= 64 qkv weights (read only by the
+                                             // unfused forward GEMM), then their transposes (read only by the unfused data-gradient GEMM)
+  int pack_nb_base = 0, pack_nb_copy = 0, pack_nb_tr = 0;   // workgroups of the three groups (round 5: the default bf16 path skips the last two:
+                                             // 6.3 M of the 14.2 M packed elements, the transposes being the slowest gathers of the kernel)
   std::map<std::string, long long> pk;       // packed weight offsets (elements of T)
   long long npacked = 0;
   bool have_seed = false, have_acts = false;
@@ -168,6 +173,8 @@ struct m2t_plan {
                                        // with the erf form of round 2 it was 1 % slower)
   int use_fused_prep_bwd = 1;          // bf16: branch_prep_bwd of branch 4 inside the attention backward of branch 3 (round 4)
   int use_fused_prep_fwd = 1;          // bf16 C = 64 / 256 branches: branch_prep inside the fused forward attention kernel (round 4)
+  int use_fused_norm_red = 0;          // bf16 with the C = 16 prep kernel: the first stage of the InstanceNorm backward reduction rides in that launch (round 5;
+                                       // measured SLOWER, -2.2 % on the step: both roles are memory-heavy, profiles/README.md -- kept for A/B)
   int fork_on_kernel = 1;              // a fork event rides on the dispatch it follows (its stop event) instead of a marker packet behind it:
                                        // same-box A/B 4.757 -> 4.726 ms (config 1), 8.536 -> 8.469 (config 3); not under stream capture
   int gate_branch = -1;                // side-stream gate: -1 ungated (a branch's side work follows its attention launch), else the branch (3..0)
@@ -202,10 +209,14 @@ struct m2t_plan {
   std::vector<std::pair<long long, long long>> buckets;
   std::vector<hipEvent_t> bucket_events;
   std::vector<hipEvent_t> events;
-  int ensure_side(hipStream_t) {
+  int ensure_side(hipStream_t caller) {
     if (side) return 0;
-    // (a CU-masked side stream and stream priorities were both measured and are slower: profiles/README.md, round 2)
-    if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return -1;
+    // (a CU-masked side stream and a side stream of LOWER priority than the caller's were both measured and are slower: profiles/README.md,
+    //  round 2.)  The side stream takes the CALLER'S priority: a caller that runs the step on a high-priority stream beside other work of
+    //  its own (the MedCLIP encoder of configs[2] on a normal-priority stream, round 5) gets both halves of the backward pass ahead of it
+    int prio = 0;
+    if (hipStreamGetPriority(caller, &prio) != hipSuccess) prio = 0;
+    if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio) != hipSuccess) return -1;
     events.resize(192);
     for (auto& e : events)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
@@ -232,6 +243,7 @@ struct m2t_plan {
     m2t_pack_desc d;
     d.src_off = poff.at(src); d.dst_off = npacked; d.n = cnt; d.kind = kind; d.d0 = d0; d.d1 = d1; d.d2 = d2;
     descs.push_back(d);
+    desc_is_qkv.push_back(src.find("qkv_conv.weight") != std::string::npos ? 1 : 0);
     pk[n] = npacked;
     npacked += cnt;
     return pk[n];
@@ -311,8 +323,16 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   const long long BP = (long long)B * p->P;
   p->add_ws("zero_page", 256, 1);          // source of every out-of-image pixel the LDS-DMA kernels stage (k_conv.hip)
   p->add_ws("pack_descs", p->descs.size() * sizeof(m2t_pack_desc), 1);
-  for (size_t i = 0; i < p->descs.size(); ++i)
-    for (long long c = 0; c * M2T_PACK_CHUNK < p->descs[i].n; ++c) { p->pack_blocks.push_back((int)i); p->pack_blocks.push_back((int)c); }
+  for (int group = 0; group < 3; ++group) {
+    int nb_g = 0;
+    for (size_t i = 0; i < p->descs.size(); ++i) {
+      const bool big = p->descs[i].n >= 3LL * 64 * 64 && (p->descs[i].kind == M2T_PACK_COPY || p->descs[i].kind == M2T_PACK_TRANSPOSE) && p->desc_is_qkv[i];
+      const int gi = !big ? 0 : (p->descs[i].kind == M2T_PACK_COPY ? 1 : 2);
+      if (gi != group) continue;
+      for (long long c = 0; c * M2T_PACK_CHUNK < p->descs[i].n; ++c) { p->pack_blocks.push_back((int)i); p->pack_blocks.push_back((int)c); ++nb_g; }
+    }
+    (group == 0 ? p->pack_nb_base : (group == 1 ? p->pack_nb_copy : p->pack_nb_tr)) = nb_g;
+  }
   p->add_ws("pack_blocks", p->pack_blocks.size() * sizeof(int), 1);
   p->add_ws("packed", p->npacked, es);
   for (int b = 0; b <= n_blocks; ++b) p->add_ws("X" + std::to_string(b), BP * 64, es);
@@ -330,6 +350,7 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("a", BP * 16, es);
   p->add_ws("norm_part", (size_t)B * 8 * M2T_NORM_SPLIT * 64 * 3, 4);      // (the conv epilogue leaves up to 256 partials per image)
   p->add_ws("norm_s", (size_t)B * 64 * 2, 4);
+  p->add_ws("norm_part0", (size_t)B * p->H * (p->W / 16) * 32, 4);      // per-tile plane-0 partials of the InstanceNorm backward (fused_norm_red)
   const int r0 = (s == 4) ? 2 : s;
   // tail activations: gelu(t) and gelu'(t) of each expansion (the pre-activation t itself is never needed again)
   p->add_ws("t1act", BP * r0 * r0 * 64, es);
@@ -420,6 +441,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "side_stream") return p->use_side;
     // (the EFFECTIVE state, like the keys below: an option whose precondition is off did not run)
     if (o == "fork_on_kernel") return p->use_side && p->fork_on_kernel;
+    if (o == "fused_norm_red") return p->dt != M2T_F32 && p->use_resident_attn_bwd && p->use_fused_qkv_dgrad && p->use_c16_prep && p->use_fused_norm_red;
     if (o == "fused_prep_fwd") return p->dt != M2T_F32 && p->use_fused_attn_fwd != 0 && p->use_fused_prep_fwd;
     if (o == "fused_prep_bwd") return p->dt != M2T_F32 && p->use_resident_attn_bwd && p->use_fused_qkv_dgrad && p->use_fused_prep_bwd;
     if (o == "gate_branch") return p->gate_branch + 1000;      // (offset: -1 is the "unknown key" value of this function)
@@ -475,7 +497,18 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
   const long long BP = (long long)B * p->P;
   (void)keep_activations;   // v1 keeps every activation in the workspace either way
   // (re-packing on the side stream under the head conv was measured: -0.4 %, both kernels are bound by workgroup launch rate)
-  CK(launch_pack(dt, params, WSP("packed"), (const m2t_pack_desc*)WSP("pack_descs"), WSP("pack_blocks"), (int)(p->pack_blocks.size() / 2), st));
+  {
+    // the plain / transposed copies of the C >= 64 qkv weights are read only by the unfused projection GEMMs (forward / data gradient):
+    // with the fused attention kernels in force (the bf16 default) they are not packed.  A change of either option invalidates the
+    // activations (m2t_set_option), so the backward pass always meets the packs of the options it runs under
+    const bool need_copy = dt == M2T_F32 || p->use_fused_attn_fwd == 0;
+    const bool need_tr = dt == M2T_F32 || !(p->use_fused_qkv_dgrad && p->use_resident_attn_bwd);
+    const char* blocks = (const char*)WSP("pack_blocks");
+    const int n0 = p->pack_nb_base + (need_copy ? p->pack_nb_copy : 0) + ((need_copy && need_tr) ? p->pack_nb_tr : 0);
+    CK(launch_pack(dt, params, WSP("packed"), (const m2t_pack_desc*)WSP("pack_descs"), blocks, n0, st));
+    if (need_tr && !need_copy)
+      CK(launch_pack(dt, params, WSP("packed"), (const m2t_pack_desc*)WSP("pack_descs"), blocks + (size_t)(p->pack_nb_base + p->pack_nb_copy) * 2 * sizeof(int), p->pack_nb_tr, st));
+  }
   CK(launch_head_conv_fwd(dt, x, params + p->poff.at("head.weight"), params + p->poff.at("head.bias"), WSP("X0"), B,
                           p->H0, p->W0, H, W, st));
   int stat_partials = 0;
@@ -838,6 +871,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
     void* xc = WSP(k + "xc");
     void* gxc = WSP("gxc");
     void* gn = WSP("gn");
+    bool norm_prered = false;                  // the InstanceNorm backward's first reduction stage rode in the C = 16 prep launch
     void* gy_blk = gy;
     void** gqkv_buf = gqkv_sets[b & 1]; float** relw_buf = relw_sets[b & 1]; void** win_buf = win_sets[b & 1];
     main_wait(block_done[b & 1]);              // the side consumers of this buffer set (block b + 2) are done
@@ -972,7 +1006,13 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st, WSP("gdwin")));
       } else if (c16_prep) {
         if (!gated) arm_fork();
-        CK(launch_c16_dgrad_prep(gqkv, win, packed_ptr(p, workspace, k + "w1T"), gxc, gn, B, H, W, st));
+        if (p->use_fused_norm_red) {
+          CK(launch_c16_dgrad_prep(gqkv, win, packed_ptr(p, workspace, k + "w1T"), gxc, gn, B, H, W, st, X, mean, rstd,
+                                   (float*)WSP("norm_part"), (float*)WSP("norm_part0")));
+          norm_prered = true;
+        } else {
+          CK(launch_c16_dgrad_prep(gqkv, win, packed_ptr(p, workspace, k + "w1T"), gxc, gn, B, H, W, st));
+        }
         CK(release_side());
       } else {
         m2t_gemm_args ga{};
@@ -982,18 +1022,20 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
         CK(launch_branch_prep_bwd(dt, L, WSP("gd"), gxc, gn, i, B, H, W, st));
       }
     }
-    void* gx = gnext[b & 1];
+    // block 0: the head's g(res) = g(X0) + g(Y) joins in the same pass and lands where the head weight gradient reads it
+    void* gx = (b == 0) ? WSP("gxc") : gnext[b & 1];
     // gx's buffer was the gy of block b+1: its conv-wgrad / colsum on the side stream must be done
     main_wait(conv_done_prev);
-    CK(launch_instnorm_bwd(dt, gn, X, mean, rstd, gy, gx, (float*)WSP("norm_part"), (float*)WSP("norm_s"), B, (int)p->P, st));
+    CK(launch_instnorm_bwd(dt, gn, X, mean, rstd, gy, gx, (float*)WSP("norm_part"), (float*)WSP("norm_s"), B, (int)p->P, st,
+                           norm_prered ? (const float*)WSP("norm_part0") : nullptr, H * (W / 16), (b == 0) ? WSP("gT") : nullptr));
     conv_done_prev = conv_done;
     gy = gx;
     if ((b & 1) == 0) { CK(flush()); mark_bucket(); }
     else if (b == 1) CK(flush());      // (the step's last pair: its first half is reduced under block 0, so that what is left after the
                                        //  last data-gradient kernel is short -- the main stream idles until it is done)
   }
-  // head: g(res) = g(X0) from the chain + g(Y) from `res + x`
-  CK(launch_add(dt, gy, WSP("gT"), WSP("gxc"), BP * 64, st));
+  // head: g(res) = g(X0) from the chain + g(Y) from `res + x`: added inside block 0's InstanceNorm backward (it wrote gxc)
+  if (p->nb == 0) CK(launch_add(dt, gy, WSP("gT"), WSP("gxc"), BP * 64, st));
   // The end of the step is a serial chain: head weight gradient -> its reduction -> (the caller's) Adam.  In steady state it runs on the
   // MAIN stream behind the last data-gradient kernel: handing it to the side stream and back cost two cross-stream waits and a
   // queue position behind the last block pair's reduction (96 us between the last backward kernel and Adam, measured).
@@ -1059,6 +1101,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (k == "fork_on_kernel") { p->fork_on_kernel = value != 0; return 0; }
   if (k == "fused_prep_fwd") { p->use_fused_prep_fwd = value != 0; return 0; }
   if (k == "fused_prep_bwd") { p->use_fused_prep_bwd = value != 0; return 0; }
+  if (k == "fused_norm_red") { p->use_fused_norm_red = value != 0; return 0; }
   if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }
   if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
   if (k == "fused_tail") {

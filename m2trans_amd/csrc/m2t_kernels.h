@@ -79,8 +79,10 @@ int launch_branch_post_bwd(int dt, int L, const void* gxc, int k, void* ga, int 
 // gdwin != nullptr: ring rows [window][36][16 * 4^L] of the fused projection data gradient, added to the border pixels on load
 int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, int k, int B, int H, int W, hipStream_t st,
                            const void* gdwin = nullptr);
+// part0 != nullptr (bf16): the first reduction stage already ran inside launch_c16_dgrad_prep (its norm arguments): skip it
 int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean, const float* rstd, const void* gres,
-                        void* gx, float* part, float* s, int B, int P, hipStream_t st);
+                        void* gx, float* part, float* s, int B, int P, hipStream_t st, const float* part0 = nullptr, int tiles0 = 0,
+                        const void* gres2 = nullptr);       // gres2: a second residual gradient added in the same pass (block 0: g(Y) of `res + x`)
 int launch_add(int dt, const void* a, const void* b, void* o, long long n, hipStream_t st);
 int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* part, int max_part_blocks, float* out,
                   int accumulate, hipStream_t st, int unshuf = 0, int gH = 0, int gW = 0, int gr = 1, int gC = 64,
@@ -216,7 +218,12 @@ int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float*
                                void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st, const void* d = nullptr,
                                const void* wqkv = nullptr);
 // bf16 C = 16 branch: halo gather + projection data gradient + branch_prep_bwd (k = 0) in one kernel (k_attn_c16.hip)
-int launch_c16_dgrad_prep(void* gqkv, const void* win, const void* wT, const void* gxc, void* gn, int B, int h, int w, hipStream_t st);
+// nx != nullptr (round 5): the first stage of the InstanceNorm backward rides in the same launch -- extra workgroups sum planes 1 .. 3
+// of g_n (complete by then) into npart [B][M2T_NORM_SPLIT][64][2], and every tile leaves the plane-0 sums of its 16 pixels in
+// npart0 [tile][2][16]; gn / nx are then the FULL P64 tensors (plane 0 first), mean / rstd [B][64]
+int launch_c16_dgrad_prep(void* gqkv, const void* win, const void* wT, const void* gxc, void* gn, int B, int h, int w, hipStream_t st,
+                          const void* nx = nullptr, const float* mean = nullptr, const float* rstd = nullptr, float* npart = nullptr,
+                          float* npart0 = nullptr);
 int launch_window_attn_fwd_resident(const void* qkv, const float* rel_h, const float* rel_w, void* out, int ldo, int oc0,
                                     const void* res, int ldr, int B, int h, int w, int C, int post_levels, hipStream_t st);
 // the resident kernel alone (bf16); M2T_UNSUPPORTED when (C, dwt_levels) has no instantiation

@@ -247,6 +247,42 @@ def test_branch_prep_bwd_inside_the_attention_backward_is_bit_identical(shape):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("shape", [(4, 3, 128, 128), (4, 2, 40, 56), (3, 2, 64, 96)])
+def test_instnorm_backward_reduction_inside_the_c16_prep_launch(shape):
+    """"fused_norm_red": the first reduction stage of the InstanceNorm backward (s1 = sum g_n, s2 = sum g_n xhat per image and channel)
+    rides in the C = 16 prep launch -- extra workgroups for planes 1 .. 3, per-tile sums of plane 0 from the tiles that produce it --
+    instead of in a launch of its own.  With ONE block everything in front of the reduction is bit-identical in both modes, so the two
+    evaluations of (s1, s2) differ by fp32 addition order only; the bitwise batch invariance of the sums (an image's sums do not depend
+    on its neighbours in the batch) must hold in the new mode too; at depth the whole gradient agrees to bf16 rounding flips."""
+    from m2trans_amd import _lib
+    scale, B, H, W = shape
+    x = O.closed_form_image(B, 3, H, W).cuda()
+    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+
+    def run(nb, val, xin, hrin):
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(xin)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_norm_red", val), "m2t_set_option")
+        assert plan.query("opt:fused_norm_red") == val
+        model.zero_grad(set_to_none=True)
+        torch.nn.L1Loss()(model(xin), hrin).backward()
+        torch.cuda.synchronize()
+        g = torch.cat([q.grad.detach().reshape(-1) for q in model.parameters() if q.requires_grad]).clone()
+        return g, plan.ws_tensor("norm_s", dtype=torch.float32).clone().view(xin.shape[0], 64, 2)
+
+    g1, s1 = run(1, 1, x, hr)
+    g0, s0 = run(1, 0, x, hr)
+    assert float((s1 - s0).abs().max() / s0.abs().max()) < 2e-6, (s1 - s0).abs().max()
+    assert float((g1 - g0).norm() / g0.norm()) < 2e-3
+    # batch invariance, bitwise: reverse the batch
+    _, sr = run(1, 1, x.flip(0).contiguous(), hr.flip(0).contiguous())
+    assert torch.equal(sr.flip(0), s1)
+    # at depth 2 the summation order reaches bf16 roundings downstream: agreement to rounding flips
+    h1, _ = run(2, 1, x, hr)
+    h0, _ = run(2, 0, x, hr)
+    assert float((h1 - h0).norm() / h0.norm()) < 3e-3
+
+
 def test_fork_event_on_the_dispatch_gives_the_same_bits_as_a_recorded_event():
     """"fork_on_kernel": the event that releases a branch's side-stream work rides on the attention-backward dispatch as its stop
     event (default) or is recorded behind it by a marker packet (0).  Same dependency either way: every gradient bit-identical,
