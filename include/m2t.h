@@ -69,6 +69,13 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           (needs "fused_attn_fwd" >= 1; bit-identical); 0 = branch_prep launches in front of it
  *   "fused_prep_bwd"    [1] bf16: the backward of branch 4's branch_prep inside branch 3's attention backward (same level and window grid; needs
  *                           "attn_bwd" >= 2; bit-identical); 0 = a branch_prep_bwd launch between the two
+ *   "fused_attn_fwd2"   [0] bf16, C = 256 branches with "fused_prep_fwd": the forward kernels that put TWO windows on a CU (k_attn_fwd2.hip: projection
+ *                           in four output-channel chunks, scores / softmax / P in registers, v re-read from L2 for P V, IWT^2 straight from the
+ *                           accumulators): 1 = 4-wave workgroups of one window (80 KB of LDS, two per CU), 2 = 8-wave workgroups of two
+ *                           neighbouring windows (1 for an odd number of windows per image), -1 = variant 1 when the branch has more windows than
+ *                           the chip has CUs (batch >= 17 at 128 x 128), 0 = never.  q | k | v bit-identical to the one-window-per-CU kernel, the
+ *                           output to fp32 summation order.  Measured at batch 32: 59.3 us against 61.7 us stand-alone, a tie inside the step (both
+ *                           windows of a CU start together and stay in the same phase: there is nothing for co-residency to overlap): off by default
  *   "fused_norm_red"    [0] bf16 with "attn_bwd" = 3: the first reduction stage of the InstanceNorm backward (sums of g_n and g_n * xhat per image
  *                           and channel) rides in the C = 16 prep launch -- extra workgroups for the planes of branches 2 .. 4, per-tile sums of
  *                           plane 0 from the tiles that produce it; 0 = its own launch behind that kernel (same sums, another addition order).

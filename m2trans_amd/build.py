@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libm2t.so")
-SOURCES = ["k_pointwise.hip", "k_gemm.hip", "k_conv.hip", "k_attn.hip", "k_attn_res.hip", "k_attn_c16.hip", "k_attn_fused.hip", "k_tail_bwd.hip", "k_tail_fwd.hip", "k_tail_stream.hip", "k_tail_bwd_stream.hip", "k_swin.hip", "k_metrics.hip", "k_fsim.hip", "k_datas.hip", "m2t_api.hip", "m2t_swin.hip", "m2t_rlutrans.hip", "m2t_text.hip"]
+SOURCES = ["k_pointwise.hip", "k_gemm.hip", "k_conv.hip", "k_attn.hip", "k_attn_res.hip", "k_attn_c16.hip", "k_attn_fused.hip", "k_attn_fwd2.hip", "k_tail_bwd.hip", "k_tail_fwd.hip", "k_tail_stream.hip", "k_tail_bwd_stream.hip", "k_swin.hip", "k_metrics.hip", "k_fsim.hip", "k_datas.hip", "m2t_api.hip", "m2t_swin.hip", "m2t_rlutrans.hip", "m2t_text.hip"]
 HEADERS = ["m2t_common.h", "m2t_kernels.h", "m2t_gemm_load.h", "m2t_haar.h", "m2t_window.h", os.path.join("..", "..", "include", "m2t.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-ffp-contract=off", "-fvisibility=hidden",

@@ -173,6 +173,15 @@ struct m2t_plan {
                                        // with the erf form of round 2 it was 1 % slower)
   int use_fused_prep_bwd = 1;          // bf16: branch_prep_bwd of branch 4 inside the attention backward of branch 3 (round 4)
   int use_fused_prep_fwd = 1;          // bf16 C = 64 / 256 branches: branch_prep inside the fused forward attention kernel (round 4)
+  int fused_attn_fwd2 = 0;             // bf16 C = 256 forward branch with branch_prep inside: the two-windows-per-CU kernels (k_attn_fwd2.hip, round 5):
+                                       // 0 = never (default: measured equal to the one-window kernel within 2 %, profiles/README.md), 1 = 4-wave workgroups
+                                       // (two per CU), 2 = 8-wave workgroups of two windows, -1 = variant 1 when the branch has more windows than CUs (256)
+  int fwd2_variant(long long nwin, int h, int w) const {
+    if (fused_attn_fwd2 == 0 || (fused_attn_fwd2 < 0 && nwin <= 256)) return 0;
+    const bool even = (((h / 8) * (w / 8)) & 1) == 0;
+    if (fused_attn_fwd2 == 2 && even) return 2;
+    return 1;
+  }
   int use_fused_norm_red = 0;          // bf16 with the C = 16 prep kernel: the first stage of the InstanceNorm backward reduction rides in that launch (round 5;
                                        // measured SLOWER, -2.2 % on the step: both roles are memory-heavy, profiles/README.md -- kept for A/B)
   int fork_on_kernel = 1;              // a fork event rides on the dispatch it follows (its stop event) instead of a marker packet behind it:
@@ -350,6 +359,7 @@ extern "C" int m2t_plan_create(m2t_plan** out, int B, int H0, int W0, int scale,
   p->add_ws("a", BP * 16, es);
   p->add_ws("norm_part", (size_t)B * 8 * M2T_NORM_SPLIT * 64 * 3, 4);      // (the conv epilogue leaves up to 256 partials per image)
   p->add_ws("norm_s", (size_t)B * 64 * 2, 4);
+  p->add_ws("vring", window_attn_fwd2_vring_elems(B, p->H / 4, p->W / 4), es);      // v rows of the ring keys (k_attn_fwd2.hip)
   p->add_ws("norm_part0", (size_t)B * p->H * (p->W / 16) * 32, 4);      // per-tile plane-0 partials of the InstanceNorm backward (fused_norm_red)
   const int r0 = (s == 4) ? 2 : s;
   // tail activations: gelu(t) and gelu'(t) of each expansion (the pre-activation t itself is never needed again)
@@ -441,6 +451,11 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "side_stream") return p->use_side;
     // (the EFFECTIVE state, like the keys below: an option whose precondition is off did not run)
     if (o == "fork_on_kernel") return p->use_side && p->fork_on_kernel;
+    if (o == "fused_attn_fwd2") {      // effective: would the C = 256 branches run k_attn_fwd2.hip
+      const bool eligible = p->dt != M2T_F32 && p->use_fused_attn_fwd != 0 && p->use_fused_prep_fwd;
+      const long long nwin = (long long)p->B * (p->H / 32) * (p->W / 32);
+      return eligible ? p->fwd2_variant(nwin, p->H / 4, p->W / 4) : 0;
+    }
     if (o == "fused_norm_red") return p->dt != M2T_F32 && p->use_resident_attn_bwd && p->use_fused_qkv_dgrad && p->use_c16_prep && p->use_fused_norm_red;
     if (o == "fused_prep_fwd") return p->dt != M2T_F32 && p->use_fused_attn_fwd != 0 && p->use_fused_prep_fwd;
     if (o == "fused_prep_bwd") return p->dt != M2T_F32 && p->use_resident_attn_bwd && p->use_fused_qkv_dgrad && p->use_fused_prep_bwd;
@@ -542,6 +557,14 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
           // branch_prep (norm apply + mix + DWT^L), the qkv projection, the window attention and IWT^L / residual in one kernel
           const void* xn_i = (const char*)X + (size_t)i * BP * 16 * p->esz;
           const void* xprev = (const char*)xc + (size_t)(i - 1) * BP * 16 * p->esz;
+          const long long nwin = (long long)B * (h / 8) * (w / 8);
+          const int v2 = (C == 256 && L == 2) ? p->fwd2_variant(nwin, h, w) : 0;
+          if (v2 != 0) {
+            // more windows than CUs: the kernels that put two windows on a CU (k_attn_fwd2.hip)
+            CK(launch_window_attn_fused_prep_fwd2(xn_i, xprev, mean, rstd, i, WSP("xin"), d, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "F"),
+                                                  rh, rw, qkv, xc_i, WSP("vring"), B, h, w, v2, st));
+            continue;
+          }
           CK(launch_window_attn_fused_prep_fwd(xn_i, xprev, mean, rstd, i, WSP("xin"), d, packed_ptr(p, workspace, k + "w" + std::to_string(i + 1) + "F"),
                                                rh, rw, (C == 64 && p->c64_recompute()) ? nullptr : qkv, xc_i, B, h, w, C, L, st));
           continue;
@@ -1102,6 +1125,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (k == "fused_prep_fwd") { p->use_fused_prep_fwd = value != 0; return 0; }
   if (k == "fused_prep_bwd") { p->use_fused_prep_bwd = value != 0; return 0; }
   if (k == "fused_norm_red") { p->use_fused_norm_red = value != 0; return 0; }
+  if (k == "fused_attn_fwd2") { if (value < -1 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_attn_fwd2: -1 .. 2"); p->fused_attn_fwd2 = (int)value; return 0; }
   if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }
   if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }
   if (k == "fused_tail") {

@@ -217,6 +217,13 @@ int launch_window_attn_fwd_c16(const void* qkv, const float* rel_h, const float*
 int launch_window_attn_bwd_c16(const void* qkv, const float* rel_h, const float* rel_w, const void* gout, int ldg, int gc0,
                                void* gqkv, void* win, float* relw, int B, int h, int w, hipStream_t st, const void* d = nullptr,
                                const void* wqkv = nullptr);
+// k_attn_fwd2.hip (round 5): the same fused C = 256 forward branch as launch_window_attn_fused_prep_fwd, built for two workgroups per
+// CU (4 waves, 80 KB of LDS, channel-chunked projection, scores in registers); vring [B (h/8)(w/8)][36][256]: scratch for the ring
+// keys' v rows (window_attn_fwd2_vring_elems elements)
+size_t window_attn_fwd2_vring_elems(int B, int h, int w);
+int launch_window_attn_fused_prep_fwd2(const void* xn, const void* xprev, const float* mean, const float* rstd, int k, void* xin, void* d,
+                                       const void* wfrag, const float* rel_h, const float* rel_w, void* qkv, void* out, void* vring,
+                                       int B, int h, int w, int windows_per_wg, hipStream_t st, int stagger = 0);
 // bf16 C = 16 branch: halo gather + projection data gradient + branch_prep_bwd (k = 0) in one kernel (k_attn_c16.hip)
 // nx != nullptr (round 5): the first stage of the InstanceNorm backward rides in the same launch -- extra workgroups sum planes 1 .. 3
 // of g_n (complete by then) into npart [B][M2T_NORM_SPLIT][64][2], and every tile leaves the plane-0 sums of its 16 pixels in

@@ -1,0 +1,98 @@
+// Stand-alone timing harness for k_attn_fwd2.hip (no torch): synthetic data, hipEvent timing, optional per-phase s_memtime stamps.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off scratch/bench_fwd2.hip -o scratch/bench_fwd2        (-DSTAMPS -> _st)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#include <string>
+#ifdef STAMPS
+__device__ unsigned long long* g_stamps;
+#define M2T_FWD2_STAMP(i) do { if ((threadIdx.x & 63) == 0) { g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); if ((i) == 0 || (i) == 7) g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#endif
+#include "../m2trans_amd/csrc/k_attn_fwd2.hip"
+
+int m2t_set_hip_error(hipError_t e, const char* f, int l) { fprintf(stderr, "HIP error %d %s at %s:%d\n", (int)e, hipGetErrorString(e), f, l); return (int)e; }
+int m2t_set_error(int c, const char* m) { fprintf(stderr, "error %d %s\n", c, m); return c; }
+int m2t_ensure_dynamic_lds(const void* k, int b) { return (int)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, b); }
+void m2t_prof_begin(int, hipStream_t) {}
+void m2t_prof_end(int, hipStream_t) {}
+bool m2t_prof_take(hipEvent_t*, hipEvent_t*) { return false; }
+hipEvent_t m2t_fork_take() { return nullptr; }
+#define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+static unsigned short f2bf(float f) { union { float f; unsigned u; } c; c.f = f; unsigned u = c.u; return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
+
+int main(int argc, char** argv) {
+  const int C = 256, B = argc > 1 ? atoi(argv[1]) : 32, h = 32, w = 32, TWv = argc > 2 ? atoi(argv[2]) : 2, stag = argc > 3 ? atoi(argv[3]) : 0;
+  const size_t M = (size_t)B * h * w, full = (size_t)B * 128 * 128;
+  std::vector<unsigned short> hwf((size_t)3 * C * C), hres(full * 16);
+  srand(1);
+  for (auto& v : hwf) v = f2bf((rand() / (float)RAND_MAX - 0.5f) * 0.2f);
+  for (auto& v : hres) v = f2bf((rand() / (float)RAND_MAX - 0.5f));
+  std::vector<float> hrel(10 * C);
+  for (auto& v : hrel) v = (rand() / (float)RAND_MAX - 0.5f);
+  void *dwf, *dqkv, *dout, *dres, *dxin, *dd, *dprev, *dvr; float *drel, *dstat;
+  const int nwin = B * (h / 8) * (w / 8);
+  CKH(hipMalloc(&dwf, (size_t)3 * C * C * 2)); CKH(hipMalloc(&dqkv, M * 3 * C * 2)); CKH(hipMalloc(&dout, full * 16 * 2)); CKH(hipMalloc(&dres, full * 16 * 2));
+  CKH(hipMalloc(&drel, 10 * C * 4)); CKH(hipMalloc(&dxin, full * 16 * 2)); CKH(hipMalloc(&dd, M * C * 2)); CKH(hipMalloc(&dprev, full * 16 * 2));
+  CKH(hipMalloc(&dstat, (size_t)B * 64 * 2 * 4)); CKH(hipMalloc(&dvr, (size_t)nwin * 36 * C * 2));
+  CKH(hipMemcpy(dwf, hwf.data(), (size_t)3 * C * C * 2, hipMemcpyHostToDevice));
+  CKH(hipMemcpy(dres, hres.data(), full * 16 * 2, hipMemcpyHostToDevice)); CKH(hipMemcpy(dprev, hres.data(), full * 16 * 2, hipMemcpyHostToDevice));
+  CKH(hipMemcpy(drel, hrel.data(), 10 * C * 4, hipMemcpyHostToDevice));
+  { std::vector<float> hs2((size_t)B * 64 * 2, 1.0f); for (size_t i = 0; i < (size_t)B * 64; ++i) hs2[i] = 0.01f * (float)(i % 7); CKH(hipMemcpy(dstat, hs2.data(), hs2.size() * 4, hipMemcpyHostToDevice)); }
+#ifdef STAMPS
+  unsigned long long* dst;
+  CKH(hipMalloc(&dst, (size_t)nwin * 8 * 16 * 8));
+  CKH(hipMemset(dst, 0, (size_t)nwin * 8 * 16 * 8));
+  CKH(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dst, sizeof(dst)));
+#endif
+  hipStream_t st; CKH(hipStreamCreate(&st));
+  auto launch = [&]() { return launch_window_attn_fused_prep_fwd2(dres, dprev, dstat, dstat + (size_t)B * 64, 2, dxin, dd, dwf, drel, drel + 5 * C, dqkv, dout, dvr, B, h, w, TWv, st, stag); };
+  for (int i = 0; i < 5; ++i) if (launch()) return 1;
+  CKH(hipStreamSynchronize(st));
+  hipEvent_t e0, e1; CKH(hipEventCreate(&e0)); CKH(hipEventCreate(&e1));
+  const int N = 40;
+  std::vector<float> ts;
+  for (int i = 0; i < N; ++i) {
+    CKH(hipEventRecord(e0, st));
+    if (launch()) return 1;
+    CKH(hipEventRecord(e1, st));
+    CKH(hipEventSynchronize(e1));
+    float ms; CKH(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms * 1e3f);
+  }
+  std::sort(ts.begin(), ts.end());
+  printf("fwd2 (windows per workgroup %d, stagger %d) B=%d windows=%d: event-bracketed min %.2f us median %.2f us\n", TWv, stag, B, nwin, ts[0], ts[N / 2]);
+#ifdef STAMPS
+  std::vector<unsigned long long> hs((size_t)nwin * 8 * 16); const int nwg = nwin / TWv;
+  CKH(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
+  const int NW = 4 * TWv, NS = 8;
+  const char* names[NS - 1] = {"phase0 loads + xin -> LDS + barrier", "Haar in place + ring request + barrier", "phase A: 4 chunks (proj, q|k|v out, S)", "d rows out + fence + barrier",
+                               "v0 / residual request + softmax", "phase C: P V (4 chunks)", "phase D: IWT + residual + store"};
+  for (int wsel : {0, NW - 1}) {
+    printf("wave %d: median cycles per segment over %d workgroups\n", wsel, nwin);
+    for (int s = 0; s + 1 < NS; ++s) {
+      std::vector<long long> d;
+      for (int b = 0; b < nwg; ++b) { const unsigned long long a = hs[((size_t)b * 8 + wsel) * 16 + s], c = hs[((size_t)b * 8 + wsel) * 16 + s + 1]; if (a && c) d.push_back((long long)(c - a)); }
+      if (d.empty()) continue;
+      std::sort(d.begin(), d.end());
+      printf("  %-40s %8lld (min %lld max %lld)\n", names[s], d[d.size() / 2], d.front(), d.back());
+    }
+    std::vector<long long> d;
+    for (int b = 0; b < nwg; ++b) d.push_back((long long)(hs[((size_t)b * 8 + wsel) * 16 + 7] - hs[((size_t)b * 8 + wsel) * 16 + 0]));
+    std::sort(d.begin(), d.end());
+    printf("  total (stamp 0 -> 7) median %lld cycles\n", d[d.size() / 2]);
+  }
+  {
+    unsigned long long lo = ~0ull, hi = 0; std::vector<long long> st0, en;
+    for (int b = 0; b < nwg; ++b) for (int wv = 0; wv < NW; ++wv) {
+      const unsigned long long a = hs[((size_t)b * 8 + wv) * 16 + 8], c = hs[((size_t)b * 8 + wv) * 16 + 15];
+      if (a) lo = std::min(lo, a); if (c) hi = std::max(hi, c);
+    }
+    for (int b = 0; b < nwg; ++b) { st0.push_back((long long)(hs[((size_t)b * 8) * 16 + 8] - lo)); en.push_back((long long)(hs[((size_t)b * 8) * 16 + 15] - lo)); }
+    std::sort(st0.begin(), st0.end()); std::sort(en.begin(), en.end());
+    printf("  chip: first start -> last end %.2f us; workgroup start offsets: median %.2f us, p90 %.2f, max %.2f; end offsets: min %.2f median %.2f max %.2f us\n", (hi - lo) * 0.01,
+           st0[st0.size() / 2] * 0.01, st0[st0.size() * 9 / 10] * 0.01, st0.back() * 0.01, en.front() * 0.01, en[en.size() / 2] * 0.01, en.back() * 0.01);
+  }
+#endif
+  return 0;
+}

@@ -12,7 +12,7 @@ if os.environ.get("M2T_PMC_SET") == "2":
                 "SQ_INST_LEVEL_LDS", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_DATA_FIFO_FULL"]
 os.makedirs(OUT, exist_ok=True)
 cmd = ["rocprofv3", "--pmc"] + COUNTERS + ["--kernel-trace", "--output-format", "csv", "-d", OUT, "--",
-       sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+       sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-also",
        "--no-kernel-events", "--no-side-stream"] + sys.argv[1:]
 subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, TMPDIR="/tmp"), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -46,7 +46,7 @@ def run(counter):
     os.makedirs(d, exist_ok=True)
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
            sys.executable, os.path.join(ROOT, "bench.py"), "--config", CONFIG, "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline", "--no-kernel-events", "--no-side-stream"]
+           "--no-cpu-baseline", "--no-also", "--no-kernel-events", "--no-side-stream"]
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, cwd=ROOT, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)

@@ -8,7 +8,7 @@ cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json
 python bench.py 2>&1 | tail -1 > gpurun_out/bench_default.json
 cut -c1-900 gpurun_out/bench_default.json
 rm -rf gpurun_out/prof_default
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_default -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_default.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_default -- python3 bench.py --no-cpu-baseline --no-also > gpurun_out/prof_default.log 2>&1
 find gpurun_out/prof_default -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/kernel_stats_default.csv
 rm -rf gpurun_out/prof_single
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_single -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-events --no-side-stream > gpurun_out/prof_single.log 2>&1
