@@ -69,6 +69,9 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *                           (needs "fused_attn_fwd" >= 1; bit-identical); 0 = branch_prep launches in front of it
  *   "fused_prep_bwd"    [1] bf16: the backward of branch 4's branch_prep inside branch 3's attention backward (same level and window grid; needs
  *                           "attn_bwd" >= 2; bit-identical); 0 = a branch_prep_bwd launch between the two
+ *   "fused_l1"          [1] bf16 x4 with the recomputing fused tail backward ("fused_tail" = 2 / 3): a loss requested through m2t_l1_loss_deferred
+ *                           is taken inside that kernel (clamp, |sr - hr| partial sums, sign seed on the staged halo); 0 = m2t_backward runs the
+ *                           clamp + L1 kernel first (bit-identical gradients either way)
  *   "fused_attn_fwd2"   [0] bf16, C = 256 branches with "fused_prep_fwd": the forward kernels that put TWO windows on a CU (k_attn_fwd2.hip: projection
  *                           in four output-channel chunks, scores / softmax / P in registers, v re-read from L2 for P V, IWT^2 straight from the
  *                           accumulators): 1 = 4-wave workgroups of one window (80 KB of LDS, two per CU), 2 = 8-wave workgroups of two
@@ -129,6 +132,13 @@ int m2t_forward(m2t_plan* p, const float* params, const float* x, float* sr, flo
  * full-batch gradient). */
 int m2t_l1_loss(m2t_plan* p, const float* hr, float lambda_l1, double divisor, float rgb_range,
                 float* loss_out, void* workspace, void* stream);
+/* The same loss and seed, produced INSIDE the next m2t_backward (round 5): loss_out is valid in stream order behind that call, and
+ * hr must stay valid until it has been issued.  On the bf16 x4 path the fused tail backward takes the clamp + L1 seed while it
+ * stages its g(sr) halo (option "fused_l1"): the seed tensor is never written, one 150 MB pass and two launches leave the step;
+ * on every other path m2t_backward runs m2t_l1_loss's kernel first (identical results to m2t_l1_loss).  The loss value differs
+ * from m2t_l1_loss's by the order of an fp32 sum.  A later m2t_l1_loss / m2t_set_output_grad / m2t_forward cancels it. */
+int m2t_l1_loss_deferred(m2t_plan* p, const float* hr, float lambda_l1, double divisor, float rgb_range,
+                         float* loss_out, void* workspace, void* stream);
 /* alternative seed: an arbitrary upstream gradient g_sr [B,3,H0*s,W0*s] (torch autograd). */
 int m2t_set_output_grad(m2t_plan* p, const float* g_sr, float rgb_range, void* workspace, void* stream);
 /* loss.backward() (train.py:209) restricted to the model: fills grads (flat, same layout as

@@ -27,6 +27,7 @@ SIGNATURES = {
     "m2t_plan_init_workspace": (_i, [_vp, _vp, _vp]),
     "m2t_forward": (_i, [_vp, _vp, _vp, _vp, _f, _i, _vp, _vp]),
     "m2t_l1_loss": (_i, [_vp, _vp, _f, _d, _f, _vp, _vp, _vp]),
+    "m2t_l1_loss_deferred": (_i, [_vp, _vp, _f, _d, _f, _vp, _vp, _vp]),
     "m2t_set_output_grad": (_i, [_vp, _vp, _f, _vp, _vp]),
     "m2t_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "m2t_adam_step": (_i, [_vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _i, _f, _vp]),

@@ -1175,6 +1175,13 @@ int launch_clamp_l1(const float* pre, const float* hr, float* sr, float* gpre, f
   return 0;
 }
 
+int launch_loss_finish(const float* part, int n, float loss_scale, float* loss, hipStream_t st) {
+  if (n < 1 || n > M2T_LOSS_BLOCKS) return m2t_set_error(-2, "loss_finish: 1 .. M2T_LOSS_BLOCKS partials");
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, st, part, n, loss_scale, loss);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+
 // =======================================================================================
 // fused multi-tensor Adam over the flat parameter buffer   (train.py:81,210)
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)

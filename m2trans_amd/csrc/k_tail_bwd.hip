@@ -44,6 +44,14 @@ struct TailBwdArgs {
   float* slab_w3;         // [nblk][256][64]  (n' x k)
   float* slab_b3;         // [nblk][256]
   int B, H, W;
+  // L1 (round 5): the clamp + L1 seed of train.py:199 (clamp_l1_vec4_kernel) is taken while the g(sr) halo is staged -- gout is then
+  // unused: g(sr) = sign(clamp(pre) - hr) * gscale where 0 <= pre <= R inside the crop, 0 elsewhere -- and the workgroup leaves the
+  // sum of |clamp(pre) - hr| over ITS tiles' own pixels in loss_part[blockIdx] (fixed tile assignment: deterministic)
+  const float* pre;       // pre-clamp output fp32 [B][3][H][W] (padded size)
+  const float* hr;        // target fp32 [B][3][Hs][Ws] (cropped size)
+  float* loss_part;       // [nblk]
+  int Hs, Ws;
+  float R, gscale;
 };
 
 __device__ __forceinline__ Frag8<bf16_t> tr_rows(const bf16_t* lo, const bf16_t* hi) {
@@ -63,7 +71,7 @@ __device__ __forceinline__ int hr_row(int m, int sub) { return (2 * (m >> 3) + (
 // the two erf-based functions 32 elements per thread.  Same operand fragments, k order, bias add and gelu_erf_both as
 // tail_expand_kernel (k_gemm.hip), so the recomputed values are the bits the forward would have stored.  gelu'(t2) is
 // written where g(t2) goes (the product is formed in place), so the LDS footprint does not grow.
-template <bool RC>
+template <bool RC, bool L1 = false>
 __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
   using T = bf16_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -128,7 +136,8 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
   // ---- register-staged loads of a tile (raw bf16; two groups so that nothing prefetched must be copied) ----
   Frag8<T> ra2[4], ra1, rder[2][2];
   bf16x4 rd1[2];
-  float rg[2];
+  float rg[2], rh[2];                            // rg: g(sr) -- with L1: the pre-clamp value; rh: the target (L1 only)
+  float l1acc = 0.f;
   auto tile_geom = [&](long long t, int& b, int& y0, int& x0) {
     const int tx = (int)(t % tw);
     const long long q = t / tw;
@@ -158,7 +167,13 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
       const int py = p / (TB_T + 2), px = p - py * (TB_T + 2);
       const int gy = y0 + py - 1, gx = x0 + px - 1;
       // (the select happens when the value is staged, not here: using the loaded value now would wait for it)
-      rg[it] = a.gout[((long long)b * 3 + oc) * hw + (long long)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
+      if constexpr (L1) {
+        const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+        rg[it] = a.pre[((long long)b * 3 + oc) * hw + (long long)cy * W + cx];
+        rh[it] = a.hr[(((long long)b * 3 + oc) * a.Hs + min(cy, a.Hs - 1)) * a.Ws + min(cx, a.Ws - 1)];
+      } else {
+        rg[it] = a.gout[((long long)b * 3 + oc) * hw + (long long)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
+      }
     }
   };
   auto fetchB = [&](long long t) {              // consumed from registers: gelu'(t2) of this lane's two conv-gradient
@@ -196,8 +211,23 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
       const int i = tid + it * 512;
       if (i < 3 * TB_HP) {
         const int p = i % TB_HP;
-        const int gy = y0 + p / (TB_T + 2) - 1, gx = x0 + p % (TB_T + 2) - 1;
-        Gs[i / TB_HP][p] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? rg[it] : 0.f;      // 0 outside the image
+        const int py = p / (TB_T + 2), px = p % (TB_T + 2);
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        if constexpr (L1) {
+          // clamp_l1_vec4_kernel's arithmetic on the staged value: the seed is 0 outside the crop and where the clamp is active
+          float gv = 0.f;
+          if (gy >= 0 && gy < a.Hs && gx >= 0 && gx < a.Ws) {
+            const float v = rg[it];
+            const float c = fminf(fmaxf(v, 0.f), a.R);
+            const float d = c - rh[it];
+            const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+            gv = (v >= 0.f && v <= a.R) ? sg * a.gscale : 0.f;
+            if (py >= 1 && py <= TB_T && px >= 1 && px <= TB_T) l1acc += fabsf(d);     // the tile's OWN pixels: each pixel of the image once
+          }
+          Gs[i / TB_HP][p] = gv;
+        } else {
+          Gs[i / TB_HP][p] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? rg[it] : 0.f;      // 0 outside the image
+        }
       }
     }
     __syncthreads();
@@ -376,6 +406,14 @@ __global__ void __launch_bounds__(512) tail_bwd_fused_kernel(TailBwdArgs a) {
     M2T_TAIL_STAMP(10);
   }
 
+  if constexpr (L1) {
+    // (the tile buffers are free behind the loop's last barrier: eight floats of Gs carry the wave sums)
+    const float ws = wave_sum(l1acc);
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane == 0) red[w8] = ws;
+    __syncthreads();
+    if (tid == 0) a.loss_part[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  }
   // ---- slabs ----
   {
     float* out = a.slab_wf + (long long)blockIdx.x * (32 * 64);
@@ -413,23 +451,30 @@ int tail_bwd_fused_blocks(int B, int H, int W) {
 // bf16 only.  H, W: high-resolution size (multiples of 32).  nslab_out: slabs written (same count for the three sets).
 int launch_tail_bwd_fused(const float* gout, const float* wf, const void* act, const void* der, const void* a1, const void* d1,
                           const void* w3t, const float* b3, void* gt1, float* slab_wf, float* slab_w3, float* slab_b3, int* nslab_out,
-                          int B, int H, int W, hipStream_t st) {
+                          int B, int H, int W, hipStream_t st, const float* l1_pre, const float* l1_hr, float* l1_part, int Hs, int Ws,
+                          float R, float gscale) {
   // act == nullptr: the forward did not store gelu(t2) / gelu'(t2); they are recomputed per tile from a1, w3t and b3
+  // l1_pre != nullptr: the clamp + L1 seed is taken inside (gout unused); l1_part [tail_bwd_fused_blocks] receives the loss partials
   if (H % 32 || W % 32) return m2t_set_error(-2, "tail_bwd_fused: H, W must be multiples of 32");
   const long long ntiles = (long long)B * (H / TB_T) * (W / TB_T);
   (void)ntiles;
   const int nblk = tail_bwd_fused_blocks(B, H, W);
   const size_t sh = tail_bwd_smem();
   TailBwdArgs a{gout, wf, (const bf16_t*)act, (const bf16_t*)der, (const bf16_t*)a1, (const bf16_t*)d1, (const bf16_t*)w3t, b3,
-                (bf16_t*)gt1, slab_wf, slab_w3, slab_b3, B, H, W};
+                (bf16_t*)gt1, slab_wf, slab_w3, slab_b3, B, H, W, l1_pre, l1_hr, l1_part, Hs, Ws, R, gscale};
+  if (l1_pre && (!l1_hr || !l1_part || act != nullptr)) return m2t_set_error(-2, "tail_bwd_fused: the fused L1 seed needs hr, the partial buffer and the recomputing variant");
+#define TB_GO(RC_, L1_)                                                                                                    \
+  do {                                                                                                                      \
+    if (int rc__ = m2t_ensure_dynamic_lds((const void*)tail_bwd_fused_kernel<RC_, L1_>, (int)sh)) return rc__;               \
+    M2T_LAUNCH_TIMED((tail_bwd_fused_kernel<RC_, L1_>), dim3(nblk), dim3(512), sh, st, a);                                   \
+  } while (0)
   if (act == nullptr) {
     if (!b3) return m2t_set_error(-2, "tail_bwd_fused: the recomputing variant needs the tail.3 bias");
-    if (int rc__ = m2t_ensure_dynamic_lds((const void*)tail_bwd_fused_kernel<true>, (int)sh)) return rc__;
-    M2T_LAUNCH_TIMED(tail_bwd_fused_kernel<true>, dim3(nblk), dim3(512), sh, st, a);
+    if (l1_pre) TB_GO(true, true); else TB_GO(true, false);
   } else {
-    if (int rc__ = m2t_ensure_dynamic_lds((const void*)tail_bwd_fused_kernel<false>, (int)sh)) return rc__;
-    M2T_LAUNCH_TIMED(tail_bwd_fused_kernel<false>, dim3(nblk), dim3(512), sh, st, a);
+    TB_GO(false, false);
   }
+#undef TB_GO
   M2T_LAUNCH_CHECK();
   *nslab_out = nblk;
   return 0;

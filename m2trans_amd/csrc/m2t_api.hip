@@ -161,6 +161,10 @@ struct m2t_plan {
   std::map<std::string, long long> pk;       // packed weight offsets (elements of T)
   long long npacked = 0;
   bool have_seed = false, have_acts = false;
+  // m2t_l1_loss_deferred: the loss and the seed are produced inside the next m2t_backward (round 5)
+  bool l1_deferred = false;
+  const float* l1_hr = nullptr; float* l1_loss_out = nullptr; float l1_sc = 0.f, l1_R = 0.f;
+  int use_fused_l1 = 1;                // bf16 x4: the clamp + L1 seed inside the fused tail backward when the loss was requested through m2t_l1_loss_deferred
   // ---- options (m2t_set_option; include/m2t.h documents each) ----
   bool use_side = true;
   bool debug_skip_side = false;        // timing experiments only: skip every parameter-gradient kernel (results are WRONG)
@@ -451,6 +455,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "side_stream") return p->use_side;
     // (the EFFECTIVE state, like the keys below: an option whose precondition is off did not run)
     if (o == "fork_on_kernel") return p->use_side && p->fork_on_kernel;
+    if (o == "fused_l1") return p->dt != M2T_F32 && p->scale == 4 && p->use_fused_l1 && p->use_fused_tail_bwd && p->use_fused_tail_fwd && !p->use_stream_tail_bwd;
     if (o == "fused_attn_fwd2") {      // effective: would the C = 256 branches run k_attn_fwd2.hip
       const bool eligible = p->dt != M2T_F32 && p->use_fused_attn_fwd != 0 && p->use_fused_prep_fwd;
       const long long nwin = (long long)p->B * (p->H / 32) * (p->W / 32);
@@ -632,6 +637,7 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
                        p->Ws, rgb_range, 0.f, 0.f, st));
   p->have_acts = true;
   p->have_seed = false;
+  p->l1_deferred = false;
   return 0;
 }
 
@@ -642,6 +648,21 @@ extern "C" int m2t_l1_loss(m2t_plan* p, const float* hr, float lambda_l1, double
   const float sc = (float)((double)lambda_l1 / divisor);
   CK(launch_clamp_l1((const float*)WSP("srpre"), hr, nullptr, (float*)WSP("gpre"), (float*)WSP("loss_part"), loss_out,
                      p->B, p->Hsp, p->Wsp, p->Hs, p->Ws, rgb_range, sc, sc, (hipStream_t)stream));
+  p->have_seed = true;
+  p->l1_deferred = false;
+  return 0;
+}
+
+// The same loss and seed, produced INSIDE the next m2t_backward: on the bf16 x4 path the clamp + L1 seed are taken by the fused tail
+// backward while it stages its g(sr) halo (the pre-clamp output is read there instead of a stored seed: one 150 MB pass and two
+// launches fewer per step); everywhere else m2t_backward simply runs m2t_l1_loss's kernel first.  hr must stay valid until then.
+extern "C" int m2t_l1_loss_deferred(m2t_plan* p, const float* hr, float lambda_l1, double divisor, float rgb_range,
+                                    float* loss_out, void* workspace, void* stream) {
+  (void)stream;
+  if (!p || !hr || !workspace || !loss_out) return m2t_set_error(M2T_ERR_ARG, "m2t_l1_loss_deferred: null argument");
+  if (!p->have_acts) return m2t_set_error(M2T_ERR_STATE, "m2t_l1_loss_deferred: call m2t_forward first");
+  p->l1_hr = hr; p->l1_loss_out = loss_out; p->l1_sc = (float)((double)lambda_l1 / divisor); p->l1_R = rgb_range;
+  p->l1_deferred = true;
   p->have_seed = true;
   return 0;
 }
@@ -672,6 +693,7 @@ extern "C" int m2t_set_output_grad(m2t_plan* p, const float* g_sr, float rgb_ran
                      p->Hs, p->Ws, rgb_range);
   M2T_LAUNCH_CHECK();
   p->have_seed = true;
+  p->l1_deferred = false;
   return 0;
 }
 
@@ -780,6 +802,12 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   if (!skip) { CK(launch_head_im2col(dt, x, WSP("head_cols"), B, p->H0, p->W0, H, W, sd)); im2col_done = side_marker(); }
   const bool fused_tail = p->use_fused_tail_bwd && s == 4 && dt != M2T_F32;
   const bool stream_x23 = p->stream_tail_x23();
+  // a deferred L1 loss (m2t_l1_loss_deferred): inside the fused tail backward where that kernel runs in its recomputing form,
+  // otherwise by m2t_l1_loss's own kernel, here, in front of everything that reads the seed
+  const bool l1_in_tail = p->l1_deferred && p->use_fused_l1 && fused_tail && p->use_fused_tail_fwd && !(p->use_stream_tail_bwd && p->use_fused_tail_fwd);
+  if (p->l1_deferred && !l1_in_tail)
+    CK(launch_clamp_l1((const float*)WSP("srpre"), p->l1_hr, nullptr, (float*)WSP("gpre"), (float*)WSP("loss_part"), p->l1_loss_out,
+                       p->B, p->Hsp, p->Wsp, p->Hs, p->Ws, p->l1_R, p->l1_sc, p->l1_sc, st));
   if (stream_x23) {
     // x2 / x3: the whole tail backward in one row-streaming launch (k_tail_bwd_stream.hip): g(body output) straight into gT
     const int N0 = 64 * r0 * r0;
@@ -808,7 +836,9 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       else
       CK(launch_tail_bwd_fused(gpre, params + p->poff.at(wl), rc ? nullptr : WSP("t2act"), rc ? nullptr : WSP("t2der"), WSP("t1act"),
                                WSP("t1der"), packed_ptr(p, workspace, "t3T"), params + p->poff.at("tail.3.bias"), WSP("g_t1pre"), swf, sw3,
-                               sb3, &ns, B, p->Hsp, p->Wsp, st)); }
+                               sb3, &ns, B, p->Hsp, p->Wsp, st, l1_in_tail ? (const float*)WSP("srpre") : nullptr, p->l1_hr,
+                               (float*)WSP("loss_part"), p->Hs, p->Ws, p->l1_R, p->l1_sc)); }
+    if (l1_in_tail) CK(launch_loss_finish((const float*)WSP("loss_part"), ns, p->l1_sc, p->l1_loss_out, st));
     defer(swf, p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0);
     defer(sw3, p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64);
     defer(sb3, p->poff.at("tail.3.bias"), ns, 256, 2, 64, 4, 1);
@@ -1105,6 +1135,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   if (bucket_i != p->buckets.size()) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: gradient bucket table out of step");
   if (!(tail_on_main && !first_backward)) main_wait(side_marker());          // join: every gradient is complete in main-stream order
   p->have_seed = false;
+  p->l1_deferred = false;
   return 0;
 }
 
@@ -1125,6 +1156,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (k == "fused_prep_fwd") { p->use_fused_prep_fwd = value != 0; return 0; }
   if (k == "fused_prep_bwd") { p->use_fused_prep_bwd = value != 0; return 0; }
   if (k == "fused_norm_red") { p->use_fused_norm_red = value != 0; return 0; }
+  if (k == "fused_l1") { p->use_fused_l1 = value != 0; return 0; }
   if (k == "fused_attn_fwd2") { if (value < -1 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_attn_fwd2: -1 .. 2"); p->fused_attn_fwd2 = (int)value; return 0; }
   if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }
   if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }

@@ -90,6 +90,8 @@ int launch_colsum(int dt, const void* a, int lda, long long M, int N, float* par
 int launch_multi_reduce(const float* arena, float* grads, const m2t_red_desc* descs, int ndesc, hipStream_t st);
 int launch_clamp_l1(const float* pre, const float* hr, float* sr, float* gpre, float* part, float* loss, int B, int Hp,
                     int Wp, int Hs, int Ws, float R, float loss_scale, float gscale, hipStream_t st);
+// loss = loss_scale * sum(part[0 .. n)) in a fixed order (n <= M2T_LOSS_BLOCKS)
+int launch_loss_finish(const float* part, int n, float loss_scale, float* loss, hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
                 int step, float gscale, hipStream_t st);
 // blocks: device table int2[nblocks] = (descriptor index, chunk of M2T_PACK_CHUNK output elements)
@@ -190,9 +192,13 @@ int launch_tail_bwd_stream(const float* gout, const float* wf, const void* a, co
 // b3 [n][256]; n = *nslab_out <= tail_bwd_fused_blocks().
 int tail_bwd_fused_blocks(int B, int H, int W);
 // act == der == nullptr: gelu(t2) / gelu'(t2) are recomputed per tile from a1, w3t and the tail.3 bias b3 (torch order)
+// l1_pre != nullptr (recomputing variant only): the clamp + L1 seed of launch_clamp_l1 is taken inside the kernel from the pre-clamp
+// output l1_pre [B][3][H][W] and the target l1_hr [B][3][Hs][Ws] (gout is then unused); l1_part [tail_bwd_fused_blocks] receives the
+// partial sums of |clamp(pre) - hr| for launch_loss_finish
 int launch_tail_bwd_fused(const float* gout, const float* wf, const void* act, const void* der, const void* a1, const void* d1,
                           const void* w3t, const float* b3, void* gt1, float* slab_wf, float* slab_w3, float* slab_b3,
-                          int* nslab_out, int B, int H, int W, hipStream_t st);
+                          int* nslab_out, int B, int H, int W, hipStream_t st, const float* l1_pre = nullptr, const float* l1_hr = nullptr,
+                          float* l1_part = nullptr, int Hs = 0, int Ws = 0, float R = 0.f, float gscale = 0.f);
 
 // ---- k_attn.hip -------------------------------------------------------------------------
 // qkv [B][h][w][3C] (q | k | v), rel_h/rel_w fp32 [10][C/2];  out rows at ldo (+ optional residual rows at ldr)

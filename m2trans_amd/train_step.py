@@ -103,8 +103,10 @@ class TrainStep:
             ws = _lib.ptr(plan.workspace)
             _lib.check(lib.m2t_forward(plan.handle, _lib.ptr(m.flat_params), _lib.ptr(lr_img), _lib.ptr(sr),
                                        float(m.rgb_range), 1, ws, st), "m2t_forward")
-            _lib.check(lib.m2t_l1_loss(plan.handle, _lib.ptr(hr_img), self.lambda_l1, divisor, float(m.rgb_range),
-                                       _lib.ptr(self.l1_loss), ws, st), "m2t_l1_loss")
+            # (deferred: the loss and the backward seed are produced inside m2t_backward, which follows at once -- on the bf16 x4
+            #  path by the fused tail backward itself; hr_img stays alive until then)
+            _lib.check(lib.m2t_l1_loss_deferred(plan.handle, _lib.ptr(hr_img), self.lambda_l1, divisor, float(m.rgb_range),
+                                                _lib.ptr(self.l1_loss), ws, st), "m2t_l1_loss_deferred")
             fwd_done = torch.cuda.current_stream(lr_img.device).record_event() if (use_clip and self.overlap_semantic) else None
             _lib.check(lib.m2t_backward(plan.handle, _lib.ptr(m.flat_params), _lib.ptr(lr_img), _lib.ptr(self.grads),
                                         ws, st), "m2t_backward")

@@ -328,6 +328,46 @@ def test_instnorm_backward_reduction_inside_the_c16_prep_launch(shape):
     assert float((h1 - h0).norm() / h0.norm()) < 3e-3
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 128), (3, 40, 56), (2, 72, 200)])
+def test_l1_seed_inside_the_fused_tail_backward_is_bit_identical(shape):
+    """m2t_l1_loss_deferred + "fused_l1": the clamp + L1 seed (train.py:199; clamp_l1_vec4_kernel) taken by the fused tail backward on the
+    g(sr) halo it stages, instead of by a kernel of its own that writes the seed tensor.  Same arithmetic per pixel -> every gradient
+    bit-identical; the loss value is the same sum of |clamp(sr) - hr| in another fp32 order.  Reflect-padded sizes (the crop: pixels of the
+    padded output outside the image carry no seed and no loss), border and interior tiles, and the immediate m2t_l1_loss as a third arm."""
+    from m2trans_amd import _lib
+    from m2trans_amd.train_step import TrainStep
+    B, H, W = shape
+    scale, nb = 4, 2
+    x = O.closed_form_image(B, 3, H, W).cuda()
+    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+    res = []
+    for val in (1, 0):
+        model, _ = build_model(scale, nb, "bf16")
+        plan = model._plan_for(x)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_l1", val), "m2t_set_option")
+        assert plan.query("opt:fused_l1") == val
+        ts = TrainStep(model, lr=1e-4, world_size=1)
+        loss = ts.forward_backward(x, hr)
+        torch.cuda.synchronize()
+        res.append((float(loss), ts.grads.clone()))
+    # third arm: the immediate API (loss and seed before m2t_backward)
+    model, _ = build_model(scale, nb, "bf16")
+    plan = model._plan_for(x)
+    lib = _lib.load()
+    ws, st = _lib.ptr(plan.workspace), _lib.stream_ptr()
+    loss3 = torch.zeros(1, device="cuda")
+    grads3 = torch.zeros_like(model.flat_params)
+    _lib.check(lib.m2t_forward(plan.handle, _lib.ptr(model.flat_params), _lib.ptr(x), None, 1.0, 1, ws, st), "fwd")
+    _lib.check(lib.m2t_l1_loss(plan.handle, _lib.ptr(hr), 1.0, float(hr.numel()), 1.0, _lib.ptr(loss3), ws, st), "l1")
+    _lib.check(lib.m2t_backward(plan.handle, _lib.ptr(model.flat_params), _lib.ptr(x), _lib.ptr(grads3), ws, st), "bwd")
+    torch.cuda.synchronize()
+    (l1, g1), (l0, g0) = res
+    assert torch.equal(g1, g0) and torch.equal(g1, grads3)
+    assert abs(l1 - l0) <= 2e-6 * abs(l0) and abs(l0 - float(loss3)) == 0.0, (l1, l0, float(loss3))
+    lo, _, _ = O.l1_loss_and_grads(x.cpu(), hr.cpu(), O.closed_form_params(64, scale, nb), scale, nb)
+    assert abs(l1 - float(lo)) < 5e-3 * abs(float(lo))          # (bf16 forward against the fp32 oracle: the loss itself is the same quantity)
+
+
 def test_fork_event_on_the_dispatch_gives_the_same_bits_as_a_recorded_event():
     """"fork_on_kernel": the event that releases a branch's side-stream work rides on the attention-backward dispatch as its stop
     event (default) or is recorded behind it by a marker packet (0).  Same dependency either way: every gradient bit-identical,
