@@ -354,11 +354,7 @@ __global__ void __launch_bounds__(256 * TW, 2) window_attn_fwd2_kernel(Fwd2Args 
         const f32x4 r4 = *reinterpret_cast<const f32x4*>(&RelC[(cc < 2) ? kr : kc][chl]);
         float kh[4] = {(float)kb4[0] + r4[0], (float)kb4[1] + r4[1], (float)kb4[2] + r4[2], (float)kb4[3] + r4[3]};
         store4(&Kc[mywin][key][chl], kh);                              // K^ = bf16(bf16(k) + rel): the rounding points of the unfused kernels
-#ifdef F2_DBG_NO_QKV_STORES
-        if (key < 0) {
-#else
         if (key < 64) {
-#endif
           const unsigned qo = ((unsigned)gm.query_pixel(key) * (3 * C) + ch) * 2u;
           f2_nt_store(reinterpret_cast<bf16x4 __attribute__((address_space(1)))*>(qkv_b + qo + 2u * C), kb4);
           *reinterpret_cast<bf16x4 __attribute__((address_space(1)))*>(qkv_b + qo + 4u * C) = vb;
