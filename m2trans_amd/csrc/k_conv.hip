@@ -19,6 +19,10 @@ __device__ __forceinline__ int head_src(int i, int n, int n0) {
   return (i < n0) ? i : (2 * n0 - 2 - i);  // the right/bottom reflect pad to a multiple of 32
 }
 
+// One thread = TWO horizontally adjacent pixels x 16 output channels (round 5; one pixel before): a broadcast LDS read of 16 weights
+// now feeds 32 FMAs instead of 16 (the kernel issued 108 ds_read_b128 for 432 FMAs per thread), the two pixels share two of their
+// four input columns (36 loads for two pixels instead of 54), and half as many workgroups stage the 27 x 64 weights.  Per output
+// the operation order is unchanged -- bias, then (ic, ky, kx) with fmaf -- so the bits are the same.
 template <typename T>
 __global__ void __launch_bounds__(256) head_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, T* __restrict__ out, int B,
@@ -31,38 +35,57 @@ __global__ void __launch_bounds__(256) head_conv_fwd_kernel(const float* __restr
   }
   if (threadIdx.x < 64) bs[threadIdx.x] = bias[threadIdx.x];
   __syncthreads();
-  const long long total = (long long)B * H * W * 4;
+  const int Wh = W >> 1;                                   // pixel pairs per row (W is a multiple of 32)
+  const long long total = (long long)B * H * Wh * 4;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total;
        t += (long long)gridDim.x * blockDim.x) {
     const int og = (int)(t & 3);
-    const long long pix = t >> 2;
-    const int xx = (int)(pix % W);
-    const long long q = pix / W;
+    const long long pp = t >> 2;
+    const int xx = 2 * (int)(pp % Wh);
+    const long long q = pp / Wh;
     const int yy = (int)(q % H);
     const int b = (int)(q / H);
-    float acc[16];
+    // the 3 x 4 input patch of the pair per channel: columns xx - 1 .. xx + 2
+    int sx[4], sy[3];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = bs[og * 16 + e];
+    for (int c = 0; c < 4; ++c) sx[c] = head_src(xx + c - 1, W, W0);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) sy[r] = head_src(yy + r - 1, H, H0);
+    float v[3][3][4];
 #pragma unroll
     for (int ic = 0; ic < 3; ++ic)
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int sy = head_src(yy + ky - 1, H, H0);
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[ic][r][c] = x[(((long long)b * 3 + ic) * H0 + sy[r]) * W0 + sx[c]];
+    float acc[2][16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[0][e] = bs[og * 16 + e]; acc[1][e] = acc[0][e]; }
+#pragma unroll
+    for (int ic = 0; ic < 3; ++ic)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const int sx = head_src(xx + kx - 1, W, W0);
-          const float v = x[(((long long)b * 3 + ic) * H0 + sy) * W0 + sx];
           const float* wr = &ws[ic * 9 + ky * 3 + kx][og * 16];
+          const float v0 = v[ic][ky][kx], v1 = v[ic][ky][kx + 1];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[e] = fmaf(v, wr[e], acc[e]);
+          for (int e = 0; e < 16; ++e) {
+            const float we = wr[e];
+            acc[0][e] = fmaf(v0, we, acc[0][e]);
+            acc[1][e] = fmaf(v1, we, acc[1][e]);
+          }
         }
-      }
-    store16f(out + ((long long)og * B * H * W + pix) * 16, acc);     // P64: chunk og is a dense plane
+    const long long pix = ((long long)b * H + yy) * W + xx;
+    T* o = out + ((long long)og * B * H * W + pix) * 16;                  // P64: chunk og is a dense plane; the pair is 64 contiguous bytes (bf16)
+    store16f(o, acc[0]);
+    store16f(o + 16, acc[1]);
   }
 }
 int launch_head_conv_fwd(int dt, const float* x, const float* w, const float* b, void* out, int B, int H0, int W0,
                          int H, int W, hipStream_t st) {
-  const long long total = (long long)B * H * W * 4;
+  if (W & 1) return m2t_set_error(-2, "head_conv_fwd: the padded width must be even");
+  const long long total = (long long)B * H * (W / 2) * 4;
   const int g = (int)std::min<long long>(ceil_divll(total, 256), 4096);
   if (dt == M2T_F32) hipLaunchKernelGGL(head_conv_fwd_kernel<float>, dim3(g), dim3(256), 0, st, x, w, b, (float*)out, B, H0, W0, H, W);
   else hipLaunchKernelGGL(head_conv_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, st, x, w, b, (bf16_t*)out, B, H0, W0, H, W);
