@@ -256,9 +256,117 @@ static int launch_gemm_nt_wide_bm(const m2t_gemm_args& a, hipStream_t st) {
   return launch_gemm_nt_wide<T, 64, EMODE>(a, st);
 }
 
+// =======================================================================================
+// fp32 (parity mode) GEMMs on v_mfma_f32_32x32x2_f32 (round 5).  The kernels above were shaped for bf16: in fp32 each `mma16` is a
+// chain of eight DEPENDENT 16x16x4 products (40-cycle dependent latency on a 32-cycle issue) whose operands are fetched from LDS
+// into the same registers right before use, one wave per SIMD -- 13 % of the fp32 MFMA rate in the C = 256 projections.  The 32x32x2
+// form needs ONE operand register per lane for 4096 FLOP (half the LDS bytes per FLOP of 16x16x4), its dependent latency equals its
+// issue interval (64 cycles), and a wave's 32 x 32 NB tile gives NB independent accumulators.
+//   lane l = (i = l & 31, h = l >> 5):  A operand = W[n0 + i][k], B operand = X[m0 + i][k], k = 8 q + 4 h + s in step s of block q
+//   (one ds_read_b128 per operand and 8-deep block; the contraction order is a fixed permutation of k, the same for every output),
+//   D[row = 8 (r >> 2) + 4 h + (r & 3)][col = i] -> a lane holds 4 consecutive output channels of ONE pixel per register quad.
+// =======================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+thread_local int g_m2t_f32_fast = 1;       // option fp32_fast of the plan being run (m2t_api.hip); 0 = the round-4 kernels
+__device__ __forceinline__ void mfma32f(f32x16& acc, float a, float b) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0); }
+
+template <int NB>
+__global__ void __launch_bounds__(256, 2)
+gemm_nt_f32_kernel(const float* __restrict__ A, int lda, const float* __restrict__ W, float* __restrict__ Y, int ldy, long long M,
+                   int N, int K) {
+  constexpr int BM = 128, BN = 32 * NB, BK = 32, LD = BK + 4, ROWS = BM + BN, NIT = ROWS / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float(*S)[ROWS][LD] = reinterpret_cast<float(*)[ROWS][LD]>(smem);         // [2][activation rows | weight rows][k]
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int gy = N / BN, L = xcd_block_index();         // column tile fastest: the tiles sharing a row strip of A sit behind one L2
+  const long long m0 = (long long)(L / gy) * BM;
+  const int n0 = (L % gy) * BN;
+  f32x16 acc[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+  const int srow = tid >> 3, skv = (tid & 7) * 4;       // staging slot: rows srow + 32 it, one float4 of the 32-deep stage
+  f32x4 rg[NIT];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const long long m = m0 + srow + 32 * it;
+      rg[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (m < M) rg[it] = *reinterpret_cast<const f32x4*>(A + m * lda + k0 + skv);
+    }
+#pragma unroll
+    for (int it = 4; it < NIT; ++it)
+      rg[it] = *reinterpret_cast<const f32x4*>(W + (long long)(n0 + srow + 32 * (it - 4)) * K + k0 + skv);
+  };
+  fetch(0);
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += BK, buf ^= 1) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) *reinterpret_cast<f32x4*>(&S[buf][srow + 32 * it][skv]) = rg[it];
+    __syncthreads();      // (the buffer written next iteration was last read before this barrier)
+    if (k0 + BK < K) fetch(k0 + BK);
+    const float* sx = &S[buf][32 * wv + li][4 * lh];
+    const float* sw = &S[buf][BM + li][4 * lh];
+    f32x4 xf[2], wf[2][NB];
+    xf[0] = *reinterpret_cast<const f32x4*>(sx);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) wf[0][b] = *reinterpret_cast<const f32x4*>(sw + 32 * b * LD);
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      if (q + 1 < BK / 8) {                              // operands of the next 8-deep block fly under this block's products
+        xf[(q + 1) & 1] = *reinterpret_cast<const f32x4*>(sx + 8 * (q + 1));
+#pragma unroll
+        for (int b = 0; b < NB; ++b) wf[(q + 1) & 1][b] = *reinterpret_cast<const f32x4*>(sw + 32 * b * LD + 8 * (q + 1));
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) mfma32f(acc[b], wf[q & 1][b][s], xf[q & 1][s]);
+    }
+  }
+  const long long m = m0 + 32 * wv + li;
+  if (m < M) {
+    float* y = Y + m * ldy + n0 + 4 * lh;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq)
+        *reinterpret_cast<f32x4*>(y + 32 * b + 8 * rq) = (f32x4){acc[b][4 * rq], acc[b][4 * rq + 1], acc[b][4 * rq + 2], acc[b][4 * rq + 3]};
+  }
+}
+template <int NB>
+static int launch_gemm_nt_f32_nb(const m2t_gemm_args& a, hipStream_t st) {
+  const size_t sh = sizeof(float) * 2 * (128 + 32 * NB) * 36;
+  if (int rc__ = m2t_ensure_dynamic_lds((const void*)gemm_nt_f32_kernel<NB>, (int)sh)) return rc__;
+  dim3 grid((unsigned)(ceil_divll(a.M, 128) * (a.N / (32 * NB))));
+  hipLaunchKernelGGL((gemm_nt_f32_kernel<NB>), grid, dim3(256), sh, st, (const float*)a.A, a.lda, (const float*)a.W, (float*)a.Y, a.ldy,
+                     a.M, a.N, a.K);
+  M2T_LAUNCH_CHECK();
+  return 0;
+}
+static bool gemm_nt_f32_ok(int amode, int emode, const m2t_gemm_args& a) {
+  return g_m2t_f32_fast && amode == M2T_A_PLAIN && emode == M2T_E_PLAIN && a.N % 32 == 0 && a.K % 32 == 0 && a.lda % 4 == 0 &&
+         a.ldy > 0 && a.ldy % 4 == 0 && a.ldy != M2T_LD_P64;
+}
+static int launch_gemm_nt_f32(const m2t_gemm_args& a, hipStream_t st) {
+  // widest column tile (fewest re-reads of the activation rows) that still gives every CU a workgroup
+  const long long rows = ceil_divll(a.M, 128);
+  const int nb32 = a.N / 32;
+  if (nb32 % 3 == 0 && rows * (nb32 / 3) >= 256) return launch_gemm_nt_f32_nb<3>(a, st);
+  if (nb32 % 2 == 0 && rows * (nb32 / 2) >= 256) return launch_gemm_nt_f32_nb<2>(a, st);
+  if (rows * nb32 >= 256 || (nb32 % 3 && nb32 % 2)) return launch_gemm_nt_f32_nb<1>(a, st);
+  if (nb32 % 2 == 0 && rows * (nb32 / 2) >= 128) return launch_gemm_nt_f32_nb<2>(a, st);
+  return launch_gemm_nt_f32_nb<1>(a, st);
+}
+
 template <typename T>
 static int launch_gemm_nt_t(int amode, int emode, const m2t_gemm_args& a, hipStream_t st) {
   if (a.K % 8 || a.N % 16) return m2t_set_error(-2, "gemm_nt: K must be a multiple of 8 and N of 16");
+  if constexpr (sizeof(T) == 4) {
+    if (gemm_nt_f32_ok(amode, emode, a)) return launch_gemm_nt_f32(a, st);
+  }
   if (amode == M2T_A_PLAIN && a.N % 128 == 0 && a.K % 64 == 0 && a.K >= 128 && a.ldy != M2T_LD_P64) {
     if (emode == M2T_E_PLAIN) return launch_gemm_nt_wide_bm<T, M2T_E_PLAIN>(a, st);
     // the Swin-T GEMMs of stages 3 / 4 (and fc1 of stage 2): bias, bias + GELU, bias + residual epilogues
@@ -682,6 +790,74 @@ static int wgrad_big_slabs(long long M, int N, int K, int target = 256) {
   return (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want, ceil_divll(M, WG_BM)));
 }
 
+// ---------------------------------------------------------------------------------------
+// fp32 weight gradient on v_mfma_f32_32x32x2_f32 (see gemm_nt_f32_kernel): 64 x 64 output tile, 2 x 2 waves of one 32 x 32 block,
+// 32-row stages of [G 64 | X 64] rows (row stride 160 floats = 32 banks mod 64: the two rows a step reads cover all 64 banks),
+// double-buffered, one barrier per stage.  The contraction runs over the ROW index, so both operands are ds_read_b32 down a column:
+// step s of a stage takes rows 2 s + h.  Same slab contract as wgrad_tn_kernel (slabs of [N][K], rows per slab a multiple of 32).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+wgrad_tn_f32_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx, float* __restrict__ slabs, long long M,
+                    int N, int K, long long rows_per_slab) {
+  constexpr int BR = 32, LD = 160;
+  __shared__ __attribute__((aligned(16))) float S[2][BR][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5, wn = wv & 1, wk = wv >> 1;
+  const int tn = N / 64, tk = K / 64;
+  const int L = xcd_block_index();
+  const int slab = L / (tn * tk), rem = L - slab * (tn * tk);
+  const int n0 = (rem % tn) * 64, k0 = (rem / tn) * 64;
+  const long long mb = (long long)slab * rows_per_slab, me = min(M, mb + rows_per_slab);
+  const int nst = (int)((me - mb + BR - 1) / BR);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // staging slot: row tid >> 3 of the stage, float4 columns 4 v and 4 v + 32 of G and of X
+  const int srow = tid >> 3, sv = (tid & 7) * 4;
+  const float* pg = G + (mb + srow) * ldg + n0 + sv;
+  const float* px = X + (mb + srow) * ldx + k0 + sv;
+  f32x4 rg[4];
+  auto fetch = [&](int st) {
+    const long long m = mb + (long long)st * BR + srow;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (m < me) {
+      const float* qg = pg + (long long)st * BR * ldg;
+      const float* qx = px + (long long)st * BR * ldx;
+      rg[0] = *reinterpret_cast<const f32x4*>(qg);
+      rg[1] = *reinterpret_cast<const f32x4*>(qg + 32);
+      rg[2] = *reinterpret_cast<const f32x4*>(qx);
+      rg[3] = *reinterpret_cast<const f32x4*>(qx + 32);
+    }
+  };
+  if (nst > 0) fetch(0);
+  int buf = 0;
+  for (int st = 0; st < nst; ++st, buf ^= 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&S[buf][srow][sv + 32 * j]) = rg[j];
+    __syncthreads();
+    if (st + 1 < nst) fetch(st + 1);
+    const float* sg = &S[buf][lh][32 * wn + li];
+    const float* sx = &S[buf][lh][64 + 32 * wk + li];
+    float gf[2][4], xf[2][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { gf[0][s] = sg[2 * s * LD]; xf[0][s] = sx[2 * s * LD]; }
+#pragma unroll
+    for (int q = 0; q < BR / 8; ++q) {
+      if (q + 1 < BR / 8) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { gf[(q + 1) & 1][s] = sg[(8 * (q + 1) + 2 * s) * LD]; xf[(q + 1) & 1][s] = sx[(8 * (q + 1) + 2 * s) * LD]; }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mfma32f(acc, gf[q & 1][s], xf[q & 1][s]);
+    }
+  }
+  // D[row n = 8 (r >> 2) + 4 h + (r & 3)][col k = li]: half a wave writes 128 contiguous bytes of one row of the slab
+  float* out = slabs + (long long)slab * N * K + (long long)(n0 + 32 * wn + 4 * lh) * K + k0 + 32 * wk + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) out[(long long)(8 * (r >> 2) + (r & 3)) * K] = acc[r];
+}
+
 int wgrad_slab_count(long long M, int N, int K) {
   const int tn = ceil_div(N, 64), tk = ceil_div(K, 64);
   const long long want = std::max<long long>(1, 512 / (tn * tk));
@@ -712,6 +888,19 @@ static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_
   }
   const long long want64 = std::max<long long>(1, 512 / (tn * tk));
   int nslab = (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want64, ceil_divll(a.M, WG_BM)));
+  if constexpr (sizeof(T) == 4) {
+    if (g_m2t_f32_fast && a.gmode == M2T_A_PLAIN && a.xmode == M2T_A_PLAIN && !a.bias_slabs && a.ldg > 0 && a.ldx > 0 && a.N % 64 == 0 &&
+        a.K % 64 == 0 && a.ldg % 4 == 0 && a.ldx % 4 == 0) {
+      // same slab bound as below (wgrad_slab_count); rows per slab a multiple of the 32-row stage so the slabs balance
+      const long long rps32 = ceil_divll(ceil_divll(a.M, nslab), 32) * 32;
+      const int ns32 = (int)ceil_divll(a.M, rps32);
+      hipLaunchKernelGGL(wgrad_tn_f32_kernel, dim3(tn * tk * ns32), dim3(256), 0, st, (const float*)a.G, a.ldg, (const float*)a.X, a.ldx,
+                         a.slabs, a.M, a.N, a.K, rps32);
+      M2T_LAUNCH_CHECK();
+      *nslab_out = ns32;
+      return 0;
+    }
+  }
   // whole slabs per XCD: the tn x tk tiles of a slab share its rows of G and X through ONE L2 (xcd_block_index gives every XCD a
   // contiguous eighth of the grid); 10 slabs of 48 tiles straddled the XCD runs and re-fetched 1.5x the operand bytes from HBM
   if (nslab > 8) nslab = nslab / 8 * 8;

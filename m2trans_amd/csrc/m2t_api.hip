@@ -164,6 +164,7 @@ struct m2t_plan {
   // m2t_l1_loss_deferred: the loss and the seed are produced inside the next m2t_backward (round 5)
   bool l1_deferred = false;
   const float* l1_hr = nullptr; float* l1_loss_out = nullptr; float l1_sc = 0.f, l1_R = 0.f;
+  int use_fp32_fast = 1;               // fp32: the v_mfma_f32_32x32x2_f32 GEMM / qkv weight-gradient kernels of round 5 (k_gemm.hip); 0 = the 16x16x4 kernels
   int use_fused_l1 = 1;                // bf16 x4: the clamp + L1 seed inside the fused tail backward when the loss was requested through m2t_l1_loss_deferred
   // ---- options (m2t_set_option; include/m2t.h documents each) ----
   bool use_side = true;
@@ -455,6 +456,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     if (o == "side_stream") return p->use_side;
     // (the EFFECTIVE state, like the keys below: an option whose precondition is off did not run)
     if (o == "fork_on_kernel") return p->use_side && p->fork_on_kernel;
+    if (o == "fp32_fast") return p->dt == M2T_F32 && p->use_fp32_fast;
     if (o == "fused_l1") return p->dt != M2T_F32 && p->scale == 4 && p->use_fused_l1 && p->use_fused_tail_bwd && p->use_fused_tail_fwd && !p->use_stream_tail_bwd;
     if (o == "fused_attn_fwd2") {      // effective: would the C = 256 branches run k_attn_fwd2.hip
       const bool eligible = p->dt != M2T_F32 && p->use_fused_attn_fwd != 0 && p->use_fused_prep_fwd;
@@ -513,6 +515,8 @@ extern "C" int m2t_forward(m2t_plan* p, const float* params, const float* x, flo
                            int keep_activations, void* workspace, void* stream) {
   if (!p || !params || !x || !workspace) return m2t_set_error(M2T_ERR_ARG, "m2t_forward: null argument");
   hipStream_t st = (hipStream_t)stream;
+  g_m2t_f32_fast = p->use_fp32_fast;        // thread-local switch the fp32 launchers of k_gemm.hip read; back to its default on every exit path
+  struct F32FastGuard { ~F32FastGuard() { g_m2t_f32_fast = 1; } } f32_fast_guard;
   const int dt = p->dt, B = p->B, H = p->H, W = p->W, s = p->scale;
   const long long BP = (long long)B * p->P;
   (void)keep_activations;   // v1 keeps every activation in the workspace either way
@@ -709,6 +713,8 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   if (!p || !params || !x || !grads || !workspace) return m2t_set_error(M2T_ERR_ARG, "m2t_backward: null argument");
   if (!p->have_acts || !p->have_seed)
     return m2t_set_error(M2T_ERR_STATE, "m2t_backward: needs m2t_forward and a seed (m2t_l1_loss / m2t_set_output_grad)");
+  g_m2t_f32_fast = p->use_fp32_fast;
+  struct F32FastGuard { ~F32FastGuard() { g_m2t_f32_fast = 1; } } f32_fast_guard;
   hipStream_t st = (hipStream_t)stream;
   if (p->ensure_side(st) != 0) return m2t_set_error(M2T_ERR_STATE, "m2t_backward: cannot create the side stream / events");
   hipStream_t sd = p->use_side ? p->side : st;
@@ -1157,6 +1163,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (k == "fused_prep_bwd") { p->use_fused_prep_bwd = value != 0; return 0; }
   if (k == "fused_norm_red") { p->use_fused_norm_red = value != 0; return 0; }
   if (k == "fused_l1") { p->use_fused_l1 = value != 0; return 0; }
+  if (k == "fp32_fast") { p->use_fp32_fast = value != 0; return 0; }
   if (k == "fused_attn_fwd2") { if (value < -1 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_attn_fwd2: -1 .. 2"); p->fused_attn_fwd2 = (int)value; return 0; }
   if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }
   if (k == "wgrad_big_tiles") { p->wgrad_big_tiles = (int)value; return 0; }

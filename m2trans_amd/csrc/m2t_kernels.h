@@ -117,6 +117,9 @@ struct m2t_gemm_args {
   const void* halo_win = nullptr;   // M2T_A_HALO: per-window dK|dV scratch (H, Wd = branch grid, C = branch channels)
 };
 int launch_gemm_nt(int dt, int amode, int emode, const m2t_gemm_args& a, hipStream_t st);
+// fp32 (parity mode): 1 = the v_mfma_f32_32x32x2_f32 kernels of round 5 for the plain GEMMs, the qkv weight gradients and the 3x3 conv,
+// 0 = the 16x16x4 kernels of rounds 1-4 (option fp32_fast of the plan being run; set by m2t_api.hip on entry)
+extern thread_local int g_m2t_f32_fast;
 // upsampler 1x1 conv + bias + pixel-shuffle scatter + GELU, K = 64, N = 64 r^2; X rows over [B][H][Wd];
 // Y = gelu(t), Yd = gelu'(t) (both [B][H r][Wd r][64])
 int launch_tail_expand(int dt, const void* X, const void* Wp, const float* bias, void* Y, void* Yd, long long M, int H, int Wd,

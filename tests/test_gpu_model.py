@@ -1036,3 +1036,30 @@ def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():
                 assert float((a.double() - b.double()).norm()) <= 1e-5 * float(a.double().norm()), (B, H, W, n)
             else:
                 assert torch.equal(a, b), (B, H, W, n)
+
+
+@pytest.mark.parametrize("scale,B,H,W", [(4, 2, 64, 64), (4, 1, 96, 32), (2, 3, 40, 56)])
+def test_fp32_mfma_32x32x2_gemms_match_the_16x16x4_kernels(scale, B, H, W):
+    """fp32 parity mode, option fp32_fast (default): the qkv projections, their data gradients and the qkv weight gradients of the C = 64 and
+    C = 256 branches on v_mfma_f32_32x32x2_f32 (gemm_nt_f32_kernel / wgrad_tn_f32_kernel, k_gemm.hip) against the 16x16x4 kernels of
+    rounds 1-4.  Both are exact fp32 products accumulated in fp32; only the contraction ORDER differs (a fixed permutation of k, other
+    slab boundaries): sr within 2e-6 of its scale, every gradient within 2e-5 of its norm -- far inside the oracle gates of the fp32
+    tests above, which run on the default (fast) path.  Ragged row counts (reflect padding, odd window counts) go through the masked tiles."""
+    from m2trans_amd import _lib
+    nb = 2
+    x = O.closed_form_image(B, 3, H, W).cuda()
+    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+    outs = []
+    for fast in (1, 0):
+        model, _ = build_model(scale, nb, "fp32")
+        plan = model._plan_for(x)
+        _lib.check(_lib.load().m2t_set_option(plan.handle, b"fp32_fast", fast), "m2t_set_option")
+        assert plan.query("opt:fp32_fast") == fast
+        sr = model(x)
+        torch.nn.L1Loss()(sr, hr).backward()
+        outs.append((sr.detach().clone(), {n: q.grad.clone() for n, q in model.named_parameters() if q.requires_grad}))
+    (sa, ga), (sb, gb) = outs
+    assert float((sa - sb).abs().max()) <= 2e-6 * max(1.0, float(sb.abs().max())), float((sa - sb).abs().max())
+    for n in ga:
+        d = float((ga[n].double() - gb[n].double()).norm()) / max(float(gb[n].double().norm()), 1e-30)
+        assert d < 2e-5, (n, d)
