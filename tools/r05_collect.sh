@@ -18,3 +18,4 @@ cp $O/attn_bwd_stamps.txt profiles/r05_attn_bwd_stamps.txt; cp $O/attn_fwd_stamp
 cp $O/ab_options.txt profiles/r05_ab_options.txt; cp $O/ab_libs.txt profiles/r05_ab_libs_round4_vs_round5.txt; cp $O/soak.txt profiles/r05_soak.txt
 cp $O/pmc_traffic.json profiles/pmc_traffic.json; cp $O/pmc_traffic_config4.json profiles/pmc_traffic_config4.json
 cp $O/pmc_traffic_config3.json profiles/pmc_traffic_config3.json
+cp $O/fp32_gemm.txt profiles/r05_fp32_gemm_32x32x2.txt

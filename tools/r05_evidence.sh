@@ -66,9 +66,12 @@ timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --mast
   echo "config 4: A = default, B = fused_attn_fwd2 1"; bash tools/ab_opts.sh "--config 4" "--config 4 --option fused_attn_fwd2=1" 2
   echo "config 2: A = main priority 0, B = -1 (default with the regulariser)"; bash tools/ab_opts.sh "--config 2 --main-priority 0" "--config 2 --main-priority -1" 2
   echo "config 2: A = default (encoder beside the backward), B = --no-overlap-semantic"; bash tools/ab_opts.sh "--config 2" "--config 2 --no-overlap-semantic" 2 ) > $O/ab_options.txt 2>&1
-( echo "A = round-4 final library (f313e5b), B = this build; config 1"; bash tools/ab_libs.sh "--config 1 --steps 30" 3
-  echo "config 3"; bash tools/ab_libs.sh "--config 3 --steps 20" 3
-  echo "config 4"; bash tools/ab_libs.sh "--config 4 --steps 20" 3 ) > $O/ab_libs.txt 2>&1
+( echo "A = round-4 final tree (f313e5b: scratch/r4tree, its own bench.py + library), B = this tree; config 1"; bash tools/ab_rounds.sh "--config 1 --steps 30" 3
+  echo "config 3"; bash tools/ab_rounds.sh "--config 3 --steps 20" 3
+  echo "config 4"; bash tools/ab_rounds.sh "--config 4 --steps 20" 3
+  echo "config 2"; bash tools/ab_rounds.sh "--config 2 --steps 20" 2 ) > $O/ab_libs.txt 2>&1
+( echo "fp32 parity mode, config 1: A = fp32_fast 0 (16x16x4 GEMMs of rounds 1-4), B = default (32x32x2)"; bash tools/ab_opts.sh "--dtype fp32 --steps 8 --warmup 2 --option fp32_fast=0" "--dtype fp32 --steps 8 --warmup 2" 2
+  echo "== scratch/bench_gemm_f32 64 (the step's fp32 GEMM shapes at batch 16, 128x128 LR)"; ./scratch/bench_gemm_f32 64 ) > $O/fp32_gemm.txt 2>&1
 cat $O/ab_libs.txt
 timeout 600 python tools/soak.py 8 12 > $O/soak.txt 2>&1; tail -2 $O/soak.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
