@@ -68,7 +68,14 @@ class TransBlock(nn.Module):
         lib = _lib.load()
         code = _lib.F32 if self.compute_dtype in ("fp32", "float32") else _lib.BF16
         xc = x.detach().contiguous().float()
-        flat = torch.cat([v.detach().reshape(-1).float() for v in self.state_dict().values()]).to(x.device).contiguous()
+        # the 22 928 parameters as one fp32 device vector in state_dict order: rebuilt only when a parameter changed (in-place
+        # version counters) or moved, not on every forward
+        vals = list(self.state_dict().values())
+        key = (str(x.device),) + tuple((v.data_ptr(), v._version) for v in vals)
+        if getattr(self, "_flat_key", None) != key:
+            self._flat = torch.cat([v.detach().reshape(-1).float() for v in vals]).to(x.device).contiguous()
+            self._flat_key = key
+        flat = self._flat
         if flat.numel() != 22928:
             raise M2TError("TransBlock: unexpected parameter count")
         need = int(lib.m2t_transblock_workspace_bytes(B, N, code))

@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
   const char* names[NS - 1] = {"phase0 x,rel->LDS", "phase1 k-step loop (q|k|v proj)", "res loads + K,Q epilogue + barrier", "V store + S + softmax", "barrier + PV", "barrier", "epilogue", "-"};
   for (int wsel : {0, NW - 1}) {
     printf("wave %d: median cycles per segment over %d workgroups\n", wsel, nwin);
-    for (int s = 0; s + 1 < NS; ++s) {
+    for (int s = 0; s + 2 < NS; ++s) {      // stamps 0..7 are s_memtime; slot 8 starts the s_memrealtime pair and is not a segment
       std::vector<long long> d;
       for (int b = 0; b < nwin; ++b) {
         const unsigned long long a = hs[((size_t)b * 8 + wsel) * 16 + s], c = hs[((size_t)b * 8 + wsel) * 16 + s + 1];

@@ -14,7 +14,8 @@ done
 cp $O/timeline_c1_default.txt profiles/r05_timeline_config1_default.txt; cp $O/timeline_c1_default_no_events.txt profiles/r05_timeline_config1_default_no_events.txt
 cp $O/pmc_sq.txt profiles/r05_pmc_sq_config1_single_stream.txt; cp $O/pmc_sq_config3.txt profiles/r05_pmc_sq_config3_single_stream.txt
 cp $O/traffic_table_config4.txt profiles/r05_traffic_table_config4.txt; cp $O/traffic_table_config1.txt profiles/r05_traffic_table_config1.txt; cp $O/traffic_table_config3.txt profiles/r05_traffic_table_config3.txt
-cp $O/attn_bwd_stamps.txt profiles/r05_attn_bwd_stamps.txt; cp $O/attn_fwd_stamps.txt profiles/r05_attn_fwd_stamps.txt; cp $O/attn_fwd2_stamps.txt profiles/r05_attn_fwd2_stamps.txt
+cp $O/attn_bwd_stamps.txt profiles/r05_attn_bwd_stamps.txt; grep -v '^  -  ' $O/attn_fwd_stamps.txt > profiles/r05_attn_fwd_stamps.txt;   # (binaries built before the printer's loop bound was fixed emit one non-segment line per wave)
+ cp $O/attn_fwd2_stamps.txt profiles/r05_attn_fwd2_stamps.txt
 cp $O/ab_options.txt profiles/r05_ab_options.txt; cp $O/ab_libs.txt profiles/r05_ab_libs_round4_vs_round5.txt; cp $O/soak.txt profiles/r05_soak.txt
 cp $O/pmc_traffic.json profiles/pmc_traffic.json; cp $O/pmc_traffic_config4.json profiles/pmc_traffic_config4.json
 cp $O/pmc_traffic_config3.json profiles/pmc_traffic_config3.json
