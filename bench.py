@@ -57,8 +57,8 @@ def parse():
     ap.add_argument("--option", action="append", default=[], metavar="KEY=INT", help="m2t_set_option on the plan (experiments)")
     ap.add_argument("--no-side-stream", action="store_true", help="run the whole backward on one stream")
     ap.add_argument("--main-priority", type=int, default=None, choices=[0, -1],
-                    help="priority of the stream the step runs on (the plan's side stream inherits it).  Default: -1 (high) with the MedCLIP "
-                         "regulariser, whose encoder then runs on a normal-priority stream BEHIND the step's kernels; 0 otherwise")
+                    help="priority of the stream the step runs on (the plan's side stream inherits it).  Default 0; -1 (high) was tried for "
+                         "configs[2] so that the MedCLIP encoder's normal-priority stream runs BEHIND the step's kernels: no gain")
     ap.add_argument("--no-overlap-semantic", action="store_true", help="SemanticLoss forward after the backward pass instead of beside it")
     ap.add_argument("--debug-skip-side", action="store_true", help="TIMING EXPERIMENT: skip all parameter-gradient kernels (wrong results)")
     ap.add_argument("--semantic-loss", action="store_true",
@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-also", action="store_true",
                     help="default run only: skip the short runs of the other BASELINE workloads that fill the line's `also` list")
     ap.add_argument("--also-steps", type=int, default=6, help="timed steps of each `also` run (>= 5)")
+    ap.add_argument("--also-list", default=None, metavar="NAME,NAME", help="which `also` workloads to run and in which order (default: all four; diagnosis)")
     ap.add_argument("--stub-step", action="store_true",
                     help="HARNESS SELF-TEST on CPU: run this script's N-rank control flow with gloo and a sleeping stand-in for the step; "
                          "prints an `invalid` line with no throughput")
@@ -352,10 +353,19 @@ def run_workload(args, device, rank: int, world: int, backend, grp: dict, cpu_ba
 
     dominant_mask = 0
     # a non-default stream: the plan's side stream is a blocking stream and would serialise against the legacy default stream
-    main_priority = args.main_priority if args.main_priority is not None else (-1 if args.semantic_loss else 0)
+    # normal priority everywhere: a high-priority launch stream beside the MedCLIP encoder's stream measured no gain (queue priority does not
+    # arbitrate CUs between resident kernels), and a SECOND launch stream in the process left the next workload's side stream on a shared
+    # hardware queue (the fp32 `also` run behind configs[2]: 872 -> 660 patches/s)
+    main_priority = args.main_priority if args.main_priority is not None else 0
     if not args.null_stream:
         torch.cuda.synchronize()
-        torch.cuda.set_stream(torch.cuda.Stream(device=device, priority=main_priority))
+        # ONE launch stream per priority for the whole process: every new stream takes a hardware queue (4 by default), and once the `also`
+        # workloads had made a handful of them a plan's main and side stream could land on the SAME queue -- configs[4] then ran 10-40 % slower
+        # inside the default line than as its own process (profiles/README.md, round 5)
+        key = (str(device), main_priority)
+        if key not in _MAIN_STREAMS:
+            _MAIN_STREAMS[key] = torch.cuda.Stream(device=device, priority=main_priority)
+        torch.cuda.set_stream(_MAIN_STREAMS[key])
     events_on = rank == 0 and not args.no_kernel_events
     for s in range(args.warmup):
         if events_on and s == args.warmup - 1:
@@ -479,6 +489,7 @@ def run_workload(args, device, rank: int, world: int, backend, grp: dict, cpu_ba
     return out
 
 
+_MAIN_STREAMS: dict = {}
 ALSO_RUNS = [("config3", dict(config=3, dtype="bf16")), ("config4", dict(config=4, dtype="bf16")),
              ("config2", dict(config=2, dtype="bf16")), ("config1_fp32", dict(config=1, dtype="fp32"))]
 
@@ -528,9 +539,10 @@ def main():
     plain_default = (world == 1 and args.config == 1 and not args.preset_overridden and args.dtype == "bf16" and not args.option
                      and not any((args.no_side_stream, args.null_stream, args.no_overlap_comm, args.force_comm_path, args.all_kernel_events,
                                   args.no_overlap_semantic, args.debug_skip_side, args.no_kernel_events)))
-    if plain_default and not args.no_also and rank == 0:
+    if (plain_default or args.also_list) and not args.no_also and rank == 0 and world == 1:
         also = []
-        for name, kw in ALSO_RUNS:
+        runs = ALSO_RUNS if not args.also_list else [(n, dict(ALSO_RUNS)[n]) for n in args.also_list.split(",")]
+        for name, kw in runs:
             if time.perf_counter() - t_start > 75.0:          # keep the whole default run within ~2 minutes
                 also.append({"workload": name, "skipped": "time box"})
                 continue

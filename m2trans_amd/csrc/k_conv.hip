@@ -1556,9 +1556,95 @@ __global__ void __launch_bounds__(256) final_conv_dgrad_kernel(const float* __re
     store16f(gt + pix * 64 + 16 * g, v);
   }
 }
+// ---------------------------------------------------------------------------------------
+// fp32 tail conv data gradient (+ GELU backward) on the VALU (round 5): K = 27 padded to 32 on exact-fp32 MFMA plus a per-pixel
+// gather loop left the kernel above at 696 us for 2.1 GB of traffic.  Here a wave owns 64 pixels of a row, LANE = PIXEL: the 27
+// gathered gradient values Geff[p][(tap, oc)] are per-lane registers built from 27 coalesced, masked row loads (the reads that reached
+// p through the reflect padding are the column x -+ 1 / row y -+ 1 values already in hand: rows / columns 1 and n - 2 also serve
+// the padded ring), the weights of one input channel are wave-uniform (scalar loads), 27 v_fmac per (pixel, channel); the
+// [pixel][channel] tile turns through LDS (33-float rows, 32 channels at a time) so that gelu'(t) is read and g(t) written as
+// 128-byte row pieces.  Same sums as final_conv_dgrad_kernel in another fp32 order.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) final_conv_dgrad_f32_kernel(const float* __restrict__ gout, const float* __restrict__ w,
+                                                                  const float* __restrict__ der, float* __restrict__ gt, int B, int H,
+                                                                  int W, int nunits) {
+  __shared__ float T[4][64][33];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int u = blockIdx.x * 4 + wv;
+  if (u >= nunits) return;                 // (no workgroup barrier below: the waves are independent)
+  const int segs = (W + 63) >> 6;
+  const int seg = u % segs, q = u / segs, y = q % H, b = q / H;
+  const int x0 = seg << 6, x = x0 + lane;
+  const long long hw = (long long)H * W;
+  // E[row r = y - 1 + j][kx][oc]: the column-combined values of the three source rows (zero outside the image)
+  float E[3][3][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int yy = y - 1 + j;
+    const bool vr = yy >= 0 && yy < H;
+#pragma unroll
+    for (int oc = 0; oc < 3; ++oc) {
+      const float* gr = gout + ((long long)b * 3 + oc) * hw + (long long)(vr ? yy : 0) * W;
+      const float vm = (vr && x - 1 >= 0 && x - 1 < W) ? gr[x - 1] : 0.f;
+      const float v0 = (vr && x < W) ? gr[x] : 0.f;
+      const float vp = (vr && x + 1 < W) ? gr[x + 1] : 0.f;
+      // output column ox = x - kx + 1; x == 1 also serves the padded column -1 (kx = 0 -> ox = 0 = x - 1), x == W - 2 the column W
+      E[j][0][oc] = vp + (x == 1 ? vm : 0.f);
+      E[j][1][oc] = v0;
+      E[j][2][oc] = vm + (x == W - 2 ? vp : 0.f);
+    }
+  }
+  // Geff[ky][kx][oc]: output row oy = y - ky + 1 -> source row index j = 2 - ky; y == 1 also serves the padded row -1 (ky = 0 -> oy = 0),
+  // y == H - 2 the row H (ky = 2 -> oy = H - 1)
+  float G[27];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int oc = 0; oc < 3; ++oc) {
+      G[(0 * 3 + kx) * 3 + oc] = E[2][kx][oc] + (y == 1 ? E[0][kx][oc] : 0.f);
+      G[(1 * 3 + kx) * 3 + oc] = E[1][kx][oc];
+      G[(2 * 3 + kx) * 3 + oc] = E[0][kx][oc] + (y == H - 2 ? E[2][kx][oc] : 0.f);
+    }
+  const long long prow = ((long long)b * H + y) * W + x0;
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll 2
+    for (int icl = 0; icl < 32; ++icl) {
+      const int ic = 32 * half + icl;
+      float sacc = 0.f;
+#pragma unroll
+      for (int oc = 0; oc < 3; ++oc) {
+        const float* wr = w + (oc * 64 + ic) * 9;       // w[oc][ic][tap]: nine contiguous values, wave-uniform
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) sacc = fmaf(G[tap * 3 + oc], wr[tap], sacc);
+      }
+      T[wv][lane][icl] = sacc;
+    }
+    // (one wave writes and reads its own tile: LDS operations of a wave complete in order)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pi = 8 * j + (lane >> 3), c4 = (lane & 7) * 4;
+      if (x0 + pi < W) {
+        const long long off = (prow + pi) * 64 + 32 * half + c4;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(der + off);
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = T[wv][pi][c4 + i] * d[i];
+        *reinterpret_cast<f32x4*>(gt + off) = v;
+      }
+    }
+  }
+}
+
 int launch_final_conv_dgrad(int dt, const float* gout, const float* w, const void* tpre, void* gtpre, int B, int H, int W,
                             hipStream_t st) {
   if (H % FC_T || W % FC_T) return m2t_set_error(-2, "final_conv: H,W must be multiples of 16");
+  if (dt == M2T_F32 && g_m2t_f32_fast && (long long)B * H * W * 64 < (1LL << 31)) {
+    const int nunits = B * H * ((W + 63) / 64);
+    M2T_LAUNCH_TIMED(final_conv_dgrad_f32_kernel, dim3((nunits + 3) / 4), dim3(256), 0, st, gout, w, (const float*)tpre, (float*)gtpre, B, H, W, nunits);
+    M2T_LAUNCH_CHECK();
+    return 0;
+  }
   dim3 grid(W / FC_T, H / FC_T, B);
   if (dt == M2T_F32) M2T_LAUNCH_TIMED(final_conv_dgrad_kernel<float>, grid, dim3(256), 0, st, gout, w, (const float*)tpre, (float*)gtpre, H, W);
   else M2T_LAUNCH_TIMED(final_conv_dgrad_kernel<bf16_t>, grid, dim3(256), 0, st, gout, w, (const bf16_t*)tpre, (bf16_t*)gtpre, H, W);
@@ -1627,6 +1713,82 @@ __global__ void __launch_bounds__(256) final_conv_wgrad_kernel(const float* __re
   }
   if (tid < 5 * 64) out[27 * 64 + tid] = 0.f;
 }
+// ---------------------------------------------------------------------------------------
+// fp32 tail conv weight gradient on the VALU (round 5).  The MFMA kernel above pads the 3 output channels to a 16-row tile: in fp32,
+// where the matrix rate EQUALS the vector rate, 13 of every 16 products are wasted and the kernel sits at its (padded) MFMA bound,
+// 794 us at batch 16 for 1.07 GB of activations.  Here a wave owns 4 output rows x 64 pixels, lane = input channel: the gradient
+// values of a pixel are wave-uniform (scalar loads, SGPR operands of v_fmac), the activation rows are 256-byte coalesced row loads
+// kept in a sliding 6 x 3 register window (1.5 loads per output pixel), 27 accumulators per lane.  Persistent workgroups; the four
+// waves fold through LDS into the slab [32 = tap * 3 + oc | 5 zero rows][64] of final_conv_wgrad_kernel.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) final_conv_wgrad_f32_kernel(const float* __restrict__ gout, const float* __restrict__ act,
+                                                                  float* __restrict__ slabs, int B, int H, int W, int units_per_wave) {
+  __shared__ float R[4][27][64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int segs = (W + 63) >> 6, rgs = H >> 2;
+  const int nunits = B * rgs * segs;
+  const int wave_id = blockIdx.x * 4 + wv;
+  const int u0 = wave_id * units_per_wave, u1 = min(nunits, u0 + units_per_wave);
+  float acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+#pragma unroll 1
+  for (int u = u0; u < u1; ++u) {
+    const int seg = u % segs, q = u / segs, yg = q % rgs, b = q / rgs;
+    const int x0 = seg << 6, x1 = min(W, x0 + 64), y0 = yg << 2;
+    const float* ab = act + (long long)b * H * W * 64 + lane;
+    const float* gb = gout + (long long)b * 3 * H * W + (long long)y0 * W;
+    long long rowo[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) rowo[j] = (long long)reflect_idx(y0 - 1 + j, H) * W * 64;
+    // columns x - 1 .. x + 4 of the six rows; four pixels per iteration (W % 16 == 0: a segment is a whole number of quads), the gradient
+    // values of a quad through one 16-byte scalar load per (row, channel)
+    float c[6][6];
+    {
+      const long long xa = (long long)reflect_idx(x0 - 1, W) * 64, xb = (long long)x0 * 64;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { c[0][j] = ab[rowo[j] + xa]; c[1][j] = ab[rowo[j] + xb]; }
+    }
+#pragma unroll 1
+    for (int x = x0; x < x1; x += 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long xr = (long long)reflect_idx(x + 1 + i, W) * 64;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) c[2 + i][j] = ab[rowo[j] + xr];
+      }
+      f32x4 gq[4][3];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int oc = 0; oc < 3; ++oc) gq[r][oc] = *reinterpret_cast<const f32x4*>(gb + (long long)(oc * H + r) * W + x);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g0 = gq[r][0][i], g1 = gq[r][1][i], g2 = gq[r][2][i];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const float a0 = c[i][r + ky], a1 = c[i + 1][r + ky], a2 = c[i + 2][r + ky];
+            float* ak = &acc[ky * 9];
+            ak[0] = fmaf(g0, a0, ak[0]); ak[1] = fmaf(g1, a0, ak[1]); ak[2] = fmaf(g2, a0, ak[2]);
+            ak[3] = fmaf(g0, a1, ak[3]); ak[4] = fmaf(g1, a1, ak[4]); ak[5] = fmaf(g2, a1, ak[5]);
+            ak[6] = fmaf(g0, a2, ak[6]); ak[7] = fmaf(g1, a2, ak[7]); ak[8] = fmaf(g2, a2, ak[8]);
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { c[0][j] = c[4][j]; c[1][j] = c[5][j]; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) R[wv][k][lane] = acc[k];
+  __syncthreads();
+  float* out = slabs + (long long)blockIdx.x * (32 * 64);
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const int k = i >> 6, c = i & 63;
+    out[i] = (k < 27) ? (R[0][k][c] + R[1][k][c]) + (R[2][k][c] + R[3][k][c]) : 0.f;
+  }
+}
 template <typename T> static size_t final_wgrad_smem() {
   return sizeof(T) * (FC_HPP * FC_LD + 16 * (FC_T * FC_T + 8));
 }
@@ -1637,6 +1799,16 @@ int launch_final_conv_wgrad(int dt, const float* gout, const void* tpre, float* 
   int nblk = (int)std::min<long long>(1024, ntiles);
   const int tpb = (int)ceil_divll(ntiles, nblk);
   nblk = (int)ceil_divll(ntiles, tpb);
+  if (dt == M2T_F32 && g_m2t_f32_fast && H % 4 == 0 && (long long)B * H * W * 64 < (1LL << 31)) {
+    const int nunits = B * (H / 4) * ((W + 63) / 64);
+    int nb = std::min(1024, (nunits + 3) / 4);
+    const int upw = (nunits + nb * 4 - 1) / (nb * 4);
+    nb = (nunits + upw * 4 - 1) / (upw * 4);
+    M2T_LAUNCH_TIMED(final_conv_wgrad_f32_kernel, dim3(nb), dim3(256), 0, st, gout, (const float*)tpre, slabs, B, H, W, upw);
+    M2T_LAUNCH_CHECK();
+    *nslab = nb;
+    return 0;
+  }
   if (dt == M2T_F32) {
     const size_t sh = final_wgrad_smem<float>();
     (void)hipFuncSetAttribute((const void*)final_conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);

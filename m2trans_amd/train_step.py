@@ -34,6 +34,19 @@ def cosine_lr(epoch: int, lr0: float = 1e-4, eta_min: float = 1e-6, t_max: float
     return eta_min + 0.5 * (lr0 - eta_min) * (1.0 + math.cos(math.pi * epoch / t_max))
 
 
+_STREAMS: dict = {}
+
+
+def _shared_stream(device, role: str):
+    """One extra stream per (device, role) for the whole process.  Every HIP stream takes one of the runtime's few hardware queues
+    (4 by default); a process that builds several TrainStep objects one after the other (bench.py's `also` workloads) would otherwise
+    leave a trail of streams behind, and a later plan's main and side stream can end up on the same queue (measured: -10 ... -40 %)."""
+    key = (str(torch.device(device)), role)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=device)
+    return _STREAMS[key]
+
+
 class TrainStep:
     def __init__(self, model: M2Trans, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  lambda_l1: float = 1.0, process_group=None, world_size: Optional[int] = None,
@@ -71,7 +84,7 @@ class TrainStep:
                                  expect_world=self.world_size) if (self.world_size > 1 or force_comm_path) else None
         # overlapped exchange for either wire format (a bf16 wire stages each range through a slice of the wire buffer)
         self.overlap_comm = bool(overlap_comm) and self.bucket is not None
-        self.comm_stream = torch.cuda.Stream(device=flat.device) if self.overlap_comm else None
+        self.comm_stream = _shared_stream(flat.device, "comm") if self.overlap_comm else None
         self._last_plan = None
         # bench.py / audits: with measure_exposed_comm the compute stream's wait for the gradient exchange is bracketed by two
         # timing events per step (exposed_comm_events: [(before, after)]) -- what the exchange costs the step after the overlap
@@ -118,7 +131,7 @@ class TrainStep:
                 main = torch.cuda.current_stream(lr_img.device)
                 if self.sem_stream is None:
                     # (normal priority: PyTorch-ROCm exposes no priority below the default one)
-                    self.sem_stream = torch.cuda.Stream(device=lr_img.device)
+                    self.sem_stream = _shared_stream(lr_img.device, "semantic")
                 self.sem_stream.wait_event(fwd_done)
                 with torch.cuda.stream(self.sem_stream):
                     self.clip_loss = self.semantic_loss.batch(sr, hr_img, captions) * self.lambda_clip

@@ -64,7 +64,7 @@ timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --mast
   echo "config 3: A = default (8-wave forward), B = fused_attn_fwd2 1"; bash tools/ab_opts.sh "--config 3" "--config 3 --option fused_attn_fwd2=1" 3
   echo "config 3: A = default, B = fused_attn_fwd2 2"; bash tools/ab_opts.sh "--config 3" "--config 3 --option fused_attn_fwd2=2" 2
   echo "config 4: A = default, B = fused_attn_fwd2 1"; bash tools/ab_opts.sh "--config 4" "--config 4 --option fused_attn_fwd2=1" 2
-  echo "config 2: A = main priority 0, B = -1 (default with the regulariser)"; bash tools/ab_opts.sh "--config 2 --main-priority 0" "--config 2 --main-priority -1" 2
+  echo "config 2: A = main priority 0 (default), B = -1"; bash tools/ab_opts.sh "--config 2 --main-priority 0" "--config 2 --main-priority -1" 2
   echo "config 2: A = default (encoder beside the backward), B = --no-overlap-semantic"; bash tools/ab_opts.sh "--config 2" "--config 2 --no-overlap-semantic" 2 ) > $O/ab_options.txt 2>&1
 ( echo "A = round-4 final tree (f313e5b: scratch/r4tree, its own bench.py + library), B = this tree; config 1"; bash tools/ab_rounds.sh "--config 1 --steps 30" 3
   echo "config 3"; bash tools/ab_rounds.sh "--config 3 --steps 20" 3
