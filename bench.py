@@ -468,6 +468,7 @@ def run_workload(args, device, rank: int, world: int, backend, grp: dict, cpu_ba
                        "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if backend else "none (single process)",
                        "world_size": grp["pg_ranks"],
                        "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                        "grad_exchange": ("none" if ts.bucket is None else
                                          ("bucketed all-reduce overlapped with backward" if ts.overlap_comm else "one all-reduce after backward")),
                        "stream_priority": main_priority,
@@ -518,6 +519,11 @@ def main():
         raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch one rank per GPU")
     if args.stub_step:
         return stub_main(args, world, rank)
+    if world > 1 or args.force_comm_path:
+        # before the first HIP call: a rank keeps the null stream, the launch stream, the plan's side stream, the communication stream and
+        # RCCL's own streams alive -- more than the runtime's default of four hardware queues, and a launch / side stream pair that shares a
+        # queue loses the overlap of the backward pass (DESIGN.md "Hardware queues are a resource").  A value the caller exported wins.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     backend = None
