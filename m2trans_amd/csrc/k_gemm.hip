@@ -500,6 +500,107 @@ tail_expand_kernel(const T* __restrict__ X, const T* __restrict__ Wp, const floa
     }
   }
 }
+// ---------------------------------------------------------------------------------------
+// fp32 x2 expansion on v_mfma_f32_32x32x2_f32 (round 5; r = 2, image rows of whole 128-pixel tiles).  tail_expand_kernel<float> runs one
+// 4-wave workgroup per CU whose waves alternate between chains of dependent 16x16x4 products and the erf epilogue (792 us for the
+// second expansion at batch 16: 34 GFLOP and 2.4 GB).  Here 8 waves share the CU: the whole 256 x 64 weight matrix and a double-buffered
+// 128-row tile in LDS ([row][64 + 4]), wave (wm, wn) = 32 pixels x the two sub-pixels 2 wn, 2 wn + 1 (four 32 x 32 accumulators), the
+// pixels as the A operand so that a lane ends with ONE channel of 16 pixels: the stores are 128-byte row pieces, the bias is one value
+// per lane and accumulator, and one wave's epilogue runs under the other wave's MFMAs.  GELU and its derivative by the same
+// gelu_erf_both as the kernel above (same values for the same pre-activation; the contraction order differs).
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+tail_expand_f32_kernel(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias, float* __restrict__ Y,
+                       float* __restrict__ Yd, int M, int H, int Wd, int tiles_per_block, int x_p64) {
+  constexpr int LD = 68;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float(*Ws)[LD] = reinterpret_cast<float(*)[LD]>(smem);                                          // [256][68]
+  float(*As)[128][LD] = reinterpret_cast<float(*)[128][LD]>(smem + sizeof(float) * 256 * LD);     // [2][128][68]
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5, wm = wv & 3, wn = wv >> 2;
+  for (int idx = tid; idx < 256 * 16; idx += 512)
+    *reinterpret_cast<f32x4*>(&Ws[idx >> 4][(idx & 15) * 4]) = *reinterpret_cast<const f32x4*>(Wp + (long long)(idx >> 4) * 64 + (idx & 15) * 4);
+  const int ntiles = M >> 7;
+  const int t0 = blockIdx.x * tiles_per_block, t1 = min(ntiles, t0 + tiles_per_block);
+  f32x4 ra[4];
+  auto fetch = [&](int t) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 512;
+      const long long m = (long long)t * 128 + (idx >> 4);
+      const int k = (idx & 15) * 4;
+      ra[it] = *reinterpret_cast<const f32x4*>(X + (x_p64 ? p64(M, m, k) : m * 64 + k));
+    }
+  };
+  if (t0 < t1) fetch(t0);
+  // bias of this lane's channel in each of the wave's four accumulators: block (s, ch) = sub-pixel 2 wn + s, channels 32 ch + li
+  float bv[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) bv[s][ch] = bias[(32 * ch + li) * 4 + 2 * wn + s];
+  int buf = 0;
+  for (int t = t0; t < t1; ++t, buf ^= 1) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + it * 512;
+      *reinterpret_cast<f32x4*>(&As[buf][idx >> 4][(idx & 15) * 4]) = ra[it];
+    }
+    __syncthreads();      // (tile staged; the buffer written next iteration was last read before this barrier; Ws staged on the first pass)
+    if (t + 1 < t1) fetch(t + 1);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s][ch][r] = 0.f;
+    const float* sx = &As[buf][32 * wm + li][4 * lh];
+    const float* sw = &Ws[128 * wn + li][4 * lh];
+    f32x4 xf[2], wf[2][4];
+    xf[0] = *reinterpret_cast<const f32x4*>(sx);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) wf[0][b] = *reinterpret_cast<const f32x4*>(sw + 32 * b * LD);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (q + 1 < 8) {
+        xf[(q + 1) & 1] = *reinterpret_cast<const f32x4*>(sx + 8 * (q + 1));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) wf[(q + 1) & 1][b] = *reinterpret_cast<const f32x4*>(sw + 32 * b * LD + 8 * (q + 1));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) mfma32f(acc[b >> 1][b & 1], xf[q & 1][e], wf[q & 1][b][e]);
+    }
+    // tile = 128 consecutive pixels of ONE image row (Wd % 128 == 0): (b, h, w0) once per tile, wave-uniform
+    const int m0 = t << 7;
+    const int w0 = m0 % Wd, qh = m0 / Wd, h = qh % H, bi = qh / H;
+    const long long rowbase = ((long long)bi * H * 2 + 2 * h) * (2LL * Wd);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int sub = 2 * wn + s, si = sub >> 1, sj = sub & 1;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const float b4[4] = {bv[s][ch], bv[s][ch], bv[s][ch], bv[s][ch]};
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          float a4[4], d4[4];
+          const f32x4 v = (f32x4){acc[s][ch][4 * rq], acc[s][ch][4 * rq + 1], acc[s][ch][4 * rq + 2], acc[s][ch][4 * rq + 3]};
+          gelu_tail_both4<float>(v, b4, a4, d4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int w = w0 + 32 * wm + 8 * rq + 4 * lh + e;           // D row = pixel 8 (r >> 2) + 4 h + (r & 3), col = channel li
+            const long long off = (rowbase + (long long)si * 2 * Wd + 2 * w + sj) * 64 + 32 * ch + li;
+            Y[off] = a4[e];
+            Yd[off] = d4[e];
+          }
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 static int launch_tail_expand_t(const T* X, const T* Wp, const float* bias, T* Y, T* Yd, long long M, int H, int Wd, int r,
                                 bool x_p64, hipStream_t st) {
@@ -529,6 +630,18 @@ int launch_tail_expand(int dt, const void* X, const void* Wp, const float* bias,
     ga.H = H; ga.Wd = Wd; ga.r = r; ga.C = 64;
     ga.Y2 = Yd;
     return launch_gemm_nt(dt, M2T_A_PLAIN, M2T_E_BIAS_SHUF, ga, st);
+  }
+  if (dt == M2T_F32 && g_m2t_f32_fast && r == 2 && Wd % 128 == 0 && M % 128 == 0 && M * 256 < (1LL << 31)) {
+    const int ntiles = (int)(M / 128);
+    int nblk = std::min(ntiles, 256);
+    const int tpb = ceil_div(ntiles, nblk);
+    nblk = ceil_div(ntiles, tpb);
+    const size_t sh = sizeof(float) * (256 + 2 * 128) * 68;
+    if (int rc__ = m2t_ensure_dynamic_lds((const void*)tail_expand_f32_kernel, (int)sh)) return rc__;
+    hipLaunchKernelGGL(tail_expand_f32_kernel, dim3(nblk), dim3(512), sh, st, (const float*)X, (const float*)Wp, bias, (float*)Y, (float*)Yd, (int)M, H, Wd,
+                       tpb, x_p64 ? 1 : 0);
+    M2T_LAUNCH_CHECK();
+    return 0;
   }
   if (dt == M2T_F32) return launch_tail_expand_t<float>((const float*)X, (const float*)Wp, bias, (float*)Y, (float*)Yd, M, H, Wd, r, x_p64, st);
   return launch_tail_expand_t<bf16_t>((const bf16_t*)X, (const bf16_t*)Wp, bias, (bf16_t*)Y, (bf16_t*)Yd, M, H, Wd, r, x_p64, st);
@@ -796,9 +909,13 @@ static int wgrad_big_slabs(long long M, int N, int K, int target = 256) {
 // double-buffered, one barrier per stage.  The contraction runs over the ROW index, so both operands are ds_read_b32 down a column:
 // step s of a stage takes rows 2 s + h.  Same slab contract as wgrad_tn_kernel (slabs of [N][K], rows per slab a multiple of 32).
 // ---------------------------------------------------------------------------------------
+// UNSHUF: G is the pixel-shuffled tensor [B][H r][W r][64], row m = (b, h, w), columns n = sub-pixel * 64 + c (a 64-column tile is one
+// sub-pixel; the tail expansions' weight gradients, gemm_load_a's mapping); XP64: X is a P64 feature map; BIAS: column sums of G
+// (the bias gradient) summed by the staging threads -- a thread always stages the same eight columns -- written by the k0 = 0 tiles.
+template <bool UNSHUF, bool XP64, bool BIAS>
 __global__ void __launch_bounds__(256, 2)
-wgrad_tn_f32_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx, float* __restrict__ slabs, long long M,
-                    int N, int K, long long rows_per_slab) {
+wgrad_tn_f32_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ X, int ldx, float* __restrict__ slabs,
+                    float* __restrict__ bias_slabs, long long M, int N, int K, long long rows_per_slab, ShufGeom sg) {
   constexpr int BR = 32, LD = 160;
   __shared__ __attribute__((aligned(16))) float S[2][BR][LD];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -816,18 +933,32 @@ wgrad_tn_f32_kernel(const float* __restrict__ G, int ldg, const float* __restric
   const int srow = tid >> 3, sv = (tid & 7) * 4;
   const float* pg = G + (mb + srow) * ldg + n0 + sv;
   const float* px = X + (mb + srow) * ldx + k0 + sv;
-  f32x4 rg[4];
+  const int sub = n0 >> 6, si = UNSHUF ? sub / sg.r : 0, sj = UNSHUF ? sub - si * sg.r : 0;
+  f32x4 rg[4], bsum[2];
+  bsum[0] = bsum[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int st) {
     const long long m = mb + (long long)st * BR + srow;
 #pragma unroll
     for (int j = 0; j < 4; ++j) rg[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (m < me) {
       const float* qg = pg + (long long)st * BR * ldg;
-      const float* qx = px + (long long)st * BR * ldx;
+      if constexpr (UNSHUF) {
+        const int mi = (int)m;                              // (the launcher takes this path for M < 2^31 only: 64-bit division is a software loop)
+        const int w = mi % sg.W, q = mi / sg.W;
+        const int h = q % sg.H, b = q / sg.H;
+        const long long pix = ((long long)b * sg.H * sg.r + (h * sg.r + si)) * ((long long)sg.W * sg.r) + (w * sg.r + sj);
+        qg = G + pix * 64 + sv;
+      }
       rg[0] = *reinterpret_cast<const f32x4*>(qg);
       rg[1] = *reinterpret_cast<const f32x4*>(qg + 32);
-      rg[2] = *reinterpret_cast<const f32x4*>(qx);
-      rg[3] = *reinterpret_cast<const f32x4*>(qx + 32);
+      if constexpr (XP64) {
+        rg[2] = *reinterpret_cast<const f32x4*>(X + p64(sg.npix, m, k0 + sv));
+        rg[3] = *reinterpret_cast<const f32x4*>(X + p64(sg.npix, m, k0 + sv + 32));
+      } else {
+        const float* qx = px + (long long)st * BR * ldx;
+        rg[2] = *reinterpret_cast<const f32x4*>(qx);
+        rg[3] = *reinterpret_cast<const f32x4*>(qx + 32);
+      }
     }
   };
   if (nst > 0) fetch(0);
@@ -835,18 +966,19 @@ wgrad_tn_f32_kernel(const float* __restrict__ G, int ldg, const float* __restric
   for (int st = 0; st < nst; ++st, buf ^= 1) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&S[buf][srow][sv + 32 * j]) = rg[j];
+    if constexpr (BIAS) { bsum[0] += rg[0]; bsum[1] += rg[1]; }
     __syncthreads();
     if (st + 1 < nst) fetch(st + 1);
-    const float* sg = &S[buf][lh][32 * wn + li];
+    const float* lg = &S[buf][lh][32 * wn + li];
     const float* sx = &S[buf][lh][64 + 32 * wk + li];
     float gf[2][4], xf[2][4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) { gf[0][s] = sg[2 * s * LD]; xf[0][s] = sx[2 * s * LD]; }
+    for (int s = 0; s < 4; ++s) { gf[0][s] = lg[2 * s * LD]; xf[0][s] = sx[2 * s * LD]; }
 #pragma unroll
     for (int q = 0; q < BR / 8; ++q) {
       if (q + 1 < BR / 8) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { gf[(q + 1) & 1][s] = sg[(8 * (q + 1) + 2 * s) * LD]; xf[(q + 1) & 1][s] = sx[(8 * (q + 1) + 2 * s) * LD]; }
+        for (int s = 0; s < 4; ++s) { gf[(q + 1) & 1][s] = lg[(8 * (q + 1) + 2 * s) * LD]; xf[(q + 1) & 1][s] = sx[(8 * (q + 1) + 2 * s) * LD]; }
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) mfma32f(acc, gf[q & 1][s], xf[q & 1][s]);
@@ -856,6 +988,20 @@ wgrad_tn_f32_kernel(const float* __restrict__ G, int ldg, const float* __restric
   float* out = slabs + (long long)slab * N * K + (long long)(n0 + 32 * wn + 4 * lh) * K + k0 + 32 * wk + li;
 #pragma unroll
   for (int r = 0; r < 16; ++r) out[(long long)(8 * (r >> 2) + (r & 3)) * K] = acc[r];
+  if constexpr (BIAS) {
+    if (bias_slabs != nullptr && k0 == 0) {          // (uniform per workgroup)
+      __syncthreads();
+      float(*Rb)[64] = reinterpret_cast<float(*)[64]>(&S[0][0][0]);          // [32 staging rows][64 columns]
+      *reinterpret_cast<f32x4*>(&Rb[srow][sv]) = bsum[0];
+      *reinterpret_cast<f32x4*>(&Rb[srow][sv + 32]) = bsum[1];
+      __syncthreads();
+      if (tid < 64) {
+        float sum = 0.f;
+        for (int r = 0; r < 32; ++r) sum += Rb[r][tid];
+        bias_slabs[(long long)slab * N + n0 + tid] = sum;
+      }
+    }
+  }
 }
 
 int wgrad_slab_count(long long M, int N, int K) {
@@ -889,13 +1035,21 @@ static int launch_wgrad_tn_t(const m2t_wgrad_args& a, int* nslab_out, hipStream_
   const long long want64 = std::max<long long>(1, 512 / (tn * tk));
   int nslab = (int)std::min<long long>(M2T_MAX_SLABS, std::min<long long>(want64, ceil_divll(a.M, WG_BM)));
   if constexpr (sizeof(T) == 4) {
-    if (g_m2t_f32_fast && a.gmode == M2T_A_PLAIN && a.xmode == M2T_A_PLAIN && !a.bias_slabs && a.ldg > 0 && a.ldx > 0 && a.N % 64 == 0 &&
-        a.K % 64 == 0 && a.ldg % 4 == 0 && a.ldx % 4 == 0) {
+    const bool plain = a.gmode == M2T_A_PLAIN && !a.bias_slabs && a.ldg > 0 && a.ldg % 4 == 0 && a.ldx > 0 && a.ldx % 4 == 0;
+    const bool unshuf = a.gmode == M2T_A_UNSHUF && a.C == 64 && a.N == 64 * a.r * a.r && a.bias_slabs && a.M < (1LL << 31) &&
+                        ((a.ldx > 0 && a.ldx % 4 == 0) || a.ldx == M2T_LD_P64);
+    if (g_m2t_f32_fast && a.xmode == M2T_A_PLAIN && (plain || unshuf) && a.N % 64 == 0 && a.K % 64 == 0) {
       // same slab bound as below (wgrad_slab_count); rows per slab a multiple of the 32-row stage so the slabs balance
       const long long rps32 = ceil_divll(ceil_divll(a.M, nslab), 32) * 32;
       const int ns32 = (int)ceil_divll(a.M, rps32);
-      hipLaunchKernelGGL(wgrad_tn_f32_kernel, dim3(tn * tk * ns32), dim3(256), 0, st, (const float*)a.G, a.ldg, (const float*)a.X, a.ldx,
-                         a.slabs, a.M, a.N, a.K, rps32);
+      ShufGeom sg{a.H, a.Wd, a.r, a.C, a.halo_win, a.M};
+#define GO32(U_, P_, B_)                                                                                                          \
+  hipLaunchKernelGGL((wgrad_tn_f32_kernel<U_, P_, B_>), dim3(tn * tk * ns32), dim3(256), 0, st, (const float*)a.G, a.ldg, (const float*)a.X, \
+                     a.ldx, a.slabs, a.bias_slabs, a.M, a.N, a.K, rps32, sg)
+      if (plain) GO32(false, false, false);
+      else if (a.ldx == M2T_LD_P64) GO32(true, true, true);
+      else GO32(true, false, true);
+#undef GO32
       M2T_LAUNCH_CHECK();
       *nslab_out = ns32;
       return 0;

@@ -1038,13 +1038,18 @@ def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():
                 assert torch.equal(a, b), (B, H, W, n)
 
 
-@pytest.mark.parametrize("scale,B,H,W", [(4, 2, 64, 64), (4, 1, 96, 32), (2, 3, 40, 56)])
+@pytest.mark.parametrize("scale,B,H,W", [(4, 2, 64, 64), (4, 1, 96, 128), (4, 1, 96, 32), (2, 3, 40, 56)])
 def test_fp32_mfma_32x32x2_gemms_match_the_16x16x4_kernels(scale, B, H, W):
-    """fp32 parity mode, option fp32_fast (default): the qkv projections, their data gradients and the qkv weight gradients of the C = 64 and
-    C = 256 branches on v_mfma_f32_32x32x2_f32 (gemm_nt_f32_kernel / wgrad_tn_f32_kernel, k_gemm.hip) against the 16x16x4 kernels of
-    rounds 1-4.  Both are exact fp32 products accumulated in fp32; only the contraction ORDER differs (a fixed permutation of k, other
-    slab boundaries): sr within 2e-6 of its scale, every gradient within 2e-5 of its norm -- far inside the oracle gates of the fp32
-    tests above, which run on the default (fast) path.  Ragged row counts (reflect padding, odd window counts) go through the masked tiles."""
+    """fp32 parity mode, option fp32_fast (default): the kernels of round 5 -- the qkv projections, their data gradients and weight gradients
+    and the x2 expansions (+ their weight / bias gradients) on v_mfma_f32_32x32x2_f32 (k_gemm.hip), the tail conv weight and data gradient
+    on the VALU (k_conv.hip) -- against the 16x16x4 kernels of rounds 1-4.  Both sides are exact fp32 products accumulated in fp32; only the
+    summation ORDER differs.  The loss is a mean squared error, not L1: an L1 seed is sign(sr - hr), and a 1e-7 change of sr flips signs, which
+    says nothing about the kernels.  sr within 2e-6 of its scale; the gradients of the tail, the head and the convs within 3e-5 of their norm;
+    the attention parameters (qkv, rel_h / rel_w) within 3e-3: on these smooth closed-form images their gradients are 1e-7 ... 1e-11 -- sums
+    that cancel almost completely -- so that rounding-order noise shows at 1e-4 ... 6e-4 of them (measured), while a wrong tile, a dropped
+    slab or a wrong index is an O(1) error in the tensor it touches.  The oracle gates of the fp32 tests above run on this default path.
+    Shapes: image rows of 64 / 128 / 256 pixels at the two expansions (the 32x32x2 expansion kernel needs whole 128-pixel tiles per row:
+    both kernels are exercised), reflect padding, odd window counts."""
     from m2trans_amd import _lib
     nb = 2
     x = O.closed_form_image(B, 3, H, W).cuda()
@@ -1056,10 +1061,11 @@ def test_fp32_mfma_32x32x2_gemms_match_the_16x16x4_kernels(scale, B, H, W):
         _lib.check(_lib.load().m2t_set_option(plan.handle, b"fp32_fast", fast), "m2t_set_option")
         assert plan.query("opt:fp32_fast") == fast
         sr = model(x)
-        torch.nn.L1Loss()(sr, hr).backward()
+        ((sr - hr) ** 2).mean().backward()
         outs.append((sr.detach().clone(), {n: q.grad.clone() for n, q in model.named_parameters() if q.requires_grad}))
     (sa, ga), (sb, gb) = outs
     assert float((sa - sb).abs().max()) <= 2e-6 * max(1.0, float(sb.abs().max())), float((sa - sb).abs().max())
     for n in ga:
         d = float((ga[n].double() - gb[n].double()).norm()) / max(float(gb[n].double().norm()), 1e-30)
-        assert d < 2e-5, (n, d)
+        tol = 3e-3 if (".attn" in n) else 3e-5
+        assert d < tol, (n, d)
