@@ -72,9 +72,11 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "fused_l1"          [1] bf16 x4 with the recomputing fused tail backward ("fused_tail" = 2 / 3): a loss requested through m2t_l1_loss_deferred
  *                           is taken inside that kernel (clamp, |sr - hr| partial sums, sign seed on the staged halo); 0 = m2t_backward runs the
  *                           clamp + L1 kernel first (bit-identical gradients either way)
- *   "fp32_fast"         [1] fp32: the plain GEMMs (qkv projections and their data gradients, N % 32 == 0, K % 32 == 0) and the qkv weight
- *                           gradients (N % 64 == 0, K % 64 == 0) on v_mfma_f32_32x32x2_f32 (k_gemm.hip, round 5: exact fp32 products, the
- *                           contraction order is a fixed permutation of k); 0 = the 16x16x4 kernels of rounds 1-4
+ *   "fp32_fast"         [1] fp32: the round-5 kernels of the parity mode -- plain GEMMs (qkv projections and their data gradients, N % 32 == 0,
+ *                           K % 32 == 0), qkv weight gradients (N % 64 == 0, K % 64 == 0), the x2 expansions 64 -> 256 (image rows of whole
+ *                           128-pixel tiles) and their weight / bias gradients on v_mfma_f32_32x32x2_f32 (k_gemm.hip), the 64 -> 3 tail conv
+ *                           weight and data gradient on the VALU (k_conv.hip): exact fp32 products, fp32 accumulation, other summation orders;
+ *                           0 = the 16x16x4 kernels of rounds 1-4
  *   "fused_attn_fwd2"   [0] bf16, C = 256 branches with "fused_prep_fwd": the forward kernels that put TWO windows on a CU (k_attn_fwd2.hip: projection
  *                           in four output-channel chunks, scores / softmax / P in registers, v re-read from L2 for P V, IWT^2 straight from the
  *                           accumulators): 1 = 4-wave workgroups of one window (80 KB of LDS, two per CU), 2 = 8-wave workgroups of two
