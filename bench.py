@@ -38,8 +38,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
-                    help="BASELINE.json configs[i] preset: 1 = x4 128x128 batch 16 L1 only (the headline; default at --gpus 1); "
-                         "2 = x4 batch 32 + MedCLIP regulariser; 3 = x4 batch 32/GPU (256 on 8 GPUs; default at --gpus N > 1); "
+                    help="BASELINE.json configs[i] preset: 1 = x4 128x128 batch 16/GPU L1 only (the headline; default at every --gpus N); "
+                         "2 = x4 batch 32 + MedCLIP regulariser; 3 = x4 batch 32/GPU (256 on 8 GPUs; runs behind the default line in `also`); "
                          "4 = x3 256x256 LR, batch 8/GPU.  --batch / --lr-size / --scale override the preset")
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (configs[1]: 16)")
     ap.add_argument("--lr-size", type=int, default=None)
@@ -68,13 +68,19 @@ def parse():
                     help="default run only: skip the short runs of the other BASELINE workloads that fill the line's `also` list")
     ap.add_argument("--also-steps", type=int, default=6, help="timed steps of each `also` run (>= 5)")
     ap.add_argument("--also-list", default=None, metavar="NAME,NAME", help="which `also` workloads to run and in which order (default: all four; diagnosis)")
+    ap.add_argument("--selftest-shared-device", action="store_true",
+                    help="HARNESS SELF-TEST on a 1-GPU box: the N ranks of --gpus N all compute on device 0 and exchange over gloo, so that the "
+                         "REAL N-rank control flow (headline, extra timing steps, `also` workload, collectives in every step) runs end to end; "
+                         "the line says `invalid` (ranks share a device)")
     ap.add_argument("--stub-step", action="store_true",
                     help="HARNESS SELF-TEST on CPU: run this script's N-rank control flow with gloo and a sleeping stand-in for the step; "
                          "prints an `invalid` line with no throughput")
     args = ap.parse_args()
     # presets = BASELINE.json configs[i]; configs[0] (x2 64x64 CPU forward) is a parity case, not a bench line
     if args.config is None:
-        args.config = 1 if args.gpus == 1 else 3
+        # the SAME per-GPU workload at every N (weak scaling: 16 patches per GPU, BASELINE configs[1]), so that the driver's 1 -> N efficiency
+        # compares like with like; configs[3] (32 per GPU = batch 256 on 8 GPUs) rides along in `also` (all ranks run it behind the headline)
+        args.config = 1
     preset = PRESETS[args.config]
     args.preset_overridden = any(v is not None for v in (args.batch, args.lr_size, args.scale))
     if args.batch is None:
@@ -217,7 +223,7 @@ def launch_ranks(args) -> int:
     JSON line, return the child's status.  The parent stays strictly GPU-free: devices are counted from sysfs, and it refuses
     only when sysfs POSITIVELY reports fewer GPUs than requested."""
     import subprocess
-    if not args.stub_step:
+    if not args.stub_step and not args.selftest_shared_device:
         visible = visible_gpu_count()
         if visible is None:
             print("bench.py: KFD topology not readable, device count unknown: launching the ranks anyway", file=sys.stderr)
@@ -416,21 +422,25 @@ def run_workload(args, device, rank: int, world: int, backend, grp: dict, cpu_ba
                                   + ".  avg_launch_us is the IN-STEP duration (two streams) and agrees with rocprofv3's kernel trace of this command run with "
                                     "--no-kernel-events; inside a rocprofv3 session the event-carrying launches themselves are recorded ~17 us longer "
                                     "(profiles/README.md, round 4), which lifts the average of the summary taken WITH events by ~3 us")
-            if not args.all_kernel_events:
-                # the other categories (side-stream weight-gradient GEMMs included) are timed AFTER the timed region, every launch of
-                # two extra steps, so that the step the value is quoted on carries events on one kernel only
-                m2t_profile.enable(m2t_profile.ALL_MASK, sample_every=1)
-                for s in range(2):
-                    ts.step(*batches[s % 2], captions)
-                torch.cuda.synchronize()
-                full = m2t_profile.roofline_report(B, args.lr_size, args.scale, args.dtype, 2, pmc, source_stamp(), workload=wl, plan=plan)
-                if full is not None:
-                    rows = [{k: full[k] for k in ("category", "bound", "frac", "avg_launch_us", "launches_per_step", "est_ms_per_step", "hbm_GBs", "mfma_TFs")}] + full["others"]
-                    rows = [r for r in rows if r["category"] != roofline["category"]]
-                    rows.sort(key=lambda r: -r["est_ms_per_step"])
-                    roofline["others"] = rows[:5]
-                    roofline["others_timing"] = ("top five other categories by est_ms_per_step; timed on two extra steps behind the timed region with events on "
-                                                 "EVERY dispatch of every category (the all-events mode costs ~8 % of the step and lengthens what it times by a few us)")
+    # The other categories (side-stream weight-gradient GEMMs included) are timed AFTER the timed region, on every launch of two extra
+    # steps, so that the step the value is quoted on carries events on one kernel only.  EVERY rank runs these two steps -- a step contains
+    # the gradient all-reduce, and a collective that only rank 0 enters never returns -- whatever rank 0's report came out as.
+    if not args.no_kernel_events and not args.all_kernel_events:
+        if events_on:
+            m2t_profile.enable(m2t_profile.ALL_MASK, sample_every=1)
+        for s in range(2):
+            ts.step(*batches[s % 2], captions)
+        torch.cuda.synchronize()
+        if events_on and roofline is not None:
+            full = m2t_profile.roofline_report(B, args.lr_size, args.scale, args.dtype, 2, pmc, source_stamp(), workload=wl, plan=plan)
+            if full is not None:
+                rows = [{k: full[k] for k in ("category", "bound", "frac", "avg_launch_us", "launches_per_step", "est_ms_per_step", "hbm_GBs", "mfma_TFs")}] + full["others"]
+                rows = [r for r in rows if r["category"] != roofline["category"]]
+                rows.sort(key=lambda r: -r["est_ms_per_step"])
+                roofline["others"] = rows[:5]
+                roofline["others_timing"] = ("top five other categories by est_ms_per_step; timed on two extra steps behind the timed region with events on "
+                                             "EVERY dispatch of every category (the all-events mode costs ~8 % of the step and lengthens what it times by a few us)")
+    if events_on:
         m2t_profile.enable(0)
     out = {}
     if rank == 0:
@@ -524,19 +534,23 @@ def main():
         # RCCL's own streams alive -- more than the runtime's default of four hardware queues, and a launch / side stream pair that shares a
         # queue loses the overlap of the backward pass (DESIGN.md "Hardware queues are a resource").  A value the caller exported wins.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.selftest_shared_device else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     backend = None
     if world > 1 or (args.force_comm_path and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rank == 0:
             print("bench.py: " + rank_environment(os.environ, world)[1], file=sys.stderr, flush=True)
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.selftest_shared_device:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)     # (RCCL refuses two ranks on one device)
+        else:
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         backend = torch.distributed.get_backend()
         if torch.distributed.get_world_size() != args.gpus and world > 1:
             raise SystemExit(f"process group has {torch.distributed.get_world_size()} ranks, --gpus says {args.gpus}")
-    grp = group_report(local_rank)
-    if world > 1 and len(set(grp["rank_devices"])) != world:
+    grp = group_report(dev_index)
+    if world > 1 and len(set(grp["rank_devices"])) != world and not args.selftest_shared_device:
         raise SystemExit(f"bench.py: ranks share a device: {grp['rank_devices']} (one rank per GPU is the contract)")
 
     t_start = time.perf_counter()
@@ -545,6 +559,24 @@ def main():
     plain_default = (world == 1 and args.config == 1 and not args.preset_overridden and args.dtype == "bf16" and not args.option
                      and not any((args.no_side_stream, args.null_stream, args.no_overlap_comm, args.force_comm_path, args.all_kernel_events,
                                   args.no_overlap_semantic, args.debug_skip_side, args.no_kernel_events)))
+    plain_multi = (world > 1 and args.config == 1 and not args.preset_overridden and args.dtype == "bf16" and not args.option
+                   and not any((args.no_side_stream, args.null_stream, args.no_overlap_comm, args.all_kernel_events, args.no_overlap_semantic,
+                                args.debug_skip_side, args.no_kernel_events)))
+    if plain_multi and not args.no_also:
+        # N > 1: EVERY rank runs configs[3]'s per-GPU share behind the headline (the collectives need all of them); rank 0 reports it
+        a = also_args(args, **dict(ALSO_RUNS)["config3"])
+        try:
+            r = run_workload(a, device, rank, world, backend, grp, cpu_base=False)
+            if rank == 0:
+                roof = r.get("roofline") or {}
+                out["also"] = [{"workload": "config3", "what": r["config"]["workload"], "dtype": r["dtype"], "n_gpus": world,
+                                "global_batch": r["config"]["global_batch"], "per_gpu_batch": r["config"]["per_gpu_batch"], "value": r["value"],
+                                "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"], "warmup": r["warmup"],
+                                "exposed_comm_ms_per_step": r.get("exposed_comm_ms_per_step"),
+                                "dominant_kernel": {k: roof.get(k) for k in ("category", "kernel", "bound", "frac", "avg_launch_us")} if roof else None}]
+        except Exception as e:            # the headline line must not be lost to a failure of the extra workload
+            if rank == 0:
+                out["also"] = [{"workload": "config3", "error": f"{type(e).__name__}: {e}"[:300]}]
     if (plain_default or args.also_list) and not args.no_also and rank == 0 and world == 1:
         also = []
         runs = ALSO_RUNS if not args.also_list else [(n, dict(ALSO_RUNS)[n]) for n in args.also_list.split(",")]
@@ -566,6 +598,9 @@ def main():
                          "others": rf.get("others")})
         out["also"] = also
     if rank == 0:
+        if args.selftest_shared_device:
+            out["invalid"] = True           # harness self-test: the ranks shared one device
+            out["value"] = None
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

@@ -1069,3 +1069,29 @@ def test_fp32_mfma_32x32x2_gemms_match_the_16x16x4_kernels(scale, B, H, W):
         d = float((ga[n].double() - gb[n].double()).norm()) / max(float(gb[n].double().norm()), 1e-30)
         tol = 3e-3 if (".attn" in n) else 3e-5
         assert d < tol, (n, d)
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_control_flow_on_one_device():
+    """`bench.py --gpus 2 --selftest-shared-device`: the REAL N-rank flow of the bench (GPU-free parent -> child torch.distributed.run -> two
+    ranks; headline workload with a collective in every step, the two extra all-event steps that EVERY rank must run, configs[3] behind it in
+    `also`, MAX-over-ranks time, rank-0-only line) with both ranks on device 0 and gloo as the transport, because the boxes of this pool have
+    one GPU.  It cannot price RCCL; it proves that no rank-0-only branch contains a step (a collective only one rank enters never returns --
+    the first version of `roofline.others` had exactly that) and that the line carries the audit fields.  The line says `invalid`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-shared-device", "--steps", "3", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["invalid"] is True and d["value"] is None and d["n_gpus"] == 2 and d["steps"] == 3
+    assert d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo" and d["rank_devices"] == [0, 0]
+    assert d["config"]["per_gpu_batch"] == 16 and d["config"]["global_batch"] == 32          # the headline's per-GPU work at every N
+    assert d["config"]["grad_exchange"].startswith("bucketed all-reduce") and d["exposed_comm_ms_per_step"] is not None
+    assert d["config"]["hw_queues"] == "8"
+    assert d["roofline"] is not None and len(d["roofline"]["others"]) == 5                   # the extra steps ran (on both ranks) and returned
+    (a,) = d["also"]
+    assert a["workload"] == "config3" and a["n_gpus"] == 2 and a["per_gpu_batch"] == 32 and a["global_batch"] == 64 and a["ms_per_step"] > 0
