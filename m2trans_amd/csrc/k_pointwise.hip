@@ -756,13 +756,15 @@ int launch_branch_prep_bwd(int dt, int L, const void* gd, void* gxc, void* gn, i
 // stage 1/2: s1[b,c] = sum_p g_n, s2[b,c] = sum_p g_n*xhat ; stage 3: apply (+ residual grad,
 // the "+ x" of the feed-forward conv, :164)
 // =======================================================================================
-template <typename T>
+template <typename T, int NCG = 8>
 __global__ void __launch_bounds__(256) instnorm_bwd_red1_kernel(const T* __restrict__ gn, const T* __restrict__ x,
                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                 float* __restrict__ part, int P, int nsplit) {
-  // part [B][nsplit][64][2]; the body is shared with c16_dgrad_prep_kernel (m2t_instnorm.h)
+  // part [B][nsplit][64][2]; the body is shared with c16_dgrad_prep_kernel (m2t_instnorm.h).  NCG < 8: the 8 channel groups are split over
+  // gridDim.z = 8 / NCG workgroups (256^2 maps at batch 8 gave only 32 x 8 = 256 workgroups of a pure streaming kernel: 3.4 TB/s).  Which
+  // form runs depends on the IMAGE size only, so an image's sums still do not depend on the batch it is in.
   __shared__ float sh[256][8][2];
-  instnorm_bwd_red1_body<T, 0, 8>(gn, x, mean, rstd, part, P, nsplit, blockIdx.y, blockIdx.x, gridDim.y, sh);
+  instnorm_bwd_red1_body<T, 0, NCG>(gn, x, mean, rstd, part, P, nsplit, blockIdx.y, blockIdx.x, gridDim.y, sh, NCG * (int)blockIdx.z);
 }
 __global__ void __launch_bounds__(64) instnorm_bwd_red2_kernel(const float* __restrict__ part, float* __restrict__ s, int nsplit, float invP) {
   // all 32 partials of a channel are fetched before the first add (one round trip instead of four dependent ones:
@@ -874,6 +876,7 @@ int launch_instnorm_bwd(int dt, const void* gn, const void* x, const float* mean
     return 0;
   }
   if (dt == M2T_F32) hipLaunchKernelGGL(instnorm_bwd_red1_kernel<float>, dim3(nsplit, B), dim3(256), 0, st, (const float*)gn, (const float*)x, mean, rstd, part, P, nsplit);
+  else if (P >= 32768) hipLaunchKernelGGL((instnorm_bwd_red1_kernel<bf16_t, 2>), dim3(nsplit, B, 4), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, part, P, nsplit);
   else hipLaunchKernelGGL(instnorm_bwd_red1_kernel<bf16_t>, dim3(nsplit, B), dim3(256), 0, st, (const bf16_t*)gn, (const bf16_t*)x, mean, rstd, part, P, nsplit);
   M2T_LAUNCH_CHECK();
   hipLaunchKernelGGL(instnorm_bwd_red2_kernel, dim3(B), dim3(64), 0, st, part, s, nsplit, 1.0f / (float)P);

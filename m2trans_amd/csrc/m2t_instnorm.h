@@ -11,12 +11,12 @@
 template <typename T, int CG0, int NCG>
 __device__ __forceinline__ void instnorm_bwd_red1_body(const T* __restrict__ gn, const T* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, float* __restrict__ part, int P, int nsplit, int b,
-                                                       int sp, int nimg, float (*sh)[8][2]) {
+                                                       int sp, int nimg, float (*sh)[8][2], int cg_off = 0) {
   constexpr int NPL = 256 / NCG;                            // pixel lanes (32 for all 64 channels, 42 for the 48 channels of planes 1 .. 3)
   const long long npix = (long long)nimg * P;               // gn, x are P64
   const int tid = threadIdx.x;
   const bool on = tid < NCG * NPL;
-  const int cgp = CG0 + (on ? tid % NCG : 0), pl = on ? tid / NCG : 0;
+  const int cgp = CG0 + cg_off + (on ? tid % NCG : 0), pl = on ? tid / NCG : 0;      // cg_off: this workgroup's first channel group (a launch that splits the channels over gridDim.z)
   const int per = ceil_div(P, nsplit);
   const int p0 = sp * per, p1 = on ? min(P, p0 + per) : 0;
   float mu[8], rs[8], s1[8], s2[8];
@@ -50,7 +50,7 @@ __device__ __forceinline__ void instnorm_bwd_red1_body(const T* __restrict__ gn,
     const int gi = tid >> 3, c = tid & 7;                   // channel group gi of this workgroup, channel c of it
     float a1 = 0.f, a2 = 0.f;
     for (int l = 0; l < NPL; ++l) { a1 += sh[l * NCG + gi][c][0]; a2 += sh[l * NCG + gi][c][1]; }
-    float* o = part + (((long long)b * nsplit + sp) * 64 + (CG0 + gi) * 8 + c) * 2;
+    float* o = part + (((long long)b * nsplit + sp) * 64 + (CG0 + cg_off + gi) * 8 + c) * 2;
     o[0] = a1; o[1] = a2;
   }
 }
