@@ -72,6 +72,9 @@ def parse():
                     help="HARNESS SELF-TEST on a 1-GPU box: the N ranks of --gpus N all compute on device 0 and exchange over gloo, so that the "
                          "REAL N-rank control flow (headline, extra timing steps, `also` workload, collectives in every step) runs end to end; "
                          "the line says `invalid` (ranks share a device)")
+    ap.add_argument("--stub-also-fail-rank", type=int, default=None,
+                    help="with --stub-step: behind the headline run a stand-in `also` workload in which this rank raises before its collective "
+                         "(exercises AlsoWatch: rank 0 still prints the headline, every rank exits 0)")
     ap.add_argument("--stub-step", action="store_true",
                     help="HARNESS SELF-TEST on CPU: run this script's N-rank control flow with gloo and a sleeping stand-in for the step; "
                          "prints an `invalid` line with no throughput")
@@ -293,15 +296,29 @@ def stub_main(args, world: int, rank: int) -> None:
         t = torch.tensor([dt, exposed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, exposed = float(t[0]), float(t[1])
+    line = {}
     if rank == 0:
-        print(json.dumps({"metric": "bench.py control-flow self-test (no GPU work)", "value": None, "invalid": True, "stub": True,
+        line = ({"metric": "bench.py control-flow self-test (no GPU work)", "value": None, "invalid": True, "stub": True,
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * dt / args.steps, 3),
                           "rank0_ms_per_step": round(1000.0 * own / args.steps, 3), "scaling": "weak",
                           "rccl_ranks": grp["rccl_ranks"], "pg_ranks": grp["pg_ranks"], "rank_devices": grp["rank_devices"],
                           "exposed_comm_ms_per_step": round(1000.0 * exposed / args.steps, 3),
                           "config": {"per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
                                      "backend": "gloo", "world_size": dist.get_world_size() if dist.is_initialized() else 1,
-                                     "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}}), flush=True)
+                                     "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}})
+    if args.stub_also_fail_rank is not None and world > 1:
+        # stand-in for the multi-rank `also` workload: one rank raises before the collective the others are already waiting in
+        watch = AlsoWatch(rank, world, line, interval=0.2)
+        try:
+            watch.start()
+            if rank == args.stub_also_fail_rank:
+                raise RuntimeError("stub failure in the extra workload")
+            dist.all_reduce(grad)
+            watch.stop()
+        except Exception as e:
+            watch.fail(f"{type(e).__name__}: {e}")
+    if rank == 0:
+        print(json.dumps(finalize_line(line)), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -505,6 +522,91 @@ ALSO_RUNS = [("config3", dict(config=3, dtype="bf16")), ("config4", dict(config=
              ("config2", dict(config=2, dtype="bf16")), ("config1_fp32", dict(config=1, dtype="fp32"))]
 
 
+def finalize_line(out: dict) -> dict:
+    """Key order of the printed line.  The driver's record keeps the parsed contract keys and the LAST 2 000 characters of the line:
+    the long per-workload tables (`also`, with their `others` lists) go in front, and the line ends with `also_summary` -- every extra
+    workload's value / ms_per_step / dominant category / frac in < 600 characters -- followed by `cpu_baseline`."""
+    also = out.get("also")
+    tail_keys = ("also_summary", "cpu_baseline")
+    res = {k: v for k, v in out.items() if k not in tail_keys and k != "also"}
+    if also is not None:
+        res["also"] = also
+        summ = {}
+        for e in also:
+            if "value" in e:
+                dk = e.get("dominant_kernel") or {}
+                summ[e["workload"]] = [e["value"], e["ms_per_step"], dk.get("category"), dk.get("frac")]
+            else:
+                summ[e["workload"]] = (e.get("error") or e.get("skipped") or "no result")[:60]
+        res["also_summary"] = {"columns": ["value (HR patches/s)", "ms_per_step", "dominant category", "frac"], **summ}
+    if "cpu_baseline" in out:
+        res["cpu_baseline"] = out["cpu_baseline"]
+    return res
+
+
+class AlsoWatch:
+    """Failure agreement for the multi-rank `also` workload.  While it runs, a thread on every rank polls the process group's store
+    for a failure flag; `fail()` sets the flag.  Whoever sees it (or sets it): rank 0 prints the headline line with the error,
+    everyone leaves through os._exit(0) -- a rank blocked inside a collective cannot be unblocked any other way."""
+    KEY = "m2t_also_failed"
+
+    def __init__(self, rank: int, world: int, headline: dict, interval: float = 0.5):
+        import threading
+        self.rank, self.world, self.headline, self.interval = rank, world, headline, interval
+        self.store = None
+        self._stop = threading.Event()
+        self._thread = None
+        self._once = threading.Lock()
+        if world > 1 and torch.distributed.is_initialized():
+            try:
+                from torch.distributed.distributed_c10d import _get_default_store
+                self.store = _get_default_store()
+            except Exception:
+                self.store = None
+
+    def _leave(self, msg: str):
+        if not self._once.acquire(blocking=False):
+            return
+        if self.rank == 0:
+            line = dict(self.headline)
+            line["also"] = [{"workload": "config3", "error": msg[:300]}]
+            print(json.dumps(finalize_line(line)), flush=True)
+        sys.stderr.write(f"bench.py rank {self.rank}: extra workload abandoned ({msg[:200]})\n")
+        sys.stderr.flush()
+        os._exit(0)
+
+    def _poll(self):
+        while not self._stop.wait(self.interval):
+            try:
+                if self.store.check([self.KEY]):
+                    self._leave(self.store.get(self.KEY).decode(errors="replace"))
+            except Exception as e:                      # the store went away with the rank that hosted it: nobody is left to wait for
+                if not self._stop.is_set():
+                    self._leave(f"rendezvous store unreachable ({type(e).__name__})")
+                return
+
+    def start(self):
+        import threading
+        if self.store is None:
+            return
+        self._thread = threading.Thread(target=self._poll, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+
+    def fail(self, msg: str):
+        self._stop.set()
+        if self.store is None:
+            return
+        try:
+            self.store.set(self.KEY, f"rank {self.rank}: {msg}")
+        except Exception:
+            return
+        time.sleep(2 * self.interval)       # let the other ranks read the flag before the store's owner may go away
+        self._leave(f"rank {self.rank}: {msg}")
+
+
 def also_args(args, config: int, dtype: str):
     """The argument set of one `also` run: the preset of BASELINE configs[config] at `dtype`, few steps, default options."""
     import copy
@@ -563,10 +665,16 @@ def main():
                    and not any((args.no_side_stream, args.null_stream, args.no_overlap_comm, args.all_kernel_events, args.no_overlap_semantic,
                                 args.debug_skip_side, args.no_kernel_events)))
     if plain_multi and not args.no_also:
-        # N > 1: EVERY rank runs configs[3]'s per-GPU share behind the headline (the collectives need all of them); rank 0 reports it
+        # N > 1: EVERY rank runs configs[3]'s per-GPU share behind the headline (the collectives need all of them); rank 0 reports it.
+        # A rank that raises inside it (out of memory, a plan error) leaves the others blocked in a collective it never enters: every
+        # rank therefore watches the rendezvous store while the extra workload runs (AlsoWatch), and when ANY rank has failed rank 0
+        # prints the headline line -- complete, with the failure under `also` -- and every rank leaves at once with status 0.
         a = also_args(args, **dict(ALSO_RUNS)["config3"])
+        watch = AlsoWatch(rank, world, out)
         try:
+            watch.start()
             r = run_workload(a, device, rank, world, backend, grp, cpu_base=False)
+            watch.stop()
             if rank == 0:
                 roof = r.get("roofline") or {}
                 out["also"] = [{"workload": "config3", "what": r["config"]["workload"], "dtype": r["dtype"], "n_gpus": world,
@@ -575,6 +683,7 @@ def main():
                                 "exposed_comm_ms_per_step": r.get("exposed_comm_ms_per_step"),
                                 "dominant_kernel": {k: roof.get(k) for k in ("category", "kernel", "bound", "frac", "avg_launch_us")} if roof else None}]
         except Exception as e:            # the headline line must not be lost to a failure of the extra workload
+            watch.fail(f"{type(e).__name__}: {e}"[:300])          # (does not return when other ranks may be inside a collective)
             if rank == 0:
                 out["also"] = [{"workload": "config3", "error": f"{type(e).__name__}: {e}"[:300]}]
     if (plain_default or args.also_list) and not args.no_also and rank == 0 and world == 1:
@@ -603,7 +712,7 @@ def main():
             out["value"] = None
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(finalize_line(out)), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

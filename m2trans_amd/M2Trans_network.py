@@ -20,6 +20,9 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading
+import warnings
+import weakref
 from collections import OrderedDict
 from typing import Dict, List, Tuple
 
@@ -58,6 +61,7 @@ class Plan:
             self.B, self.H0, self.W0, self.scale, self.n_blocks, self.dtype = B, H0, W0, scale, n_blocks, dtype
             self.device = device
             self.gen = 0
+            self.trained = False         # a backward pass has run on this plan: the LRU keeps it while forward-only plans remain
             nbytes = self.query("workspace_bytes")
             self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
             _lib.check(lib.m2t_plan_init_workspace(self.handle, _lib.ptr(self.workspace), _lib.stream_ptr()),
@@ -124,8 +128,35 @@ class _M2TransFunction(torch.autograd.Function):
             grads = torch.empty_like(model.flat_params)
             _lib.check(lib.m2t_backward(plan.handle, _lib.ptr(model.flat_params), _lib.ptr(x), _lib.ptr(grads),
                                         _lib.ptr(plan.workspace), st), "m2t_backward")
+        plan.trained = True
+        if model._dp_master is not None:
+            model._dp_release()
         outs = [grads[o: o + n].view(s) for (o, n, s) in model._slots]
         return (None, None, *outs)
+
+
+class _ReplicaState:
+    """What one nn.DataParallel replica needs on ITS device and cannot share: the flat fp32 copy of the parameters the
+    kernels read and the plans (workspaces with the saved activations).  Owned by the master module, handed to the
+    short-lived replica objects DataParallel builds every forward, returned when the replica (and the autograd node that
+    holds it) is gone."""
+
+    def __init__(self, device, numel: int):
+        self.device = device
+        self.flat = torch.empty(numel, dtype=torch.float32, device=device)
+        self.plans: "OrderedDict[Tuple, Plan]" = OrderedDict()
+        self.busy = False
+        self.owner = None                # token of the replica that holds the state (a late finalizer must not free a re-issued state)
+
+
+def _release_replica_state(state: _ReplicaState, lock: threading.Lock, token) -> None:
+    with lock:
+        if state.owner is token:
+            state.owner = None
+            state.busy = False
+
+
+_DP_WARNED = False
 
 
 class M2Trans(nn.Module):
@@ -143,6 +174,11 @@ class M2Trans(nn.Module):
         cd = getattr(args, "compute_dtype", None) or os.environ.get("M2T_COMPUTE_DTYPE", "fp32")
         self.compute_dtype = str(cd)
         self._plans: "OrderedDict[Tuple, Plan]" = OrderedDict()
+        self._dp_master = None                       # set on the replicas nn.DataParallel makes of this module
+        self._dp_params = None
+        self._dp_release = None
+        self._dp_pool: Dict[int, List[_ReplicaState]] = {}
+        self._dp_lock = threading.Lock()
         self._build_parameters(n_feats)
         self._flatten()
 
@@ -234,6 +270,75 @@ class M2Trans(nn.Module):
         self._names = [n for n, _ in named]
         self.flat_grads = None
         self._plans = OrderedDict()
+        self._dp_pool = {}
+
+    # ------------------------------------------------------------------ nn.DataParallel over more than one device
+    def _replicate_for_data_parallel(self):
+        """``nn.DataParallel(model)`` (train.py:73, test.py:68) on a node with SEVERAL visible GPUs replicates the module every
+        forward (``torch.nn.parallel.replicate``): the replica is a shallow copy whose parameters are broadcast copies set as
+        plain attributes.  A replica of THIS module additionally needs its own flat parameter buffer and plans on its device
+        (the master's live on ``device_ids[0]``): they are bound in ``forward`` from a per-device pool the master owns, so the
+        unchanged reference script runs on all devices -- one Python thread per replica, parameters broadcast and gradients
+        reduced to device 0 by DataParallel every step, exactly the reference's mechanism and its cost.  The fast path on a
+        multi-GPU node is one process per GPU (``python -m torch.distributed.run --nproc-per-node N``; ``TrainStep`` /
+        ``m2trans_amd.dist``): a one-time warning says so.  ``M2T_DATA_PARALLEL=error`` turns the warning into an M2TError."""
+        global _DP_WARNED
+        mode = os.environ.get("M2T_DATA_PARALLEL", "replicate")
+        msg = ("nn.DataParallel is replicating M2Trans over several devices: every step broadcasts the parameters and "
+               "reduces the gradients through device 0 from Python threads of ONE process (the reference's train.py:73 "
+               "mechanism).  For full speed launch one process per GPU instead: python -m torch.distributed.run "
+               "--nproc-per-node <N> with m2trans_amd.train_step.TrainStep (RCCL all-reduce of the flat gradient buffer), or "
+               "restrict this process to one device (nn.DataParallel(model, device_ids=[0]) / HIP_VISIBLE_DEVICES).")
+        if mode == "error":
+            raise M2TError(msg)
+        if not _DP_WARNED:
+            _DP_WARNED = True
+            warnings.warn(msg, stacklevel=3)
+        replica = super()._replicate_for_data_parallel()
+        replica._dp_master = self
+        replica._dp_params = None
+        replica._dp_release = None
+        replica.flat_params = None          # bound to this replica's device in forward()
+        replica.flat_grads = None
+        replica._plans = None
+        return replica
+
+    def _bind_replica(self, x: torch.Tensor) -> None:
+        """First use of a DataParallel replica (its device is only known now): take a free state of x.device from the master's
+        pool, gather the broadcast parameter copies into that state's flat buffer (ONE cat: 14.5 MB), serve plans from it."""
+        if self.flat_params is not None:
+            return
+        master = self._dp_master
+        if not x.is_cuda:
+            raise M2TError("M2Trans (MI355X build) runs only on a HIP device tensor; there is no CPU fallback")
+        params = []
+        for n in master._names:
+            obj = self
+            for part in n.split("."):
+                obj = getattr(obj, part)
+            if obj.device != x.device:
+                raise M2TError(f"DataParallel replica: parameter {n} is on {obj.device}, the replica's input on {x.device}")
+            params.append(obj)
+        dev = x.device.index
+        with master._dp_lock:
+            pool = master._dp_pool.setdefault(dev, [])
+            state = next((s for s in pool if not s.busy), None)
+            if state is None:
+                state = _ReplicaState(x.device, master.flat_params.numel())
+                pool.append(state)
+            state.busy = True
+            token = state.owner = object()
+        # The state returns to the pool as soon as nothing needs its workspace any more: behind a no-grad forward, or behind the backward
+        # pass of this replica's autograd node (work enqueued later on the stream is ordered behind it, as for the master's own plan; a
+        # second backward through a retained graph then fails the plan-generation check instead of reading overwritten activations).
+        # The finalizer covers replicas whose graph is dropped without a backward.
+        self._dp_release = lambda: _release_replica_state(state, master._dp_lock, token)
+        weakref.finalize(self, _release_replica_state, state, master._dp_lock, token)
+        with torch.no_grad():
+            torch.cat([p.detach().reshape(-1) for p in params], out=state.flat)
+        self.flat_params = state.flat
+        self._plans = state.plans
+        self._dp_params = params
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -316,8 +421,14 @@ class M2Trans(nn.Module):
             self._plans[key] = plan
             # least-recently-used plans go first; a plan whose backward is still pending is kept alive by its autograd node
             # (ctx.plan), only the cache entry is dropped
+            # Plans that have run a backward pass (the training shape: rebuilding it costs a workspace allocation, the descriptor
+            # uploads and a first_backward pass) go only when nothing else is left: a validation sweep over many image sizes
+            # (test.py:77-122 between epochs) evicts among ITS OWN forward-only plans.
             while len(self._plans) > max(1, PLAN_CACHE_SIZE):
-                self._plans.popitem(last=False)
+                victim = next((k for k, pl in self._plans.items() if not getattr(pl, "trained", False) and k != key), None)
+                if victim is None:
+                    victim = next(k for k in self._plans if k != key)
+                del self._plans[victim]
         else:
             self._plans.move_to_end(key)
         return plan
@@ -335,11 +446,18 @@ class M2Trans(nn.Module):
         return sr
 
     def forward(self, x):
-        plan_needed_grad = torch.is_grad_enabled() and any(p.requires_grad for _, p in self._trainable())
-        if plan_needed_grad:
+        if self._dp_master is not None:                      # a replica made by nn.DataParallel: bind its device state first
+            self._bind_replica(x)
+            params = self._dp_params
+        else:
             params = [p for _, p in self._trainable()]
+        plan_needed_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if plan_needed_grad:
             return _M2TransFunction.apply(x, self, *params)
-        return self._run_forward(self._plan_for(x), x, keep=False)
+        sr = self._run_forward(self._plan_for(x), x, keep=False)
+        if self._dp_master is not None:
+            self._dp_release()
+        return sr
 
     def check_image_size(self, x):
         """Kept for API parity (models/M2Trans_network.py:78-86); the kernels pad by index math."""

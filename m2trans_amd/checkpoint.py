@@ -94,6 +94,12 @@ def import_checkpoint(ckpt: dict, model, train_step=None) -> int:
             train_step.exp_avg_sq[o:o + k].copy_(s["exp_avg_sq"].reshape(-1).to(train_step.exp_avg_sq))
             step = int(float(s["step"]))
         train_step.step_count = step
+    else:
+        # a resume checkpoint written before the first optimizer step: optimizer.load_state_dict (train.py:101) would leave an EMPTY
+        # Adam state, i.e. zero moments and step 0 -- not whatever this TrainStep accumulated before the load
+        train_step.exp_avg.zero_()
+        train_step.exp_avg_sq.zero_()
+        train_step.step_count = 0
     pg = opt.get("param_groups")
     if pg:
         train_step.set_lr(pg[0]["lr"])

@@ -242,7 +242,8 @@ struct m2t_plan {
   ~m2t_plan() {
     for (auto e : events) if (e) (void)hipEventDestroy(e);
     for (auto e : bucket_events) if (e) (void)hipEventDestroy(e);
-    if (side) (void)hipStreamDestroy(side);
+    // the caller releases the workspace right after this: nothing of the plan's own stream may still be running in it
+    if (side) { (void)hipStreamSynchronize(side); (void)hipStreamDestroy(side); }
   }
 
   void add_param(const std::string& n, long long cnt) { pnames.push_back(n); poff[n] = nparams; pnum[n] = cnt; nparams += cnt; }
@@ -803,17 +804,19 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
   void* g_last = (s == 4) ? WSP("g_t2pre") : WSP("g_t1pre");
   const bool skip = p->debug_skip_side;
   hipStream_t tws = sd;      // tail weight gradients: side stream (same-box A/B: +0.5 % over the main stream)
-  fork();
-  hipEvent_t im2col_done = nullptr;           // head_cols is produced on the side stream; the head weight gradient may run on the main one
-  if (!skip) { CK(launch_head_im2col(dt, x, WSP("head_cols"), B, p->H0, p->W0, H, W, sd)); im2col_done = side_marker(); }
   const bool fused_tail = p->use_fused_tail_bwd && s == 4 && dt != M2T_F32;
   const bool stream_x23 = p->stream_tail_x23();
   // a deferred L1 loss (m2t_l1_loss_deferred): inside the fused tail backward where that kernel runs in its recomputing form,
-  // otherwise by m2t_l1_loss's own kernel, here, in front of everything that reads the seed
+  // otherwise by m2t_l1_loss's own kernel, here -- on the main stream IN FRONT OF THE FIRST FORK: on the unfused tail path the tail
+  // conv's weight gradient reads the seed on the side stream, which only orders itself behind what the fork event covers (round 5
+  // enqueued it behind the fork: the side stream could read gpre while it was being written, or the previous step's seed)
   const bool l1_in_tail = p->l1_deferred && p->use_fused_l1 && fused_tail && p->use_fused_tail_fwd && !(p->use_stream_tail_bwd && p->use_fused_tail_fwd);
   if (p->l1_deferred && !l1_in_tail)
     CK(launch_clamp_l1((const float*)WSP("srpre"), p->l1_hr, nullptr, (float*)WSP("gpre"), (float*)WSP("loss_part"), p->l1_loss_out,
                        p->B, p->Hsp, p->Wsp, p->Hs, p->Ws, p->l1_R, p->l1_sc, p->l1_sc, st));
+  fork();
+  hipEvent_t im2col_done = nullptr;           // head_cols is produced on the side stream; the head weight gradient may run on the main one
+  if (!skip) { CK(launch_head_im2col(dt, x, WSP("head_cols"), B, p->H0, p->W0, H, W, sd)); im2col_done = side_marker(); }
   if (stream_x23) {
     // x2 / x3: the whole tail backward in one row-streaming launch (k_tail_bwd_stream.hip): g(body output) straight into gT
     const int N0 = 64 * r0 * r0;

@@ -57,6 +57,22 @@ class TransBlock(nn.Module):
         self.compute_dtype = compute_dtype
         self._ws = None
 
+    def invalidate(self) -> None:
+        """Drop the cached flat parameter vector (call after writing parameters through ``.data``)."""
+        self._flat_key = None
+
+    def _apply(self, fn, *a, **k):
+        self._flat_key = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._flat_key = None
+        return super().load_state_dict(*a, **k)
+
+    def train(self, mode: bool = True):
+        self._flat_key = None
+        return super().train(mode)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.device.type != "cuda":
             raise M2TError("TransBlock (MI355X build): needs a HIP device tensor; there is no CPU fallback")
@@ -70,11 +86,16 @@ class TransBlock(nn.Module):
         xc = x.detach().contiguous().float()
         # the 22 928 parameters as one fp32 device vector in state_dict order: rebuilt only when a parameter changed (in-place
         # version counters) or moved, not on every forward
+        # Contract: the cache is trusted only in eval mode under no_grad (inference loops); while the module trains or autograd is on
+        # the vector is rebuilt on every call (one cat of 16 small tensors), because writes through ``p.data`` (EMA, weight clipping,
+        # legacy loaders) do not bump the version counters the key is made of.  ``_apply`` (.to / .cuda / .half), ``load_state_dict``
+        # and ``train()`` / ``eval()`` drop it; ``invalidate()`` does so explicitly.
         vals = list(self.state_dict().values())
         key = (str(x.device),) + tuple((v.data_ptr(), v._version) for v in vals)
-        if getattr(self, "_flat_key", None) != key:
+        trust = (not self.training) and (not torch.is_grad_enabled())
+        if not trust or getattr(self, "_flat_key", None) != key:
             self._flat = torch.cat([v.detach().reshape(-1).float() for v in vals]).to(x.device).contiguous()
-            self._flat_key = key
+            self._flat_key = key if trust else None
         flat = self._flat
         if flat.numel() != 22928:
             raise M2TError("TransBlock: unexpected parameter count")

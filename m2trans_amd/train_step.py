@@ -110,6 +110,7 @@ class TrainStep:
         use_clip = self.semantic_loss is not None and self.lambda_clip > 0 and captions is not None
         sr = torch.empty_like(hr_img) if use_clip else None
         plan.gen += 1
+        plan.trained = True              # (the plan LRU of the model keeps training plans while forward-only ones remain)
         self._last_plan = plan
         with torch.cuda.device(lr_img.device):
             st = _lib.stream_ptr()

@@ -125,3 +125,42 @@ def test_plan_cache_is_a_small_lru(monkeypatch):
     assert first_alive in [p.key for p in m._plans.values()]
     assert (1, 32 + 4, 32) not in [p.key for p in m._plans.values()]
     assert len(FakePlan.made) == n_made + 1 and len(m._plans) == cap
+
+
+def test_plan_cache_keeps_the_training_plan_through_a_validation_sweep(monkeypatch):
+    """A validation pass over more than PLAN_CACHE_SIZE distinct image sizes (test.py:77-122 between epochs) must not evict the plan
+    the train step runs on (rebuilding it = a workspace allocation, the descriptor uploads and a first-backward pass every epoch):
+    plans that have run a backward go only when no forward-only plan is left."""
+    from m2trans_amd import M2Trans_network as N
+
+    class FakePlan:
+        def __init__(self, B, H0, W0, scale, n_blocks, dtype, device):
+            self.key = (B, H0, W0)
+            self.trained = False
+
+    monkeypatch.setattr(N, "Plan", FakePlan)
+    monkeypatch.setattr(N.M2Trans, "_check_plan", lambda self, plan: None)
+    monkeypatch.setattr(N.M2Trans, "_device_ok", lambda self, x: None)
+    m = N.M2Trans(types.SimpleNamespace(n_feats=64, scale=4, rgb_range=1.0, n_blocks=1, colors=3))
+
+    class X:
+        is_cuda = True
+
+        def __init__(self, B, H, W, dev):
+            self.shape = (B, 3, H, W)
+            self.device = dev
+
+        def dim(self):
+            return 4
+
+    dev = m.flat_params.device
+    train = m._plan_for(X(16, 128, 128, dev))
+    train.trained = True                                    # what TrainStep.forward_backward / the autograd node set
+    for i in range(3 * N.PLAN_CACHE_SIZE):
+        m._plan_for(X(1, 33 + i, 47, dev))
+    assert m._plan_for(X(16, 128, 128, dev)) is train and len(m._plans) == N.PLAN_CACHE_SIZE
+    # when every cached plan has trained, the least recently used one goes after all
+    for pl in m._plans.values():
+        pl.trained = True
+    m._plan_for(X(2, 64, 64, dev))
+    assert len(m._plans) == N.PLAN_CACHE_SIZE

@@ -326,6 +326,99 @@ def test_checkpoint_without_scheduler_state_is_a_pretrain_load_or_an_error():
     assert torch.equal(fs3.exp_avg, before) and fs3.step_count == 7     # nothing half-restored
 
 
+def test_resume_checkpoint_saved_before_the_first_optimizer_step_resets_the_moments():
+    """A resume checkpoint with scheduler state and param_groups but an EMPTY Adam state (train.py:341-349 called before any
+    optimizer.step): optimizer.load_state_dict (train.py:101) leaves zero moments and step 0 -- the importing TrainStep must not keep
+    whatever it had accumulated before the load (round-5 advisor finding)."""
+    from m2trans_amd.M2Trans_network import create_model
+    from m2trans_amd.checkpoint import export_checkpoint, import_checkpoint
+    m = create_model(_args(4, 1))
+    ck = export_checkpoint(m, _FakeStep(m, step_count=0, lr=3e-5), epoch=2)
+    assert ck["optimizer_state_dict"]["state"] == {} and ck["optimizer_state_dict"]["param_groups"]
+    m2 = create_model(_args(4, 1))
+    fs2 = _FakeStep(m2, step_count=11)                      # stale moments of an earlier run
+    assert float(fs2.exp_avg.abs().max()) > 0
+    assert import_checkpoint(ck, m2, fs2) == 3
+    assert fs2.step_count == 0 and fs2.lr == 3e-5 and fs2.scheduler_last_epoch == 1
+    assert float(fs2.exp_avg.abs().max()) == 0.0 and float(fs2.exp_avg_sq.abs().max()) == 0.0
+
+
+def test_data_parallel_replica_surface_without_a_gpu(monkeypatch):
+    """nn.DataParallel over several devices (the unchanged train.py:73 on a multi-GPU node) calls _replicate_for_data_parallel on the
+    module every forward.  Defined behaviour, checked here without a GPU: the replica is marked, owns no flat buffer / plans of the
+    master (they are bound per device in forward), a one-time warning names the fast path (torch.distributed.run), M2T_DATA_PARALLEL=error
+    turns it into an M2TError, and a replica -- like the master -- refuses a CPU tensor (no CPU fallback)."""
+    import warnings
+    from m2trans_amd import M2Trans_network as N
+    from m2trans_amd._lib import M2TError
+    m = N.create_model(_args(4, 1))
+    monkeypatch.setattr(N, "_DP_WARNED", False)
+    monkeypatch.delenv("M2T_DATA_PARALLEL", raising=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        r = m._replicate_for_data_parallel()
+        r2 = m._replicate_for_data_parallel()
+    assert len(w) == 1 and "torch.distributed.run" in str(w[0].message)          # once per process
+    assert r._dp_master is m and r.flat_params is None and r._plans is None and r is not r2
+    assert m._dp_master is None and m.flat_params is not None                     # the master is untouched
+    assert list(r.named_parameters(recurse=False)) == []                          # torch's replica contract
+    with pytest.raises(M2TError, match="no CPU fallback"):
+        r(torch.zeros(1, 3, 32, 32))
+    monkeypatch.setenv("M2T_DATA_PARALLEL", "error")
+    with pytest.raises(M2TError, match="torch.distributed.run"):
+        m._replicate_for_data_parallel()
+
+
+def test_bench_line_ends_with_the_compact_summary_and_the_cpu_baseline():
+    """The driver's record keeps the last 2 000 characters of the line: `also_summary` (< 600 characters: every extra workload's value,
+    ms_per_step, dominant category, frac) and `cpu_baseline` are the LAST keys, the long tables come first."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    others = [{"category": f"c{i}", "bound": "hbm", "frac": 0.25, "avg_launch_us": 30.0, "launches_per_step": 8, "est_ms_per_step": 0.5,
+               "hbm_GBs": 2000.0, "mfma_TFs": 100.0} for i in range(5)]
+    also = [{"workload": n, "what": "x" * 120, "dtype": "bf16", "value": 1234.567, "unit": "HR patches/s", "ms_per_step": 8.123, "steps": 6, "warmup": 2,
+             "per_gpu_batch": 32, "final_loss": 0.4, "dominant_kernel": {"category": "attn_bwd_c256", "kernel": "k", "bound": "hbm", "frac": 0.2712,
+                                                                        "avg_launch_us": 70.0}, "others": others}
+            for n in ("config3", "config4", "config2")] + [{"workload": "config1_fp32", "error": "RuntimeError: " + "y" * 200}]
+    out = {"metric": "m", "value": 1.0, "cpu_baseline": {"value": 1.63, "unit": "HR patches/s", "cores": 16, "kind": "port", "sample": "s" * 120},
+           "roofline": {"frac": 0.29}, "also": also}
+    line = bench.finalize_line(out)
+    keys = list(line.keys())
+    assert keys[-2:] == ["also_summary", "cpu_baseline"] and keys.index("also") < keys.index("also_summary")
+    summ = json.dumps(line["also_summary"])
+    assert len(summ) < 600, len(summ)
+    assert line["also_summary"]["config3"] == [1234.567, 8.123, "attn_bwd_c256", 0.2712]
+    assert line["also_summary"]["config1_fp32"].startswith("RuntimeError")
+    tail = json.dumps(line)[-2000:]
+    for n in ("config3", "config4", "config2", "config1_fp32", "cpu_baseline"):
+        assert f'"{n}"' in tail
+    assert bench.finalize_line({"metric": "m", "cpu_baseline": {"v": 1}}) == {"metric": "m", "cpu_baseline": {"v": 1}}
+
+
+@pytest.mark.parametrize("fail_rank", [1, 0])
+def test_bench_extra_workload_failure_on_one_rank_does_not_hang_the_others(fail_rank):
+    """Multi-rank `also` run (round-5 advisor finding): a rank that raises before a collective leaves the others blocked in it.  With
+    AlsoWatch every rank polls the rendezvous store; rank 0 still prints the ONE headline line (the failure under `also`), all ranks
+    exit 0.  Exercised on two gloo ranks with the stub step; the failing rank is rank 1, then rank 0."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-step",
+                        "--stub-also-fail-rank", str(fail_rank)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3
+    assert d["also"][0]["workload"] == "config3" and f"rank {fail_rank}" in d["also"][0]["error"] and "stub failure" in d["also"][0]["error"]
+    assert list(d.keys())[-1] == "also_summary" and "stub failure" in d["also_summary"]["config3"]
+    assert "extra workload abandoned" in r.stderr
+
+
 def test_checkpoint_matches_the_reference_manifest(golden_dir):
     """export_checkpoint against the manifest of what the REAL reference saves (DataParallel model + torch.optim.Adam +
     CosineAnnealingLR run through two epochs, oracle/pin_against_reference.py section 10): same keys at every level,
@@ -546,6 +639,14 @@ def test_every_plan_option_is_documented_in_the_header_and_readable():
         assert re.search(r'\*\s+"%s"\s+\[-?\d+\]' % k, hdr), f"option {k} is not documented (with its default) in include/m2t.h"
         if k != "debug_skip_side":
             assert f'o == "{k}"' in query, f'm2t_plan_query("opt:{k}") is missing'
+    # INTEGRATION.md's list of options is the header's: same keys, same defaults (round-5 verdict: it still said "ten")
+    integ = open(os.path.join(root, "INTEGRATION.md")).read()
+    para = integ[integ.index("plan options of `include/m2t.h`") - 10:]
+    para = para[:para.index("## Build")]
+    listed = dict(re.findall(r"`([a-z_0-9]+)` \[(-?\d+)\]", para))
+    documented = dict(re.findall(r'^ \*   "([a-z0-9_]+)"\s+\[(-?\d+)\]', hdr, re.M))
+    assert listed == documented and set(keys) == set(documented), (set(listed) ^ set(documented), set(keys) ^ set(documented))
+    assert f"The {len(documented)} plan options" in integ
 
 
 
