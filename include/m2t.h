@@ -72,6 +72,11 @@ long long m2t_plan_query(const m2t_plan* p, const char* key);
  *   "fused_l1"          [1] bf16 x4 with the recomputing fused tail backward ("fused_tail" = 2 / 3): a loss requested through m2t_l1_loss_deferred
  *                           is taken inside that kernel (clamp, |sr - hr| partial sums, sign seed on the staged halo); 0 = m2t_backward runs the
  *                           clamp + L1 kernel first (bit-identical gradients either way)
+ *   "tail_bwd_mfma32"   [1] bf16 x4 with the recomputing fused tail backward ("fused_tail" = 2 / 3): the round-6 form of that kernel on
+ *                           v_mfma_f32_32x32x16_bf16 (k_tail_bwd.hip: LDS pixel order by sub-pixel position, conflict-free operand reads with half
+ *                           the bytes per FLOP, gelu'(t2) and g(t2) formed in registers, reflect-border gather without divergent loops, three
+ *                           barriers per tile): 346 us against 426 us stand-alone at batch 16.  g(t1), dW3 bit-identical to the 16x16x32 kernel
+ *                           (0), dWf / db3 the same products in another fp32 order
  *   "fp32_fast"         [1] fp32: the round-5 kernels of the parity mode -- plain GEMMs (qkv projections and their data gradients, N % 32 == 0,
  *                           K % 32 == 0), qkv weight gradients (N % 64 == 0, K % 64 == 0), the x2 expansions 64 -> 256 (image rows of whole
  *                           128-pixel tiles) and their weight / bias gradients on v_mfma_f32_32x32x2_f32 (k_gemm.hip), the 64 -> 3 tail conv

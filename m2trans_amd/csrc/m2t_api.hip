@@ -166,6 +166,7 @@ struct m2t_plan {
   const float* l1_hr = nullptr; float* l1_loss_out = nullptr; float l1_sc = 0.f, l1_R = 0.f;
   int use_fp32_fast = 1;               // fp32: the v_mfma_f32_32x32x2_f32 GEMM / qkv weight-gradient kernels of round 5 (k_gemm.hip); 0 = the 16x16x4 kernels
   int use_fused_l1 = 1;                // bf16 x4: the clamp + L1 seed inside the fused tail backward when the loss was requested through m2t_l1_loss_deferred
+  int use_tail_bwd32 = 1;              // bf16 x4, recomputing fused tail backward: the 32x32x16-MFMA kernel of round 6 (k_tail_bwd.hip); 0 = the 16x16x32 kernel
   // ---- options (m2t_set_option; include/m2t.h documents each) ----
   bool use_side = true;
   bool debug_skip_side = false;        // timing experiments only: skip every parameter-gradient kernel (results are WRONG)
@@ -458,6 +459,7 @@ extern "C" long long m2t_plan_query(const m2t_plan* p, const char* key) {
     // (the EFFECTIVE state, like the keys below: an option whose precondition is off did not run)
     if (o == "fork_on_kernel") return p->use_side && p->fork_on_kernel;
     if (o == "fp32_fast") return p->dt == M2T_F32 && p->use_fp32_fast;
+    if (o == "tail_bwd_mfma32") return p->dt != M2T_F32 && p->scale == 4 && p->use_tail_bwd32 && p->use_fused_tail_bwd && p->use_fused_tail_fwd && !p->use_stream_tail_bwd;
     if (o == "fused_l1") return p->dt != M2T_F32 && p->scale == 4 && p->use_fused_l1 && p->use_fused_tail_bwd && p->use_fused_tail_fwd && !p->use_stream_tail_bwd;
     if (o == "fused_attn_fwd2") {      // effective: would the C = 256 branches run k_attn_fwd2.hip
       const bool eligible = p->dt != M2T_F32 && p->use_fused_attn_fwd != 0 && p->use_fused_prep_fwd;
@@ -846,7 +848,7 @@ extern "C" int m2t_backward(m2t_plan* p, const float* params, const float* x, fl
       CK(launch_tail_bwd_fused(gpre, params + p->poff.at(wl), rc ? nullptr : WSP("t2act"), rc ? nullptr : WSP("t2der"), WSP("t1act"),
                                WSP("t1der"), packed_ptr(p, workspace, "t3T"), params + p->poff.at("tail.3.bias"), WSP("g_t1pre"), swf, sw3,
                                sb3, &ns, B, p->Hsp, p->Wsp, st, l1_in_tail ? (const float*)WSP("srpre") : nullptr, p->l1_hr,
-                               (float*)WSP("loss_part"), p->Hs, p->Ws, p->l1_R, p->l1_sc)); }
+                               (float*)WSP("loss_part"), p->Hs, p->Ws, p->l1_R, p->l1_sc, p->use_tail_bwd32 ? 32 : 16)); }
     if (l1_in_tail) CK(launch_loss_finish((const float*)WSP("loss_part"), ns, p->l1_sc, p->l1_loss_out, st));
     defer(swf, p->poff.at(wl), ns, 32 * 64, 3, 0, 0, 0);
     defer(sw3, p->poff.at("tail.3.weight"), ns, 256 * 64, 2, 64, 4, 64);
@@ -1166,6 +1168,7 @@ extern "C" int m2t_set_option(m2t_plan* p, const char* key, long long value) {
   if (k == "fused_prep_bwd") { p->use_fused_prep_bwd = value != 0; return 0; }
   if (k == "fused_norm_red") { p->use_fused_norm_red = value != 0; return 0; }
   if (k == "fused_l1") { p->use_fused_l1 = value != 0; return 0; }
+  if (k == "tail_bwd_mfma32") { p->use_tail_bwd32 = value != 0; return 0; }
   if (k == "fp32_fast") { p->use_fp32_fast = value != 0; return 0; }
   if (k == "fused_attn_fwd2") { if (value < -1 || value > 2) return m2t_set_error(M2T_ERR_ARG, "fused_attn_fwd2: -1 .. 2"); p->fused_attn_fwd2 = (int)value; return 0; }
   if (k == "gate_branch") { if (value < -1 || value > 3) return m2t_set_error(M2T_ERR_ARG, "gate_branch: -1..3"); p->gate_branch = (int)value; return 0; }

@@ -201,7 +201,10 @@ int tail_bwd_fused_blocks(int B, int H, int W);
 int launch_tail_bwd_fused(const float* gout, const float* wf, const void* act, const void* der, const void* a1, const void* d1,
                           const void* w3t, const float* b3, void* gt1, float* slab_wf, float* slab_w3, float* slab_b3,
                           int* nslab_out, int B, int H, int W, hipStream_t st, const float* l1_pre = nullptr, const float* l1_hr = nullptr,
-                          float* l1_part = nullptr, int Hs = 0, int Ws = 0, float R = 0.f, float gscale = 0.f);
+                          float* l1_part = nullptr, int Hs = 0, int Ws = 0, float R = 0.f, float gscale = 0.f, int variant = 32);
+// variant (recomputing form): 32 = the round-6 kernel on v_mfma_f32_32x32x16_bf16 (conflict-free LDS operand reads, g(t2) formed in
+// registers; results agree with the older kernel to fp32 summation order), 16 = the 16x16x32 kernel of rounds 2-5 (what the stored
+// form always runs)
 
 // ---- k_attn.hip -------------------------------------------------------------------------
 // qkv [B][h][w][3C] (q | k | v), rel_h/rel_w fp32 [10][C/2];  out rows at ldo (+ optional residual rows at ldr)

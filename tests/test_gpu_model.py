@@ -1174,20 +1174,56 @@ def test_fused_forward_tail_and_recomputing_backward_are_bit_identical():
             sr = model(x)
             torch.nn.L1Loss()(sr, hr).backward()
             outs.append((sr.detach().clone(), torch.cat([q.grad.reshape(-1) for _, q in model.named_parameters() if q.requires_grad]).clone()))
-        for other in outs[1:3]:
-            assert torch.equal(outs[0][0], other[0]), (B, H, W)
-            assert torch.equal(outs[0][1], other[1]), (B, H, W)
-        # option 4: the row-streaming BACKWARD (kept for A/B).  Its data gradient g(t1) is bit-identical, so every gradient upstream
-        # of the tail is; the three tail parameter gradients sum the same products in another order (fp32)
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (B, H, W)     # 3 vs 2: the two forward kernels
+        # option 1 runs the STORED form of the tile backward (16x16x32 MFMAs); the recomputing form is the 32x32x16 kernel since round 6:
+        # g(t1) -- hence every gradient upstream of the tail -- and dW3 stay bit-identical, dWf / db3 sum the same products in another order.
+        # option 4: the row-streaming BACKWARD (kept for A/B): g(t1) bit-identical, the three tail parameter gradients in another order
         model, _ = build_model(scale, nb, "bf16")
         offs = model.param_offsets()
-        assert torch.equal(outs[0][0], outs[3][0]), (B, H, W)
+        for other in (outs[2], outs[3]):
+            assert torch.equal(outs[0][0], other[0]), (B, H, W)
+            for n, (o, k) in offs.items():
+                a, b = outs[0][1][o:o + k], other[1][o:o + k]
+                if n in ("tail.3.weight", "tail.3.bias", "tail.6.weight"):
+                    assert float((a.double() - b.double()).norm()) <= 1e-5 * float(a.double().norm()), (B, H, W, n)
+                else:
+                    assert torch.equal(a, b), (B, H, W, n)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 128), (3, 40, 56), (1, 72, 200), (1, 32, 32)])
+def test_tail_backward_on_32x32x16_mfma_matches_the_16x16x32_kernel(shape):
+    """Option tail_bwd_mfma32 (round 6, default): the recomputing x4 tail backward rebuilt around v_mfma_f32_32x32x16_bf16 -- LDS pixel order
+    by sub-pixel position, gelu'(t2) / g(t2) formed in registers, branch-free reflect-border gather, dW3 on four waves and g(t1) on the other
+    four -- against the 16x16x32 kernel of rounds 2-5, through the whole step (TrainStep, L1 seed inside the kernel; and the immediate-seed
+    arm).  Same products and the same bf16 rounding points: the loss, g(t1) -- i.e. every gradient upstream of the tail -- and dW3 are
+    bit-identical; dWf and db3 are summed in another fp32 order.  Reflect-padded sizes put border tiles on every side."""
+    from m2trans_amd import _lib
+    from m2trans_amd.train_step import TrainStep
+    B, H, W = shape
+    scale, nb = 4, 1
+    x = O.closed_form_image(B, 3, H, W).cuda()
+    hr = O.closed_form_image(B, 3, H * scale, W * scale, phase=0.7).cuda()
+    for fused_l1 in (1, 0):
+        res = []
+        for val in (1, 0):
+            model, _ = build_model(scale, nb, "bf16")
+            plan = model._plan_for(x)
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"tail_bwd_mfma32", val), "m2t_set_option")
+            _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_l1", fused_l1), "m2t_set_option")
+            assert plan.query("opt:tail_bwd_mfma32") == val
+            ts = TrainStep(model, lr=1e-4, world_size=1)
+            for step in range(2):                            # (a second step: the strip accumulators and LDS buffers start clean)
+                loss = ts.forward_backward(x, hr)
+            torch.cuda.synchronize()
+            res.append((float(loss), ts.grads.clone(), model.param_offsets()))
+        (l1, g1, offs), (l0, g0, _) = res
+        assert l1 == l0, (l1, l0)
         for n, (o, k) in offs.items():
-            a, b = outs[0][1][o:o + k], outs[3][1][o:o + k]
-            if n in ("tail.3.weight", "tail.3.bias", "tail.6.weight"):
-                assert float((a.double() - b.double()).norm()) <= 1e-5 * float(a.double().norm()), (B, H, W, n)
+            a, b = g1[o:o + k], g0[o:o + k]
+            if n in ("tail.3.bias", "tail.6.weight"):
+                assert float((a.double() - b.double()).norm()) <= 1e-5 * float(b.double().norm()), (shape, n)
             else:
-                assert torch.equal(a, b), (B, H, W, n)
+                assert torch.equal(a, b), (shape, fused_l1, n)
 
 
 @pytest.mark.parametrize("scale,B,H,W", [(4, 2, 64, 64), (4, 1, 96, 128), (4, 1, 96, 32), (2, 3, 40, 56)])
