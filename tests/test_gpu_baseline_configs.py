@@ -165,10 +165,11 @@ def check_repeated_batch(model_small, x, hr, sr_small, grads_small, scale, dtype
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_config1_x4_128_vs_oracle_and_batch16(dtype):
-    """BASELINE configs[1]: x4, 128x128 LR, 8 blocks; batch 2 against the oracle, then the benchmarked batch 16
-    (fp32 mode: batch 8, the workspace of its exact-fp32 activations is twice as large)."""
+    """BASELINE configs[1]: x4, 128x128 LR, 8 blocks; batch 2 against the oracle, then the benchmarked batch 16 in BOTH compute
+    types (round 6: the fp32 leg stopped at batch 8 while `bench.py --dtype fp32` -- the `also.config1_fp32` line -- runs batch 16;
+    its workspace is ~8 GB of the 288)."""
     model, x, hr, sr, grads = check_vs_oracle(4, 128, 2, dtype)
-    check_repeated_batch(model, x, hr, sr, grads, 4, dtype, 8 if dtype == "bf16" else 4)
+    check_repeated_batch(model, x, hr, sr, grads, 4, dtype, 8)
 
 
 def test_config4_x3_256_vs_oracle_and_batch8():
