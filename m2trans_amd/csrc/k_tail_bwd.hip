@@ -634,34 +634,55 @@ __global__ void __launch_bounds__(512) tail_bwd32_kernel(TailBwdArgs a) {
     bf16x4 rd1[4];
     float rg[2], rh[2];
     float l1acc = 0.f;
+    // Global addresses: a scalar (per tile) base + a 32-bit per-lane byte offset that does not depend on the tile -- the kernel is bound
+    // by VALU issue, and the 64-bit per-lane address arithmetic of the five prefetches and four stores of a tile was a quarter of a wave's
+    // vector instructions.  Only the g(sr) halo of a tile that touches the image border (or the crop's) needs per-lane clamping; its offsets
+    // are formed under a scalar branch that contains NO load (a load under any branch is followed by s_waitcnt vmcnt(0) at the join).
+    const unsigned a1_off = (unsigned)((((tid >> 3) >> 3) * Wm + ((tid >> 3) & 7)) * 128 + (tid & 7) * 16);
+    unsigned hl_off[2], hh_off[2];                 // halo entry (oc, py, px): offsets from the halo origin in pre / gout and in hr
+    int hl_oc[2], hl_py[2], hl_px[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int ic = min(tid + it * 512, 3 * TB_HP - 1);
+      const int oc = ic / TB_HP, p = ic - oc * TB_HP;
+      const int py = p / (TB_T + 2), px = p - py * (TB_T + 2);
+      hl_off[it] = (unsigned)(((long long)oc * hw + (long long)py * W + px) * 4);
+      hh_off[it] = (unsigned)((((long long)oc * a.Hs + py) * a.Ws + px) * 4);
+      hl_oc[it] = oc; hl_py[it] = py; hl_px[it] = px;
+    }
+    const unsigned d_off = (unsigned)((((32 * d_mt + r32) >> 3) * Wm + ((32 * d_mt + r32) & 7)) * 128 + (32 * d_kt + 4 * h) * 2);
     auto fetchA = [&](int t) {              // staged through LDS: a1 tile, g(sr) halo
       int b, y0, x0;
       tile_geom(t, b, y0, x0);
-      {
-        const int m = tid >> 3, cv = tid & 7;
-        ra1 = load8(a.a1 + (((long long)b * Hm + y0 / 2 + (m >> 3)) * Wm + x0 / 2 + (m & 7)) * 64 + cv * 8);
+      ra1 = load8(reinterpret_cast<const T*>(reinterpret_cast<const char*>(a.a1 + (((long long)b * Hm + y0 / 2) * Wm + x0 / 2) * 64) + a1_off));
+      // the tile's halo inside the image AND (with the loss inside) inside the crop: no clamping, the offsets are the precomputed ones
+      const bool fast = y0 >= TB_T && x0 >= TB_T && y0 + TB_T + 1 <= (L1 ? a.Hs : H) && x0 + TB_T + 1 <= (L1 ? a.Ws : W);
+      unsigned ol[2], oh[2];
+      if (fast) {
+        const unsigned tl = (unsigned)(((y0 - 1) * W + (x0 - 1)) * 4), th2 = (unsigned)(((y0 - 1) * a.Ws + (x0 - 1)) * 4);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) { ol[it] = tl + hl_off[it]; oh[it] = th2 + hh_off[it]; }
+      } else {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int gy = y0 + hl_py[it] - 1, gx = x0 + hl_px[it] - 1;
+          const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
+          ol[it] = (unsigned)(((long long)hl_oc[it] * hw + (long long)cy * W + cx) * 4);
+          oh[it] = (unsigned)((((long long)hl_oc[it] * a.Hs + min(cy, a.Hs - 1)) * a.Ws + min(cx, a.Ws - 1)) * 4);
+        }
       }
+      const char* lb = reinterpret_cast<const char*>((L1 ? a.pre : a.gout) + (long long)b * 3 * hw);
+      const char* hb = reinterpret_cast<const char*>(a.hr + (long long)b * 3 * a.Hs * a.Ws);
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
-        const int i = tid + it * 512;
-        const int ic = min(i, 3 * TB_HP - 1);                        // branch-free: clamp the address, select when staging
-        const int oc = ic / TB_HP, p = ic - oc * TB_HP;
-        const int py = p / (TB_T + 2), px = p - py * (TB_T + 2);
-        const int gy = y0 + py - 1, gx = x0 + px - 1;
-        if constexpr (L1) {
-          const int cy = min(max(gy, 0), H - 1), cx = min(max(gx, 0), W - 1);
-          rg[it] = a.pre[((long long)b * 3 + oc) * hw + (long long)cy * W + cx];
-          rh[it] = a.hr[(((long long)b * 3 + oc) * a.Hs + min(cy, a.Hs - 1)) * a.Ws + min(cx, a.Ws - 1)];
-        } else {
-          rg[it] = a.gout[((long long)b * 3 + oc) * hw + (long long)min(max(gy, 0), H - 1) * W + min(max(gx, 0), W - 1)];
-        }
+        rg[it] = *reinterpret_cast<const float*>(lb + ol[it]);
+        if constexpr (L1) rh[it] = *reinterpret_cast<const float*>(hb + oh[it]);
       }
     };
     auto fetchB = [&](int t) {              // D role: gelu'(t1) of this lane's mid pixel, its 16 output channels (4 x 8 bytes)
       int b, y0, x0;
       tile_geom(t, b, y0, x0);
-      const int m = 32 * d_mt + r32;
-      const T* dp = a.d1 + (((long long)b * Hm + y0 / 2 + (m >> 3)) * Wm + x0 / 2 + (m & 7)) * 64 + 32 * d_kt + 4 * h;
+      const T* dp = reinterpret_cast<const T*>(reinterpret_cast<const char*>(a.d1 + (((long long)b * Hm + y0 / 2) * Wm + x0 / 2) * 64) + d_off);
 #pragma unroll
       for (int j = 0; j < 4; ++j) rd1[j] = *reinterpret_cast<const bf16x4*>(dp + 8 * j);
     };
@@ -824,8 +845,7 @@ __global__ void __launch_bounds__(512) tail_bwd32_kernel(TailBwdArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) mma32(acd, fa[ks], fb[ks]);
         M2T_TAIL_STAMP2(12);
-        const int m = 32 * d_mt + r32_d;
-        T* gp = a.gt1 + (((long long)b * Hm + y0 / 2 + (m >> 3)) * Wm + x0 / 2 + (m & 7)) * 64 + 32 * d_kt + 4 * h_d;
+        T* gp = reinterpret_cast<T*>(reinterpret_cast<char*>(a.gt1 + (((long long)b * Hm + y0 / 2) * Wm + x0 / 2) * 64) + d_off);
         if constexpr (!(T32_KO & 2)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

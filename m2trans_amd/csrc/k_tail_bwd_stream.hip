@@ -322,22 +322,61 @@ __global__ void __launch_bounds__(BSCfg<R>::NTHR, (R == 2 ? 2 : 4)) tail_bwd_str
           auto ring = [&](int oc, int y, int x) -> float {      // y in the step's R + 2 rows, x in the strip's columns
             return Gr[(oc * RSLOT + (y - (R * r - 1)) + R * CC) * BS_RROW + (x - (R * ci - 1))];
           };
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int n = 8 * g + j;
-            const int tap = n / 3, oc = min(n - 3 * tap, 2), ky = min(tap / 3, 2), kx = tap - 3 * (tap / 3);
-            float v = 0.f;
-            if (n < 27) {
-              v = ring(oc, yy - ky + 1, xx - kx + 1);
-#pragma unroll 1
-              for (int combo = 1; combo < 4; ++combo) {
-                if ((combo & 1) && ey == yy) continue;
-                if ((combo & 2) && ex == xx) continue;
-                const int oy = ((combo & 1) ? ey : yy) - ky + 1, oxx = ((combo & 2) ? ex : xx) - kx + 1;
-                if (oy >= 0 && oy < H && oxx >= 0 && oxx < W) v += ring(oc, oy, oxx);
+          if constexpr (R == 3) {
+            // Round 6: the reflect terms without divergent loops.  Pixel row 1 also receives, through tap ky = 0, the gradient of output row 0
+            // (row H - 2 through ky = 2 that of row H - 1; columns likewise): in ring coordinates the mirrored source of tap (ky, kx) is the
+            // entry the OPPOSITE tap reads (row yy + ky - 1, column xx + kx - 1), always inside the step's rows / the strip's columns, so the
+            // three extra reads per value are issued unconditionally and selected afterwards.  (Rounds 4-5 walked them in a `combo` loop with
+            // one serialized, divergent LDS read per branch -- every step of the image's first and last strip, 12.5 % of the x3 tasks.)
+            const bool r0 = yy == 1, r2 = yy == H - 2, c0 = xx == 1, c2 = xx == W - 2;
+            // (two values at a time, pinned: the R = 3 kernel runs at 128 registers)
+  #pragma unroll
+            for (int j2 = 0; j2 < 8; j2 += 2) {
+              float vb[2], vr[2], vc[2], vk[2];
+              int kyv[2], kxv[2];
+  #pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const int n = min(8 * g + j2 + u, 26);
+                const int tap = n / 3, oc = n - 3 * tap, ky = tap / 3, kx = tap - 3 * ky;
+                kyv[u] = ky; kxv[u] = kx;
+                vb[u] = ring(oc, yy - ky + 1, xx - kx + 1);
+                vr[u] = ring(oc, yy + ky - 1, xx - kx + 1);
+                vc[u] = ring(oc, yy - ky + 1, xx + kx - 1);
+                vk[u] = ring(oc, yy + ky - 1, xx + kx - 1);
               }
+              __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+              for (int u = 0; u < 2; ++u) {
+                const bool rm = (kyv[u] == 0 && r0) || (kyv[u] == 2 && r2);
+                const bool cm = (kxv[u] == 0 && c0) || (kxv[u] == 2 && c2);
+                float v = vb[u];
+                v += rm ? vr[u] : 0.f;              // (the order the loop added them in: mirrored row, mirrored column, both)
+                v += cm ? vc[u] : 0.f;
+                v += (rm && cm) ? vk[u] : 0.f;
+                ge[j2 + u] = (8 * g + j2 + u < 27) ? v : 0.f;
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
-            ge[j] = v;
+        
+          } else {
+            // (R = 2 -- x2, and the x4 A/B variant -- sits at the 256-register limit: the walk of rounds 4-5)
+  #pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int n = 8 * g + j;
+              const int tap = n / 3, oc = min(n - 3 * tap, 2), ky = min(tap / 3, 2), kx = tap - 3 * (tap / 3);
+              float v = 0.f;
+              if (n < 27) {
+                v = ring(oc, yy - ky + 1, xx - kx + 1);
+  #pragma unroll 1
+                for (int combo = 1; combo < 4; ++combo) {
+                  if ((combo & 1) && ey == yy) continue;
+                  if ((combo & 2) && ex == xx) continue;
+                  const int oy = ((combo & 1) ? ey : yy) - ky + 1, oxx = ((combo & 2) ? ex : xx) - kx + 1;
+                  if (oy >= 0 && oy < H && oxx >= 0 && oxx < W) v += ring(oc, oy, oxx);
+                }
+              }
+              ge[j] = v;
+            }
           }
         }
 #pragma unroll
