@@ -50,7 +50,7 @@ KERNEL_OF_BF16 = {   # bf16 mode launches the specialised kernels for these cate
     "gemm_qkv": "gemm_nt_kernel / gemm_nt_wide_kernel (qkv projections)",
     "gemm_qkv_dgrad": "gemm_nt_kernel / gemm_nt_wide_kernel (qkv data gradients)",
     "tail_gemm": "tail_expand_kernel (fwd) + gemm_nt_kernel (data gradients)",
-    "final_conv_dgrad": "tail_bwd_fused_kernel (x4) / tail_bwd_stream_kernel (x2, x3): tail conv dgrad+wgrad, GELU', expansion dgrad+wgrad, recomputing",
+    "final_conv_dgrad": "tail_bwd32_kernel (x4, round 6; tail_bwd_fused_kernel with tail_bwd_mfma32 = 0) / tail_bwd_stream_kernel (x2, x3): tail conv dgrad+wgrad, GELU', expansion dgrad+wgrad, recomputing",
 }
 MERGED = {"conv3x3_fwd+dgrad": ("conv3x3_fwd", "conv3x3_dgrad")}
 MERGED_KERNEL = {"conv3x3_fwd+dgrad": "conv3x3_c64_rows_kernel (64->64 3x3 conv, row-streaming LDS-DMA kernel: forward and data gradient are the same kernel)"}

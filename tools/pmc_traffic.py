@@ -24,7 +24,7 @@ CATEGORY_OF = [   # (substring of the kernel name, extra substring, category)
     ("tail_fwd_stream_kernel", "", "tail_fwd_fused"), ("tail_fwd_fused_kernel", "", "tail_fwd_fused"), ("window_attn_fused_c16_fwd_kernel", "", "attn_fused_c16"),
     ("window_attn_bwd_res_kernel", "ILi256E", "attn_bwd_c256"), ("window_attn_bwd_res_kernel", "ILi64E", "attn_bwd_c64"),
     ("window_attn_fwd_res_kernel", "ILi256E", "attn_fwd_c256"), ("window_attn_fwd_res_kernel", "ILi64E", "attn_fwd_c64"),
-    ("tail_bwd_fused_kernel", "", "final_conv_dgrad"),
+    ("tail_bwd_fused_kernel", "", "final_conv_dgrad"), ("tail_bwd32_kernel", "", "final_conv_dgrad"),
     ("window_attn_bwd_c16_kernel", "", "attn_bwd_c16"), ("window_attn_fwd_c16_kernel", "", "attn_fwd_c16"),
     ("window_attn_fwd_kernel", "Li16E", "attn_fwd_c16"), ("window_attn_fwd_kernel", "Li64E", "attn_fwd_c64"),
     ("window_attn_fwd_kernel", "Li256E", "attn_fwd_c256"), ("window_attn_bwd_kernel", "Li16E", "attn_bwd_c16"),
