@@ -110,7 +110,15 @@ def check_vs_oracle(scale, lr, B, dtype, nb=8, verbose=True):
             _lib.check(_lib.load().m2t_set_option(plan.handle, b"fused_tail", 1), "m2t_set_option")
             sr1, loss1, grads1 = fwd_bwd(model, x.cuda(), hr.cuda(), hr.numel())
             assert plan.query("stores_t2") == 1
-            assert torch.equal(sr1, sr) and loss1 == loss and torch.equal(grads1, grads), "fused forward tail is not bit-identical"
+            assert torch.equal(sr1, sr) and loss1 == loss, "fused forward tail is not bit-identical"
+            # the stored form runs the 16x16x32 tile backward, the default (recomputing) form the 32x32x16 kernel of round 6: g(t1) -- every
+            # gradient upstream of the tail -- and dW3 are bit-identical, dWf / db3 sum the same products in another fp32 order
+            for n, (o, k) in model.param_offsets().items():
+                a, b = grads1[o:o + k], grads[o:o + k]
+                if n in ("tail.3.bias", "tail.6.weight"):
+                    assert float((a.double() - b.double()).norm()) <= 1e-5 * float(b.double().norm()), n
+                else:
+                    assert torch.equal(a, b), f"fused forward tail / recomputing backward: {n} is not bit-identical"
         if scale != 4 and plan.query("stores_t1") == 0:
             # default x2 / x3 path (round 4): the row-streaming tail keeps gelu(t) / gelu'(t) in registers.  The plain kernels store them
             # and must give the same forward bits (the backward sums in another order: tolerances in test_gpu_model.py); their
