@@ -551,6 +551,7 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
   }
   GoStage<C, L, NTHR> gos;
   gos.issue(go, ldg, gc0, gm, tid);
+  M2T_RES_STAMP(10);                    // (bench: every load of the window issued)
 #pragma unroll
   for (int it = 0; it < KIT; ++it) {
     const int idx = tid + it * NTHR;
@@ -562,7 +563,9 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
       store8f(&Kh[key][cv * 8], v);
     }
   }
+  M2T_RES_STAMP(11);                    // (bench: K^ rows arrived, rel-pos added, staged)
   gos.finish(DOs, tid);
+  M2T_RES_STAMP(12);                    // (bench: dO through DWT^L staged)
 #pragma unroll
   for (int it = 0; it < KIT; ++it) {
     const int idx = tid + it * NTHR;

@@ -63,7 +63,11 @@ __device__ __forceinline__ int halo_sources(int b, int y, int x, int nh, int nw,
 __device__ __forceinline__ WinGeom make_geom(int h, int w) {
   WinGeom g;
   g.h = h; g.w = w; g.nw = w / 8; g.nh = h / 8;
+#ifdef M2T_WIN_HOT       // scratch/bench_*.hip knock-out (results WRONG): every workgroup works on one of M2T_WIN_HOT windows -- the kernel's
+  const int wi = xcd_block_index() % (M2T_WIN_HOT);      // loads and stores hit L2, its HBM traffic all but disappears, its instruction stream stays
+#else
   const int wi = xcd_block_index();
+#endif
   g.wi = wi;
   g.wx = wi % g.nw;
   const int q = wi / g.nw;
