@@ -202,7 +202,13 @@ __global__ void __launch_bounds__(64 * R * R, (R == 2 ? 4 : 3)) tail_fwd_stream_
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
       float v8[8];
+#if defined(TS_KO) && (TS_KO & 1)       // scratch/bench_tail.hip knock-out (results WRONG): the activation replaced by bias add
+      { const f32x4 b0 = Bs[(wv * 4 + 2 * kc) * 4 + g], b1 = Bs[(wv * 4 + 2 * kc + 1) * 4 + g];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v8[e] = acc[kc][0][e] + b0[e]; v8[4 + e] = acc[kc][1][e] + b1[e]; } }
+#else
       gelu_tail8<T>(acc[kc][0], acc[kc][1], Bs[(wv * 4 + 2 * kc) * 4 + g], Bs[(wv * 4 + 2 * kc + 1) * 4 + g], v8);
+#endif
       Frag8<T> bf;
 #pragma unroll
       for (int e = 0; e < 8; ++e) bf.set(e, v8[e]);
@@ -216,11 +222,17 @@ __global__ void __launch_bounds__(64 * R * R, (R == 2 ? 4 : 3)) tail_fwd_stream_
       yb[(4 + g) * NPX] = y[1];
       if (g == 0) yb[8 * NPX] = y[2];
     }
+#if !(defined(TS_KO) && (TS_KO & 2))    // knock-out 2: no barrier (and so no ordering between producers and the consumer)
     lds_barrier();
+#endif
     // ---- output rows R (ri + s) - 1 .. R (ri + s) + R - 2: their three Y rows are complete.  Unit u (RPW rows) -> wave (s UPS + u) % NW ----
 #pragma unroll
     for (int u = 0; u < UPS; ++u) {
+#if defined(TS_KO) && (TS_KO & 4)       // knock-out 4: no consumer (tap sums + stores)
+      if (wv == 77) {
+#else
       if (wv == (s * UPS + u) % NW) {
+#endif
         const int j = u * RPW + c_lrow;                          // row R (ri + s) - 1 + j
         const int yrow = R * (ri + s) - 1 + j;
         if (s > 0) {
