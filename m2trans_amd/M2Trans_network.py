@@ -448,12 +448,10 @@ class M2Trans(nn.Module):
     def forward(self, x):
         if self._dp_master is not None:                      # a replica made by nn.DataParallel: bind its device state first
             self._bind_replica(x)
-            params = self._dp_params
-        else:
-            params = [p for _, p in self._trainable()]
-        plan_needed_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        if plan_needed_grad:
-            return _M2TransFunction.apply(x, self, *params)
+        if torch.is_grad_enabled():                          # (the parameter walk only where an autograd edge may be needed)
+            params = self._dp_params if self._dp_master is not None else [p for _, p in self._trainable()]
+            if any(p.requires_grad for p in params):
+                return _M2TransFunction.apply(x, self, *params)
         sr = self._run_forward(self._plan_for(x), x, keep=False)
         if self._dp_master is not None:
             self._dp_release()
