@@ -24,6 +24,9 @@
 #ifndef M2T_RES_STAMP
 #define M2T_RES_STAMP(i) do { } while (0)        // scratch/bench_res.hip defines it to record s_memtime per phase
 #endif
+#ifndef M2T_RES_STAMP2
+#define M2T_RES_STAMP2(i) do { } while (0)       // (a second set for the inside of phase 0)
+#endif
 
 namespace {
 
@@ -59,6 +62,23 @@ __device__ __forceinline__ Frag8<bf16_t> tr8(const bf16_t* base, int ld, int row
   return f;
 }
 
+// Key `key` (0..99) of the window as a 32-bit element offset of its pixel row in a [pixel][row_elems] tensor, relative to the first key
+// row of the window (key_row0), clamped into the image (the loads are unconditional), and whether the key lies inside the image.
+// 24-bit multiplies on purpose: a 64-bit pixel index per lane and load costs two v_mad_u64_u32 and two v_mul_lo_u32, quarter-rate
+// instructions, and phase 0 of these kernels is bound by exactly that integer work (profiles/r06_attn_phase0_integer_work.txt).
+struct KeyAddr { unsigned off; bool ok; int kr, kc; };
+__device__ __forceinline__ int key_row0(const WinGeom& gm) { return max(8 * gm.wy - 1, 0); }
+__device__ __forceinline__ KeyAddr key_addr(const WinGeom& gm, int h, int w, int key, int row_elems) {
+  KeyAddr a;
+  a.kr = (int)(__umul24((unsigned)key, 205u) >> 11);                             // key / 10 for key < 1024
+  a.kc = key - 10 * a.kr;
+  const int yy = 8 * gm.wy + a.kr - 1, xx = 8 * gm.wx + a.kc - 1;
+  a.ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
+  const unsigned pix = __umul24((unsigned)(min(max(yy, 0), h - 1) - key_row0(gm)), (unsigned)w) + (unsigned)min(max(xx, 0), w - 1);
+  a.off = __umul24(pix, (unsigned)row_elems);
+  return a;
+}
+
 // dO rows for the whole window: DOs[q][c], c over all C channels.
 // L = 0: plain rows of go (ld, channel offset coff).  L = 1, 2: go is the full-resolution g_xc tensor and the
 // branch gradient is DWT^L of its 16-channel slice: thread (q, 4-channel group) reads its (2^L)^2 pixel block
@@ -87,14 +107,15 @@ __device__ __forceinline__ void stage_go_all(bf16_t (*dst)[C + 8], const bf16_t*
     if (tid < 256) {
       const int q = tid >> 2, cg = tid & 3;
       const int H = gm.h * S, W = gm.w * S;
-      const int by = 8 * gm.wy + (q >> 3), bx = 8 * gm.wx + (q & 7);
+      const bf16_t* gwin = go + (((long long)gm.b * H + 8 * S * gm.wy) * W + 8 * S * gm.wx) * ld + coff;      // uniform; the lanes add 32-bit offsets
+      const unsigned o0 = __umul24(__umul24((unsigned)(S * (q >> 3)), (unsigned)W) + S * (q & 7), (unsigned)ld) + 4 * cg;
       float v[4][S][S];
 #pragma unroll
       for (int y = 0; y < S; ++y)
 #pragma unroll
         for (int x = 0; x < S; ++x) {
           float t4[4];
-          load4(go + (((long long)gm.b * H + S * by + y) * W + S * bx + x) * ld + coff + 4 * cg, t4);
+          load4(gwin + o0 + (unsigned)((y * W + x) * ld), t4);
 #pragma unroll
           for (int i = 0; i < 4; ++i) v[i][y][x] = t4[i];
         }
@@ -130,12 +151,13 @@ template <int C, int L, int NTHR> struct GoStage {
       if (tid < 256) {                                   // wave-uniform
         const int q = tid >> 2, cg = tid & 3;
         const int H = gm.h * S, W = gm.w * S;
-        const int by = 8 * gm.wy + (q >> 3), bx = 8 * gm.wx + (q & 7);
+        const bf16_t* gwin = go + (((long long)gm.b * H + 8 * S * gm.wy) * W + 8 * S * gm.wx) * ld + coff;      // uniform; the lanes add 32-bit offsets
+        const unsigned o0 = __umul24(__umul24((unsigned)(S * (q >> 3)), (unsigned)W) + S * (q & 7), (unsigned)ld) + 4 * cg;
 #pragma unroll
         for (int y = 0; y < S; ++y)
 #pragma unroll
           for (int x = 0; x < S; ++x)
-            raw[y][x] = *reinterpret_cast<const bf16x4*>(go + (((long long)gm.b * H + S * by + y) * W + S * bx + x) * ld + coff + 4 * cg);
+            raw[y][x] = *reinterpret_cast<const bf16x4*>(gwin + o0 + (unsigned)((y * W + x) * ld));
       }
     }
   }
@@ -258,15 +280,14 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
       Frag8<T> xf[XIT];
       bool ok[XIT];
       f32x4 rf[RIT];
+      const T* xwin = xsrc + ((long long)gm.b * h + key_row0(gm)) * w * C;        // uniform; the lanes add 32-bit offsets
 #pragma unroll
       for (int it = 0; it < XIT; ++it) {
         const int idx = tid + it * NTHR;
         const int key = min(idx / VEC, 100), cv = idx % VEC;
-        const int kk = min(key, 99), kr = kk / 10, kc = kk - kr * 10;
-        const int yy = 8 * gm.wy + kr - 1, xx = 8 * gm.wx + kc - 1;
-        ok[it] = (key < 100) && yy >= 0 && yy < h && xx >= 0 && xx < w;
-        const int yc = min(max(yy, 0), h - 1), xc = min(max(xx, 0), w - 1);
-        xf[it] = load8(xsrc + (((long long)gm.b * h + yc) * w + xc) * C + cv * 8);       // branch-free: clamped address, select below
+        const KeyAddr ka = key_addr(gm, h, w, min(key, 99), C);
+        ok[it] = (key < 100) && ka.ok;
+        xf[it] = load8(xwin + ka.off + cv * 8);                                          // branch-free: clamped address, select below
       }
 #pragma unroll
       for (int it = 0; it < RIT; ++it) {
@@ -373,6 +394,7 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
     const float* rp = (c4 < C / 2) ? (rel_h + kk * (C / 2) + c4) : (rel_w + kk * (C / 2) + (c4 - C / 2));
     rf[it] = *reinterpret_cast<const f32x4*>(rp);
   }
+  M2T_RES_STAMP2(0);                    // (bench: q and table loads issued)
   auto stage_rel = [&]() {
 #pragma unroll
     for (int it = 0; it < RIT; ++it) {
@@ -396,28 +418,33 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
       long long ho[3];
       const int ns = halo_sources(gm.b, 8 * gm.wy + (cq >> 3), 8 * gm.wx + (cq & 7), gm.nh, gm.nw, C, ho);
       const Frag8<T> piece = load8(pb.gdwinn + (a < ns ? ho[a] : 0) + vec * 8);
+      M2T_RES_STAMP2(1);                // (bench: loader role, corner piece issued)
       stage_rel();
+      M2T_RES_STAMP2(2);                // (bench: loader role, table staged = q and table landed)
       store8(&CornS[(cn * 2 + (a - 1)) * C + vec * 8], a < ns ? piece : frag_zero<T>());
+      M2T_RES_STAMP2(3);                // (bench: loader role, corner piece landed and staged)
     }
     lds_barrier();
+    M2T_RES_STAMP(13);
+    const T* kwin = qkv + ((long long)gm.b * h + key_row0(gm)) * w * (3 * C);    // uniform; the lanes add 32-bit offsets
+    static_assert(256 % VEC == 0, "a thread keeps its channel piece over the iterations");
+    bool kok[KIT2];
 #pragma unroll
     for (int it = 0; it < KIT2; ++it) {
       const int idx = t2 + it * 256;
       const int cv = idx % VEC, key = min(idx / VEC, WA_NK - 1);
-      const int kr = key / 10, kc = key - kr * 10;
-      const int yy = 8 * gm.wy + kr - 1, xx = 8 * gm.wx + kc - 1;
-      const long long kp = ((long long)gm.b * h + min(max(yy, 0), h - 1)) * w + min(max(xx, 0), w - 1);     // clamped: the loads are unconditional
-      kf[it] = load8(qkv + kp * (3 * C) + C + cv * 8);
-      vf[it] = load8(qkv + kp * (3 * C) + 2 * C + cv * 8);
+      const KeyAddr ka = key_addr(gm, h, w, key, 3 * C);                          // clamped: the loads are unconditional
+      kok[it] = ka.ok;
+      kf[it] = load8(kwin + ka.off + C + cv * 8);
+      vf[it] = load8(kwin + ka.off + 2 * C + cv * 8);
     }
 #pragma unroll
     for (int it = 0; it < KIT2; ++it) {
       const int idx = t2 + it * 256;
       const int cv = idx % VEC, key = idx / VEC;
-      if (key < WA_NK) {
-        const int kr = key / 10, kc = key - kr * 10;
-        const int yy = 8 * gm.wy + kr - 1, xx = 8 * gm.wx + kc - 1;
-        const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
+      if (it * 256 + 255 < WA_NK * VEC || key < WA_NK) {                          // (a branch in the last iteration only)
+        const int kr = (int)(__umul24((unsigned)key, 205u) >> 11), kc = key - 10 * kr;
+        const bool ok = kok[it];
         const int cc = cv * 8;
         const f32x4 ra = *reinterpret_cast<const f32x4*>(&RelS[(cc < C / 2) ? kr : kc][cc]);
         const f32x4 rb = *reinterpret_cast<const f32x4*>(&RelS[(cc < C / 2) ? kr : kc][cc + 4]);
@@ -437,25 +464,31 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
     const int pq = tid >> 2, cg = tid & 3;
     const int H = gm.h * S, W = gm.w * S;
     const int by = 8 * gm.wy + (pq >> 3), bx = 8 * gm.wx + (pq & 7);
-    const T* drow = pb.gdn + (((long long)gm.b * gm.h + by) * gm.w + bx) * C + 4 * cg;
     long long hoff[3];
     const int nsrc = halo_sources(gm.b, by, bx, gm.nh, gm.nw, C, hoff);
+    M2T_RES_STAMP2(1);                  // (bench: prep role, ring sources known)
     bf16x4 rd[NB], rr[NB], p3[S][S], p2[S][S];
-#pragma unroll
-    for (int n = 0; n < NB; ++n) rd[n] = *reinterpret_cast<const bf16x4*>(drow + n * 16);
     {
+      const T* dwin = pb.gdn + (((long long)gm.b * gm.h + 8 * gm.wy) * gm.w + 8 * gm.wx) * C;                 // uniform; the lanes add 32-bit offsets
+      const unsigned d0 = (__umul24((unsigned)(pq >> 3), (unsigned)gm.w) + (pq & 7)) * C + 4 * cg;
+#pragma unroll
+      for (int n = 0; n < NB; ++n) rd[n] = *reinterpret_cast<const bf16x4*>(dwin + d0 + n * 16);
       const T* r0p = pb.gdwinn + (nsrc > 0 ? hoff[0] : 0) + 4 * cg;               // clamped: unconditional loads, selected below
 #pragma unroll
       for (int n = 0; n < NB; ++n) rr[n] = *reinterpret_cast<const bf16x4*>(r0p + n * 16);
     }
+    const long long pwin = (((long long)gm.b * H + 8 * S * gm.wy) * W + 8 * S * gm.wx) * 16;                   // uniform
+    const unsigned po0 = (__umul24((unsigned)(S * (pq >> 3)), (unsigned)W) + S * (pq & 7)) * 16 + 4 * cg;
+#define PB_PO(y, x) (po0 + (unsigned)(((y) * W + (x)) * 16))
 #pragma unroll
     for (int y = 0; y < S; ++y)
 #pragma unroll
       for (int x = 0; x < S; ++x) {
-        const long long po = (((long long)gm.b * H + S * by + y) * W + S * bx + x) * 16 + 4 * cg;
-        p3[y][x] = *reinterpret_cast<const bf16x4*>(pb.gxk + po);
-        p2[y][x] = *reinterpret_cast<const bf16x4*>(go + po);
+        const unsigned po = PB_PO(y, x);
+        p3[y][x] = *reinterpret_cast<const bf16x4*>(pb.gxk + pwin + po);
+        p2[y][x] = *reinterpret_cast<const bf16x4*>(go + pwin + po);
       }
+    M2T_RES_STAMP2(2);                  // (bench: prep role, every load issued)
     // two channel pairs per thread, packed fp32 (v_pk_add / v_pk_mul: IEEE per component).  g_d row of the block = own-window products
     // + the neighbours' ring rows (fp32 adds in halo_sources' order, one rounding to bf16).  The first sums sit in front of the
     // barrier on purpose: the loader waves start the K | V burst when these loads have landed
@@ -469,7 +502,9 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
         o2[c2][n] = nsrc > 0 ? sum : q2;
       }
     stage_rel();
+    M2T_RES_STAMP2(3);                  // (bench: prep role, table staged, at the barrier)
     lds_barrier();
+    M2T_RES_STAMP(13);                  // (bench: g_d rows of the block arrived, rel-pos barrier passed)
     if (nsrc > 1) {                                                               // corner pixels only (4 of 64): rows staged by the loader waves
       const int cn = ((pq & 7) == 7 ? 1 : 0) + (pq >= 56 ? 2 : 0);
       for (int a = 1; a < nsrc; ++a) {
@@ -489,12 +524,13 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
       for (int n = 0; n < NB; ++n) o2[c2][n] = (f32x2){to_f(from_f<T>(o2[c2][n][0])), to_f(from_f<T>(o2[c2][n][1]))};
       Haar2Inv2::inv(o2[c2], vq[c2]);
     }
+    M2T_RES_STAMP(12);                  // (bench: DWT^-1 of the block done)
     // g_n[k] = (IWT + g_xc[k]) / 2 ; g_xc[i] += that ; the new g_xc[i] (rounded as stored) is this window's dO before DWT^L
 #pragma unroll
     for (int y = 0; y < S; ++y)
 #pragma unroll
       for (int x = 0; x < S; ++x) {
-        const long long po = (((long long)gm.b * H + S * by + y) * W + S * bx + x) * 16 + 4 * cg;
+        const unsigned po = PB_PO(y, x);
         f32x2 qv[2], pp[2];
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
@@ -502,12 +538,13 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
           pp[c2] = (f32x2){(float)p2[y][x][2 * c2], (float)p2[y][x][2 * c2 + 1]} + qv[c2];
         }
         const bf16x4 gv = {(bf16_t)qv[0][0], (bf16_t)qv[0][1], (bf16_t)qv[1][0], (bf16_t)qv[1][1]};
-        *reinterpret_cast<bf16x4*>(pb.gnk + po) = gv;
+        *reinterpret_cast<bf16x4*>(pb.gnk + pwin + po) = gv;
         const bf16x4 nv = {(bf16_t)pp[0][0], (bf16_t)pp[0][1], (bf16_t)pp[1][0], (bf16_t)pp[1][1]};
-        *reinterpret_cast<bf16x4*>(const_cast<T*>(go) + po) = nv;
+        *reinterpret_cast<bf16x4*>(const_cast<T*>(go) + pwin + po) = nv;
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) vq[c2][y][x] = (f32x2){(float)nv[2 * c2], (float)nv[2 * c2 + 1]};
       }
+    M2T_RES_STAMP(14);                  // (bench: full-resolution planes read, combined, stored)
     f32x2 ob[2][NB];
 #pragma unroll
     for (int c2 = 0; c2 < 2; ++c2) Haar2<L>::fwd(vq[c2], ob[c2]);
@@ -517,38 +554,39 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
       *reinterpret_cast<bf16x4*>(&DOs[pq][n * 16 + 4 * cg]) = dv;
     }
   }
+  M2T_RES_STAMP(10);                    // (bench: this wave's phase-0 role done)
   __syncthreads();
   } else {
   // ---- phase 0: every global load of the window is issued -- q first (phase 1 needs it in registers; issued behind the LDS
-  // writes it cost a second exposed HBM round trip), K^ | rel, V, dO -- then written to LDS.  The burst is bandwidth-bound
-  // (166 KB per workgroup, all 256 in lockstep: 13 k cycles = 6.7 TB/s over the chip); a split that starts S^T on K^ while
-  // V / dO are still arriving gained nothing: the first 93 KB do not arrive earlier than the last (stamps, scratch/bench_res.hip) ----
+  // writes it cost a second exposed round trip), K^ | rel, V, dO -- then written to LDS.  All 256 workgroups run this phase at the
+  // same time and the chip's memory system bounds it: 266 KB of lane requests per workgroup in 16 k cycles = 16 B/clk per CU, the
+  // rate at which 256 CUs streaming together are served (scratch/bench_ta.hip: 15 B/clk per CU; a CU alone on L2-resident data
+  // gets 62).  A split that starts S^T on K^ while V / dO are still arriving gained nothing, and neither did the rel-pos table
+  // through LDS (10 KB once instead of two 16-byte loads beside every K load: those hit L1 / L2, the extra barrier cost 1 us --
+  // profiles/r06_attn_phase0_integer_work.txt) ----
   constexpr int KIT = (WA_NK * VEC + NTHR - 1) / NTHR;
 #pragma unroll
   for (int kc = 0; kc < NKC; ++kc) qreg[kc] = load8(qkv + qpix * (3 * C) + kc * 32 + 8 * g);
   Frag8<T> kf[KIT], vf[KIT];
   f32x4 r0[KIT], r1[KIT];
   bool kok[KIT];
-  long long kpix[KIT];
+  unsigned koff[KIT];
+  const T* kwin = qkv + ((long long)gm.b * h + key_row0(gm)) * w * (3 * C);      // uniform; the lanes add 32-bit offsets
 #pragma unroll
   for (int it = 0; it < KIT; ++it) {
     const int idx = tid + it * NTHR;
     const int cv = idx % VEC, key = min(idx / VEC, WA_NK - 1);
-    const int kr = key / 10, kc = key - kr * 10;
-    const int yy = 8 * gm.wy + kr - 1, xx = 8 * gm.wx + kc - 1;
-    kok[it] = yy >= 0 && yy < h && xx >= 0 && xx < w;
-    kpix[it] = ((long long)gm.b * h + min(max(yy, 0), h - 1)) * w + min(max(xx, 0), w - 1);     // clamped: the load is unconditional
-    kf[it] = load8(qkv + kpix[it] * (3 * C) + C + cv * 8);
+    const KeyAddr ka = key_addr(gm, h, w, key, 3 * C);                            // clamped: the load is unconditional
+    kok[it] = ka.ok;
+    koff[it] = ka.off + cv * 8;
+    kf[it] = load8(kwin + koff[it] + C);
     const int cc = cv * 8;
-    const float* rp = (cc < C / 2) ? (rel_h + kr * (C / 2) + cc) : (rel_w + kc * (C / 2) + (cc - C / 2));
+    const float* rp = (cc < C / 2) ? (rel_h + ka.kr * (C / 2) + cc) : (rel_w + ka.kc * (C / 2) + (cc - C / 2));
     r0[it] = *reinterpret_cast<const f32x4*>(rp);
     r1[it] = *reinterpret_cast<const f32x4*>(rp + 4);
   }
 #pragma unroll
-  for (int it = 0; it < KIT; ++it) {
-    const int idx = tid + it * NTHR;
-    vf[it] = load8(qkv + kpix[it] * (3 * C) + 2 * C + (idx % VEC) * 8);
-  }
+  for (int it = 0; it < KIT; ++it) vf[it] = load8(kwin + koff[it] + 2 * C);
   GoStage<C, L, NTHR> gos;
   gos.issue(go, ldg, gc0, gm, tid);
   M2T_RES_STAMP(10);                    // (bench: every load of the window issued)
@@ -556,7 +594,7 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
   for (int it = 0; it < KIT; ++it) {
     const int idx = tid + it * NTHR;
     const int cv = idx % VEC, key = idx / VEC;
-    if (key < WA_NK) {
+    if (it * NTHR + NTHR - 1 < WA_NK * VEC || key < WA_NK) {                      // (a branch in the last iteration only)
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = (kok[it] ? kf[it].get(e) : 0.f) + r0[it][e]; v[4 + e] = (kok[it] ? kf[it].get(4 + e) : 0.f) + r1[it][e]; }

@@ -42,22 +42,24 @@ __device__ __forceinline__ T* dkv_row(T* gqkv, T* win, long long wi, int b, int 
 // The (<= 3) neighbouring windows whose 10x10 neighbourhood covers pixel (y, x) of image b, as element offsets of their
 // ring rows in a [window][36][rw] scratch (same order as halo_gather_kernel adds them: row-neighbour column first).
 __device__ __forceinline__ int halo_sources(int b, int y, int x, int nh, int nw, int rw, long long (&off)[3]) {
+  // branch-free: the three candidates -- A = the column neighbour of the pixel's own window row, B = the row neighbour, C = the diagonal one --
+  // are all computed (their indices are valid whether they exist or not) and packed by selects.  As two nested loops with data-dependent
+  // trip counts this cost the attention backward's prep role 4.7 k cycles per workgroup (profiles/r06_attn_phase0_integer_work.txt)
   const int wy0 = y >> 3, wx0 = x >> 3, py = y & 7, px = x & 7;
-  int wys[2], krs[2], ny = 1, wxs[2], kcs[2], nx = 1;
-  wys[0] = wy0; krs[0] = py + 1;
-  if (py == 0 && wy0 > 0) { wys[1] = wy0 - 1; krs[1] = 9; ny = 2; }
-  else if (py == 7 && wy0 < nh - 1) { wys[1] = wy0 + 1; krs[1] = 0; ny = 2; }
-  wxs[0] = wx0; kcs[0] = px + 1;
-  if (px == 0 && wx0 > 0) { wxs[1] = wx0 - 1; kcs[1] = 9; nx = 2; }
-  else if (px == 7 && wx0 < nw - 1) { wxs[1] = wx0 + 1; kcs[1] = 0; nx = 2; }
-  int n = 0;
-  for (int a = 0; a < ny; ++a)
-    for (int c = 0; c < nx; ++c) {
-      if (a == 0 && c == 0) continue;
-      const long long wi = ((long long)b * nh + wys[a]) * nw + wxs[c];
-      off[n++] = (wi * WA_RING + ring_index(krs[a], kcs[c])) * rw;
-    }
-  return n;
+  const bool up = py == 0 && wy0 > 0, dn = py == 7 && wy0 < nh - 1;
+  const bool lf = px == 0 && wx0 > 0, rt = px == 7 && wx0 < nw - 1;
+  const bool hasy = up || dn, hasx = lf || rt;
+  const int wy1 = wy0 + (dn ? 1 : 0) - (up ? 1 : 0), kr1 = up ? 9 : 0;
+  const int wx1 = wx0 + (rt ? 1 : 0) - (lf ? 1 : 0), kc1 = lf ? 9 : 0;
+  const int kr0 = py + 1, kc0 = px + 1;
+  const int row0 = (b * nh + wy0) * nw, row1 = (b * nh + wy1) * nw;          // window counts stay far below 2^31 / 36
+  const int eA = (row0 + wx1) * WA_RING + ((kc1 == 0) ? 19 + kr0 : 27 + kr0); // ring_index(kr0 in 1..8, kc1 in {0, 9})
+  const int eB = (row1 + wx0) * WA_RING + ((kr1 == 0) ? kc0 : 10 + kc0);      // ring_index(kr1 in {0, 9}, kc0)
+  const int eC = (row1 + wx1) * WA_RING + ((kr1 == 0) ? kc1 : 10 + kc1);
+  off[0] = (long long)(hasx ? eA : eB) * rw;
+  off[1] = (long long)eB * rw;                                               // (read only when both neighbours exist)
+  off[2] = (long long)eC * rw;
+  return (hasx ? 1 : 0) + (hasy ? 1 : 0) + ((hasx && hasy) ? 1 : 0);
 }
 
 __device__ __forceinline__ WinGeom make_geom(int h, int w) {

@@ -11,6 +11,8 @@
 __device__ unsigned long long* g_stamps;
 #define M2T_RES_STAMP(i) do { if ((threadIdx.x & 63) == 0) { g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
   if ((i) == 0 || (i) == 7) g_stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+__device__ unsigned long long* g_stamps2;
+#define M2T_RES_STAMP2(i) do { if ((threadIdx.x & 63) == 0) g_stamps2[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #endif
 #include "../m2trans_amd/csrc/k_attn_res.hip"
 
@@ -25,6 +27,12 @@ hipEvent_t m2t_fork_take() { return nullptr; }
 #define CKH(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 static unsigned short f2bf(float f) { union { float f; unsigned u; } c; c.f = f; unsigned u = c.u; return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); }
 
+__global__ void __launch_bounds__(512) lds_fill_kernel(unsigned pat, unsigned* sink) {      // leaves `pat` in every LDS word of the CU (uninitialised-LDS probe)
+  extern __shared__ unsigned lds_words[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 512) lds_words[i] = pat;
+  __syncthreads();
+  if (lds_words[(threadIdx.x * 97) % (160 * 1024 / 4)] != pat) sink[0] = 1;
+}
 int main(int argc, char** argv) {
   const int C = argc > 1 ? atoi(argv[1]) : 256;
   const int B = argc > 2 ? atoi(argv[2]) : 16;
@@ -48,6 +56,9 @@ int main(int argc, char** argv) {
   unsigned long long* dst;
   CKH(hipMalloc(&dst, (size_t)nwin * 8 * 16 * 8)); CKH(hipMemset(dst, 0, (size_t)nwin * 8 * 16 * 8));
   CKH(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dst, sizeof(dst)));
+  unsigned long long* dst2;
+  CKH(hipMalloc(&dst2, (size_t)nwin * 8 * 8 * 8)); CKH(hipMemset(dst2, 0, (size_t)nwin * 8 * 8 * 8));
+  CKH(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps2), &dst2, sizeof(dst2)));
 #endif
   hipStream_t st; CKH(hipStreamCreate(&st));
   const bool rc = (C == 64);
@@ -56,6 +67,7 @@ int main(int argc, char** argv) {
   void *dgd2 = nullptr, *dgdwin2 = nullptr, *dgnk = nullptr;
   if (pbm) {
     CKH(hipMalloc(&dgd2, M * C * 2)); CKH(hipMalloc(&dgdwin2, (size_t)nwin * 36 * C * 2)); CKH(hipMalloc(&dgnk, full * 16 * 2));
+    srand(2);                                                        // (the HIP runtime draws from rand() too: without this the two tensors differ from process to process)
     auto hg = fill(M * C, 0.5f), hw2 = fill((size_t)nwin * 36 * C, 0.5f);
     CKH(hipMemcpy(dgd2, hg.data(), M * C * 2, hipMemcpyHostToDevice)); CKH(hipMemcpy(dgdwin2, hw2.data(), (size_t)nwin * 36 * C * 2, hipMemcpyHostToDevice));
   }
@@ -72,18 +84,27 @@ int main(int argc, char** argv) {
   }
   std::sort(ts.begin(), ts.end());
   printf("bwd_res C=%d B=%d windows=%d: event-bracketed min %.2f us median %.2f us\n", C, B, nwin, ts[0], ts[N / 2]);
-  {   // output hashes of one launch into zeroed buffers (compare builds: identical hashes = identical bits)
+  for (int rep = 0; rep < (pbm ? 3 : 1); ++rep) {   // output hashes of one launch into zeroed buffers (compare builds: identical hashes = identical bits)
     const size_t n1 = M * 3 * C * 2, n2 = (size_t)nwin * 36 * 2 * C * 2, n3 = (size_t)nwin * 10 * C * 4, n4 = M * C * 2, n5 = (size_t)nwin * 36 * C * 2;
     CKH(hipMemset(dgqkv, 0, n1)); CKH(hipMemset(dwin, 0, n2)); CKH(hipMemset(drelw, 0, n3)); CKH(hipMemset(dgd, 0, n4)); CKH(hipMemset(dgdwin, 0, n5));
+    if (pbm) { static unsigned* sink = nullptr; if (!sink) { CKH(hipMalloc(&sink, 4)); CKH(hipFuncSetAttribute((const void*)lds_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
+      const unsigned pats[3] = {0u, 0xFFFFFFFFu, 0x7FC07FC0u};
+      hipLaunchKernelGGL(lds_fill_kernel, dim3(1024), dim3(512), 160 * 1024, st, pats[rep], sink); CKH(hipStreamSynchronize(st)); }
+    CKH(hipMemcpy(dgo, hgo.data(), full * 64 * 2, hipMemcpyHostToDevice));      // (the fused prep updates g_xc in place: the hash is of ONE launch on the initial data)
     if (launch()) return 1;
     CKH(hipStreamSynchronize(st));
     auto hash = [&](void* d, size_t n) { std::vector<unsigned char> hb(n); CKH(hipMemcpy(hb.data(), d, n, hipMemcpyDeviceToHost)); unsigned long long hsh = 1469598103934665603ull;
       const unsigned long long* p8 = (const unsigned long long*)hb.data(); for (size_t i = 0; i < n / 8; ++i) { hsh ^= p8[i]; hsh *= 1099511628211ull; } return hsh; };
-    printf("  hashes: gqkv %016llx win %016llx relw %016llx gd %016llx gdwin %016llx\n", hash(dgqkv, n1), hash(dwin, n2), hash(drelw, n3), hash(dgd, n4), hash(dgdwin, n5));
+    printf("  hashes: gqkv %016llx win %016llx relw %016llx gd %016llx gdwin %016llx", hash(dgqkv, n1), hash(dwin, n2), hash(drelw, n3), hash(dgd, n4), hash(dgdwin, n5));
+    if (pbm) printf(" g_xc %016llx g_n %016llx | inputs gd2 %016llx gdwin2 %016llx planes1-3 %016llx qkv %016llx wd %016llx rel %016llx", hash(dgo, full * 16 * 2), hash(dgnk, full * 16 * 2),
+                    hash(dgd2, M * C * 2), hash(dgdwin2, (size_t)nwin * 36 * C * 2), hash((char*)dgo + full * 16 * 2, full * 48 * 2), hash(dqkv, M * 3 * C * 2), hash(dwd, (size_t)3 * C * C * 2), hash(drel, 10 * C * 4));
+    printf("\n");
   }
 #ifdef STAMPS
   std::vector<unsigned long long> hs((size_t)nwin * 8 * 16);
   CKH(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> hs2((size_t)nwin * 8 * 8);
+  CKH(hipMemcpy(hs2.data(), dst2, hs2.size() * 8, hipMemcpyDeviceToHost));
   const int NW = (C == 256) ? 8 : 4;
   const char* names[7] = {"phase0 loads -> LDS (+recompute)", "phase1 S, dP MFMA", "softmax, dS, row/col sums", "phase2 dV, dK^ MFMA", "relw, dV->LDS, dq MFMA, dK^/dq->LDS",
                           "DG: g_d = [dq|dK^|dV] W", "g_d stores + gqkv/win stores"};
@@ -104,6 +125,12 @@ int main(int argc, char** argv) {
       std::vector<long long> e1;
       for (int b = 0; b < nwin; ++b) { const unsigned long long* r = &hs[((size_t)b * 8 + wsel) * 16]; if (r[10]) e1.push_back((long long)(r[10] - r[0])); }
       if (!e1.empty()) { std::sort(e1.begin(), e1.end()); printf("  (start -> end of this wave's phase-0 role %lld)\n", e1[e1.size() / 2]); }
+      for (int k : {13, 12, 14}) { std::vector<long long> e;
+        for (int b = 0; b < nwin; ++b) { const unsigned long long* r = &hs[((size_t)b * 8 + wsel) * 16]; if (r[k]) e.push_back((long long)(r[k] - r[0])); }
+        if (!e.empty()) { std::sort(e.begin(), e.end()); printf("  (start -> stamp %d: %lld)\n", k, e[e.size() / 2]); } }
+      for (int k = 0; k < 8; ++k) { std::vector<long long> e;
+        for (int b = 0; b < nwin; ++b) { const unsigned long long v = hs2[((size_t)b * 8 + wsel) * 8 + k]; if (v) e.push_back((long long)(v - hs[((size_t)b * 8 + wsel) * 16])); }
+        if (!e.empty()) { std::sort(e.begin(), e.end()); printf("  (start -> inner stamp %d: %lld)\n", k, e[e.size() / 2]); } }
       std::vector<long long> e2, e3;
       for (int b = 0; b < nwin; ++b) { const unsigned long long* r = &hs[((size_t)b * 8 + wsel) * 16]; if (r[11]) e2.push_back((long long)(r[11] - r[0])); if (r[12]) e3.push_back((long long)(r[12] - r[0])); }
       if (!e2.empty()) { std::sort(e2.begin(), e2.end()); printf("  (start -> rel-pos barrier passed %lld)\n", e2[e2.size() / 2]); }
