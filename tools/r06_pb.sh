@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT/scratch
-for b in bench_res_base bench_res_i32b; do for a in "256 16 1"; do echo "== $b $a"; timeout 120 ./$b $a 2>&1 | grep -v "^$" | head -3 | cut -c1-170; done; done 2>&1 | tee ../gpurun_out/r06_det.txt
+for a in "256 16 0 1" "256 16 1 1" "64 16 0 1"; do echo "== bench_fused_ns $a"; timeout 120 ./bench_fused_ns $a 2>&1 | head -2; echo "== bench_fused_st $a"; timeout 120 ./bench_fused_st $a 2>&1 | head -24; done 2>&1 | tee ../gpurun_out/r06_fused_st.txt

@@ -1,4 +1,4 @@
-# round 6: refresh of the build-stamped evidence after a source edit that does not change any kernel (bench-only macros): the traffic
+# round 6: refresh of the build-stamped evidence after a kernel-source edit: the traffic
 # counters of configs 1 / 3 / 4 (bench.py reports roofline.traffic only for the stamp of the library it runs), the default line, the suite
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
