@@ -873,15 +873,23 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
     }
   M2T_RES_STAMP(5);
   if constexpr (DG) {
-    // the dq row block has no row for ring keys: row 64 (the first row of the dead region behind it) is zeroed
-    if (tid < VEC) store8(&QOUT[64][tid * 8], frag_zero<T>());
+    // Row order of this product: the window's OWN 64 pixels first (row tiles 0..3, query order), then the 36 ring keys (tiles 4..6, ring_index
+    // order, 12 pad rows on the zero row).  Ring keys have no dq row, so the dq part of the k range runs on four row tiles instead of seven
+    // (-14 % of the phase's MFMAs; in key order every tile mixes own and ring keys and the ring lanes multiplied zeros).
     int krow[WA_KT], qrow[WA_KT];
 #pragma unroll
     for (int t = 0; t < WA_KT; ++t) {
-      const int key = 16 * t + lr;
-      const int kr = key / 10, kc = key - kr * 10;
-      krow[t] = min(key, ZR);
-      qrow[t] = (key < WA_NK && kr >= 1 && kr <= 8 && kc >= 1 && kc <= 8) ? (kr - 1) * 8 + (kc - 1) : 64;
+      if (t < 4) {
+        const int qq = 16 * t + lr;
+        qrow[t] = qq;
+        krow[t] = 10 * ((qq >> 3) + 1) + (qq & 7) + 1;
+      } else {
+        const int r = 16 * (t - 4) + lr;                          // ring_index^-1: rows 0 and 9 (10 keys each), then columns 0 and 9 of rows 1..8
+        const int kr = (r < 10) ? 0 : ((r < 20) ? 9 : ((r < 28) ? r - 19 : r - 27));
+        const int kc = (r < 10) ? r : ((r < 20) ? r - 10 : ((r < 28) ? 0 : 9));
+        qrow[t] = 0;                                              // (never read: the dq part skips these tiles)
+        krow[t] = (r < WA_RING) ? 10 * kr + kc : ZR;
+      }
     }
     f32x4 ad[TPW][WA_KT];
 #pragma unroll
@@ -895,6 +903,7 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
       const int part = ks / NKC, kk = ks - part * NKC;
 #pragma unroll
       for (int t = 0; t < WA_KT; ++t) {
+        if (part == 0 && t >= 4) continue;                        // ring rows: no dq
         const T* rp = (part == 0) ? &QOUT[qrow[t]][0] : ((part == 1) ? &KOUT[krow[t]][0] : &VOUT[krow[t]][0]);
         bf[t] = load8(rp + 32 * kk + 8 * g);
       }
@@ -951,7 +960,7 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
       }
       __builtin_amdgcn_sched_barrier(0);      // keep the prefetches HERE: hipcc otherwise sinks them to just before their use
 #pragma unroll
-      for (int t = 0; t < WA_KT; ++t)
+      for (int t = 0; t < ((ks < NKC) ? 4 : WA_KT); ++t)
 #pragma unroll
         for (int m = 0; m < TPW; ++m) mma16(ad[m][t], a[m], bq[ks & 1][t]);
       __builtin_amdgcn_sched_barrier(0);
@@ -959,14 +968,13 @@ __global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16
 #undef M2T_RES_ITEM
     static_assert(SPS * (NK3 - 1) >= NSLOT, "every slot has a k-step");
   M2T_RES_STAMP(6);
-    // lane (key 16 t + lr, g) holds channels 16 (mt0 + m) + 4 g .. + 3 of g_d for that key
+    // lane (row 16 t + lr of the order above, g) holds channels 16 (mt0 + m) + 4 g .. + 3 of g_d for that key
 #pragma unroll
     for (int t = 0; t < WA_KT; ++t) {
-      const int key = 16 * t + lr;
+      const int key = krow[t];
       long long pix;
-      if (key < WA_NK && gm.key_pixel(key, pix)) {
-        const int kr = key / 10, kc = key - kr * 10;
-        T* dst = (qrow[t] != 64) ? gd + pix * C : gdwin + ((long long)gm.wi * WA_RING + ring_index(kr, kc)) * C;
+      if (key < WA_NK && gm.key_pixel(key, pix)) {                // (ring keys outside the image are dropped: the gradient of zero padding)
+        T* dst = (t < 4) ? gd + pix * C : gdwin + ((long long)gm.wi * WA_RING + 16 * (t - 4) + lr) * C;
 #pragma unroll
         for (int m = 0; m < TPW; ++m) {
           float v[4] = {ad[m][t][0], ad[m][t][1], ad[m][t][2], ad[m][t][3]};
