@@ -63,17 +63,29 @@ __device__ __forceinline__ void fused_key_rc(int k, int& kr, int& kc) {
 
 template <int C> struct FusedCfg {
   static constexpr int LD = C + 8;          // bf16 rows of Xs|Vs / Kh / Qs
-  static constexpr int PLD = 128 + 8;       // P [query][key 0..127]
+  // P [query][key].  C = 256 (8 waves, two key halves, one workgroup per CU): keys 0..127 in a region of its own, which the rel-pos table
+  // borrows in phases 0-2.  C = 64 (4 waves, 1 024 windows at batch 16): the footprint decides how many windows a CU works on at once -- P has
+  // 112 keys (the 16 padding keys of the last k-step are read from the zero row of Xs | Vs) and OVERLAYS Kh | Qs (dead once every wave has its
+  // S^T tile: one more barrier; O overlays them too: a second one), the rel-pos table gets 2.5 KB of its own, the cross-half reduction buffer
+  // is gone: 40 864 bytes, FOUR workgroups per CU instead of two = all 1 024 windows of a batch-16 launch resident in one round (round 6)
+  static constexpr bool P_OVER_K = (C == 64);
+  static constexpr int PKEYS = P_OVER_K ? 112 : 128;
+  static constexpr int PLD = PKEYS + 8;
   static constexpr int OLD = C + 4;         // O [query][channel] fp32
   static constexpr int ZR = 100;            // the zero row of Xs|Vs and Kh (every padding key aliases it)
   static constexpr size_t szX = sizeof(bf16_t) * 101 * LD;
   static constexpr size_t szQ = sizeof(bf16_t) * 64 * LD;
   static constexpr size_t szP = sizeof(bf16_t) * 64 * PLD;
-  static constexpr size_t szR = sizeof(float) * 2 * 2 * 64;            // [max | sum][key half][query]
-  static constexpr size_t offX = 0, offK = szX, offQ = 2 * szX, offP = 2 * szX + szQ, offR = offP + szP;
+  static constexpr size_t szR = P_OVER_K ? 0 : sizeof(float) * 2 * 2 * 64;    // [max | sum][key half][query]; one key half at C = 64
+  static constexpr size_t szRel = sizeof(float) * 10 * C;
+  static constexpr size_t offX = 0, offK = szX, offQ = 2 * szX;
+  static constexpr size_t offP = P_OVER_K ? offK : 2 * szX + szQ;
+  static constexpr size_t offRel = P_OVER_K ? 2 * szX + szQ : offP;
+  static constexpr size_t offR = P_OVER_K ? offRel + szRel : offP + szP;
   static constexpr size_t total = offR + szR;
+  static_assert(!P_OVER_K || szP <= szX + szQ, "P overlays Kh | Qs");
   static_assert(sizeof(float) * 64 * OLD <= szX + szQ, "the fp32 O tile overlays Kh | Qs");
-  static_assert(sizeof(float) * 10 * C <= szP, "the rel-pos table borrows P's region");
+  static_assert(P_OVER_K || szRel <= szP, "the rel-pos table borrows P's region");
   static_assert(szX % 16 == 0 && szQ % 16 == 0 && szP % 16 == 0, "16-byte carve offsets");
 };
 
@@ -110,7 +122,7 @@ struct FusedPrepArgs {
   int k;
 };
 template <int C, int L, int NW, bool PREP = false>
-__global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wfrag,
+__global__ void __launch_bounds__(NW * 64, (C == 64) ? 4 : 1) window_attn_fused_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wfrag,
                                                                         const float* __restrict__ rel_h, const float* __restrict__ rel_w,
                                                                         bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int ldo, int oc0,
                                                                         const bf16_t* __restrict__ res, int ldr, int h, int w,
@@ -129,7 +141,7 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
   T(*Kh)[LD] = reinterpret_cast<T(*)[LD]>(smem + Cfg::offK);
   T(*Qs)[LD] = reinterpret_cast<T(*)[LD]>(smem + Cfg::offQ);
   T(*Ps)[PLD] = reinterpret_cast<T(*)[PLD]>(smem + Cfg::offP);
-  float(*RelS)[C] = reinterpret_cast<float(*)[C]>(smem + Cfg::offP);          // phases 0-2 only: P's region
+  float(*RelS)[C] = reinterpret_cast<float(*)[C]>(smem + Cfg::offRel);        // phases 0-2 only (C = 256: P's region)
   float(*Os)[OLD] = reinterpret_cast<float(*)[OLD]>(smem + Cfg::offK);        // phase 4 on: overlays Kh | Qs
   float(*red)[2][64] = reinterpret_cast<float(*)[2][64]>(smem + Cfg::offR);   // [max | sum][key half][query]
 
@@ -456,6 +468,7 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
       for (int tl = 0; tl < NTL; ++tl)       // (key tile 7 of the second half does not exist: it aliases the zero row and is masked)
         mma16(s[tl], load8(&Kh[min(16 * (t0 + tl) + lr, ZR)][32 * ks + 8 * g]), qf);
     }
+    if constexpr (Cfg::P_OVER_K) lds_barrier();        // every wave has its S^T tile: Kh and Qs are dead, P may overwrite them
     // lane (q, g) holds keys 16 (t0 + tl) + 4 g + r
     const float scale = rsqrtf((float)C);
     float mx = -3.0e38f;
@@ -498,7 +511,7 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
       float pv[4] = {s[tl][0] * inv, s[tl][1] * inv, s[tl][2] * inv, s[tl][3] * inv};
       store4(&Ps[q][16 * (t0 + tl) + 4 * g], pv);          // (KH == 2: tile 7 = keys 112..127 gets exact zeros)
     }
-    if constexpr (KH == 1) {
+    if constexpr (KH == 1 && Cfg::PKEYS == 128) {          // (not instantiated any more: C = 64 reads its padding keys from the zero row)
       float z[4] = {0.f, 0.f, 0.f, 0.f};
       store4(&Ps[q][112 + 4 * g], z);                      // keys 112..127: contraction padding of P V
     }
@@ -520,11 +533,13 @@ __global__ void __launch_bounds__(NW * 64) window_attn_fused_fwd_kernel(const bf
       for (int m = 0; m < TPW; ++m) a[m] = tr8z(&Xs[0][0], LD, 32 * c4 + 8 * g, 32 * c4 + 8 * g + 4, 16 * (wv * TPW + m), lane, ZR);
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt) {
-        const Frag8<T> b = load8(&Ps[16 * qt + lr][32 * c4 + 8 * g]);
+        // (P rows of 112 keys: the contraction padding 112..127 of the last k-step is read from the zero row of Xs | Vs instead)
+        const Frag8<T> b = load8((Cfg::PKEYS == 128 || 32 * c4 + 8 * g < Cfg::PKEYS) ? &Ps[16 * qt + lr][32 * c4 + 8 * g] : &Xs[ZR][0]);
 #pragma unroll
         for (int m = 0; m < TPW; ++m) mma16(o[m][qt], a[m], b);
       }
     }
+    if constexpr (Cfg::P_OVER_K) lds_barrier();        // every wave is done reading P: O may overwrite it
 #pragma unroll
     for (int m = 0; m < TPW; ++m)
 #pragma unroll

@@ -84,6 +84,14 @@ int main(int argc, char** argv) {
   const double flop = (double)M * 2.0 * C * 3 * C + (double)nwin * 25600.0 * C;
   printf("C=%d B=%d windows=%d %s: event-bracketed min %.2f us median %.2f us  -> %.1f TFLOP/s algorithmic (%.1f %% of 2.5 PF) at the median\n", C, B, nwin,
          cold ? "cold" : "warm", ts[0], ts[N / 2], flop / ts[N / 2] * 1e-6, flop / ts[N / 2] * 1e-6 / 2500.0 * 100.0);
+  {   // output hashes of the last launch (compare builds: identical hashes = identical bits)
+    CKH(hipStreamSynchronize(st));
+    auto hash = [&](void* d, size_t n) { std::vector<unsigned char> hb(n); CKH(hipMemcpy(hb.data(), d, n, hipMemcpyDeviceToHost)); unsigned long long hsh = 1469598103934665603ull;
+      const unsigned long long* p8 = (const unsigned long long*)hb.data(); for (size_t i = 0; i < n / 8; ++i) { hsh ^= p8[i]; hsh *= 1099511628211ull; } return hsh; };
+    printf("  hashes: out %016llx qkv %016llx", hash(dout, full * 16 * 2), hash(dqkv, M * 3 * C * 2));
+    if (prep) printf(" d %016llx xin %016llx", hash(dd, M * C * 2), hash(dxin, full * 16 * 2));
+    printf("\n");
+  }
 #ifdef STAMPS
   std::vector<unsigned long long> hs((size_t)nwin * 8 * 16);
   CKH(hipMemcpy(hs.data(), dst, hs.size() * 8, hipMemcpyDeviceToHost));
