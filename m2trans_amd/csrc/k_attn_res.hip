@@ -222,7 +222,7 @@ struct ResPrepArgs {
   bf16_t* gnk;             // plane k of g_n (written)
 };
 template <int C, int L, int NW, bool DG, bool RC = false, bool PB = false>
-__global__ void __launch_bounds__(NW * 64) window_attn_bwd_res_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
+__global__ void __launch_bounds__(NW * 64, (C == 64) ? 2 : 1) window_attn_bwd_res_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ rel_h,
                                                                       const float* __restrict__ rel_w, const bf16_t* __restrict__ go,
                                                                       int ldg, int gc0, bf16_t* __restrict__ gqkv,
                                                                       bf16_t* __restrict__ win, float* __restrict__ relw, int h, int w,
